@@ -1,0 +1,19 @@
+"""ddsp_piano_amd -- MI355X (gfx950) native synthesis hot path of DDSP-Piano.
+
+Drop-in for the processor group of lrenault/ddsp-piano (ddsp_piano/default_model.py:20-85,
+ddsp_piano/modules/polyphonic_dag.py, ddsp_piano/modules/piano_model.py:160): same Processor /
+ProcessorGroup call signatures, arithmetic in hand-written HIP kernels behind the C-ABI of
+include/ddspp.h.  Nothing else of the reference (control networks, MIDI / audio I/O, training) is
+rebuilt here.
+"""
+from . import core  # noqa: F401
+from .core import exp_sigmoid, exp_tanh  # noqa: F401
+from .effects import FeedbackDelayNetworkApply, Reverb  # noqa: F401
+from .polyphonic_dag import polyphonic_dag  # noqa: F401
+from .processors import Add, Processor, ProcessorGroup  # noqa: F401
+from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiAdd,  # noqa: F401
+                     MultiInharmonic)
+
+__all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
+           'MultiInharmonic', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
+           'FeedbackDelayNetworkApply', 'polyphonic_dag']

@@ -1,0 +1,150 @@
+"""Build + ctypes binding of ``libddspp.so`` (the hand-written HIP kernels, C-ABI in include/ddspp.h).
+
+PyTorch-ROCm is only the buffer carrier: every call passes raw device pointers and the current HIP
+stream.  There is no CPU fallback -- if the shared library is missing or cannot be loaded the
+import of any operator fails loudly.
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import ctypes
+import os
+import shutil
+import subprocess
+import sys
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libddspp.so')
+SOURCES = ['error.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip', 'reverb.hip']
+ARCH = 'gfx950'
+
+DDSPP_OK = 0
+DDSPP_EINVAL = -22
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: cannot build libddspp.so')
+
+
+def _needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, 'ddspp_common.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP translation unit for gfx950 and link libddspp.so in-tree."""
+    if not force and not _needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objdir = os.path.join(_HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+             '-I', _CSRC, '-Wno-unused-value']
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+        srcp = os.path.join(_CSRC, src)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
+                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, 'ddspp_common.h'))):
+            return obj
+        cmd = [hipcc] + flags + ['-x', 'hip', '-c', srcp, '-o', obj]
+        if verbose:
+            print('[ddspp build]', ' '.join(cmd), file=sys.stderr, flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), 'lib')
+    tmp = LIB_PATH + '.tmp'
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + \
+          ['-L', rocm_lib, '-L', '/opt/rocm/lib', '-lrocfft', '-Wl,-rpath,/opt/rocm/lib', '-o', tmp]
+    if verbose:
+        print('[ddspp build]', ' '.join(cmd), file=sys.stderr, flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/ddspp.h
+SIGNATURES = {
+    'ddspp_version': (c_int, []),
+    'ddspp_target_arch': (c_char_p, []),
+    'ddspp_last_error': (c_char_p, []),
+    'ddspp_resample_linear': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    'ddspp_resample_window': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_osc_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ddspp_cos_oscillator_bank': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                          c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_harmonic_synthesis': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                         c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                          c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
+    'ddspp_scale_bias': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_float, c_float,
+                                 c_float, c_void_p]),
+    'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_fir_from_magnitudes': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'ddspp_time_varying_fir': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
+    'ddspp_uniform_noise': (c_int, [c_void_p, c_size_t, c_uint64, c_uint64, c_void_p]),
+    'ddspp_fft_size': (c_int, [c_int, c_int]),
+    'ddspp_fftconv_plan_create': (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'ddspp_fftconv_plan_destroy': (c_int, [c_void_p]),
+    'ddspp_fftconv_workspace_bytes': (c_size_t, [c_void_p]),
+    'ddspp_fftconv_fft_size': (c_int, [c_void_p]),
+    'ddspp_fftconv_execute': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libddspp.so (building it first if hipcc is available and the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(
+                f'libddspp.so is missing at {LIB_PATH} and could not be built ({e}). '
+                'The DDSP-Piano MI355X synthesis path has no CPU fallback: run '
+                '`python -c "import __graft_entry__ as g; g.build()"` on a machine with hipcc.') from e
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f'cannot load {LIB_PATH}: {e}. No CPU fallback exists.') from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ddspp_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    """Map a C-ABI return code onto the exception type ddsp raises for the same mistake."""
+    if rc == DDSPP_OK:
+        return
+    msg = last_error()
+    if rc == DDSPP_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(f'libddspp error {rc}: {msg}')

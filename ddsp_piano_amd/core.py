@@ -1,0 +1,564 @@
+"""Host side of the hot path: the ``ddsp.core`` functions the reference calls, same names and
+argument meaning, evaluated by the HIP kernels of libddspp on torch-ROCm buffers.
+
+Reference call sites (all under /root/reference/ddsp_piano/modules):
+  inharm_synth.py:20-46   get_inharmonic_freq
+  inharm_synth.py:49-84   cos_oscillator_bank            (core.remove_above_nyquist, core.angular_cumsum)
+  inharm_synth.py:87-127  harmonic_synthesis             (core.get_harmonic_frequencies, core.resample)
+  filtered_noise_synth.py:41-42  core.frequency_filter   (frequency_impulse_response, fft_convolve)
+  fdn_reverb.py:409       fft_convolve
+Everything here is float32; Python only validates shapes (raising what ddsp raises), builds the
+small index / window tables with the float32 arithmetic of the TF kernels, and enqueues kernels on
+the current HIP stream.
+"""
+from __future__ import annotations
+
+import atexit
+import ctypes
+import functools
+import math
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F32 = np.float32
+_TWO_PI_F32 = F32(2.0 * np.pi)
+
+
+# ----------------------------------------------------------------------------------------------------
+# buffer plumbing
+# ----------------------------------------------------------------------------------------------------
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('ddsp_piano_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                           'there is no CPU fallback for the synthesis path.')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def tf_float32(x, device=None):
+    """ddsp.core.tf_float32: cast to float32 (and make the buffer a contiguous device tensor)."""
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda or (device is None and not torch.cuda.is_available()):
+            # already resident (or: no GPU at all -- host-logic tests; kernels refuse CPU buffers)
+            return x.to(dtype=torch.float32).contiguous()
+        return x.to(device=device or default_device(), dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.asarray(x, dtype=np.float32), device=device or default_device()).contiguous()
+
+
+def _ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError('libddspp kernels take device buffers only: got a CPU tensor '
+                           '(there is no CPU fallback for the synthesis path)')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _lib_():
+    return _lib.load()
+
+
+# ----------------------------------------------------------------------------------------------------
+# scale functions (usable as `scale_fn=`; the kernels recognise them through `_ddspp_kind`)
+# ----------------------------------------------------------------------------------------------------
+def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
+    """ddsp.core.exp_sigmoid: ``max_value * sigmoid(x) ** log(exponent) + threshold``."""
+    x = tf_float32(x)
+    y = torch.empty_like(x)
+    _lib.check(_lib_().ddspp_scale_bias(_ptr(x), _ptr(y), x.numel(), 0.0, 1, exponent, max_value, threshold,
+                                        1.0, _stream()))
+    return y
+
+
+exp_sigmoid._ddspp_kind = (1, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0))
+
+
+def exp_tanh(x, max_value=2.0, exponent=10.0, gain=1.0, threshold=1e-7):
+    """ddsp_piano/modules/inharm_synth.py:13-17."""
+    x = tf_float32(x)
+    y = torch.empty_like(x)
+    _lib.check(_lib_().ddspp_scale_bias(_ptr(x), _ptr(y), x.numel(), 0.0, 2, exponent, max_value, threshold,
+                                        gain, _stream()))
+    return y
+
+
+exp_tanh._ddspp_kind = (2, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0))
+
+
+def scale_kind(scale_fn):
+    """(kind, params) for the fused control kernels, or None for an arbitrary python callable."""
+    if scale_fn is None:
+        return 0, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0)
+    fn = scale_fn
+    kw = {}
+    if isinstance(fn, functools.partial):
+        if fn.args:
+            return None
+        kw = dict(fn.keywords)
+        fn = fn.func
+    kind = getattr(fn, '_ddspp_kind', None)
+    if kind is None:
+        return None
+    params = dict(kind[1])
+    for k, v in kw.items():
+        if k not in params:
+            return None
+        params[k] = float(v)
+    return kind[0], params
+
+
+def safe_divide(numerator, denominator, eps=1e-7):
+    """ddsp.core.safe_divide."""
+    numerator, denominator = tf_float32(numerator), tf_float32(denominator)
+    safe = torch.where(denominator == 0.0, torch.full_like(denominator, eps), denominator)
+    return numerator / safe
+
+
+def remove_above_nyquist(frequency_envelopes, amplitude_envelopes, sample_rate=16000):
+    """ddsp.core.remove_above_nyquist (``>=``)."""
+    f, a = tf_float32(frequency_envelopes), tf_float32(amplitude_envelopes)
+    return torch.where(f >= sample_rate / 2.0, torch.zeros_like(a), a)
+
+
+def get_harmonic_frequencies(frequencies, n_harmonics):
+    """ddsp.core.get_harmonic_frequencies: ``f0 * linspace(1, H, H)``."""
+    frequencies = tf_float32(frequencies)
+    ratios = torch.linspace(1.0, float(n_harmonics), int(n_harmonics), device=frequencies.device,
+                            dtype=torch.float32)
+    return frequencies * ratios[None, None, :]
+
+
+def get_inharmonic_freq(f0_hz, inharm_coef, n_harmonics):
+    """ddsp_piano/modules/inharm_synth.py:20-46 (each op separately rounded, as in the reference)."""
+    f0_hz, inharm_coef = tf_float32(f0_hz), tf_float32(inharm_coef)
+    k = torch.linspace(1.0, float(n_harmonics), int(n_harmonics), device=f0_hz.device,
+                       dtype=torch.float32)[None, None, :]
+    inharm_factor = k * k                                  # tf.math.pow(int_multiplier, 2)
+    inharm_factor = inharm_factor * inharm_coef + 1.0
+    inharm_factor = torch.sqrt(inharm_factor)
+    inharmonic_freq = f0_hz * k * inharm_factor
+    harmonic_shifts = inharm_factor - 1.0
+    return inharmonic_freq, harmonic_shifts
+
+
+def midi_to_hz(notes):
+    """ddsp.core.midi_to_hz."""
+    return 440.0 * (2.0 ** ((np.asarray(notes, dtype=np.float64) - 69.0) / 12.0))
+
+
+# ----------------------------------------------------------------------------------------------------
+# host-built tables (float32 arithmetic of the TF kernels)
+# ----------------------------------------------------------------------------------------------------
+def _hann_window_np(n, periodic=True):
+    """tf.signal.hann_window in float32: ``0.5 - 0.5 * cos(2*pi*i / (n + periodic*even - 1))``."""
+    n = int(n)
+    if n == 1:
+        return np.ones([1], F32)
+    even = 1 - n % 2
+    denom = F32(n + int(periodic) * even - 1)
+    count = np.arange(n, dtype=F32)
+    cos_arg = ((_TWO_PI_F32 * count).astype(F32) / denom).astype(F32)
+    return (F32(0.5) - (F32(0.5) * np.cos(cos_arg, dtype=F32)).astype(F32)).astype(F32)
+
+
+@functools.lru_cache(maxsize=64)
+def _linear_tables_np(n_frames, n_timesteps):
+    """Legacy bilinear (align_corners=False, no half-pixel centres) source rows and weights."""
+    scale = F32(n_frames) / F32(n_timesteps)
+    pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
+    fl = np.floor(pos)
+    lo = fl.astype(np.int32)
+    hi = np.minimum(np.ceil(pos).astype(np.int32), n_frames - 1).astype(np.int32)
+    w = (pos - fl).astype(F32)
+    aligned = False
+    if n_timesteps % n_frames == 0:
+        u = n_timesteps // n_frames
+        aligned = bool(np.array_equal(lo, (np.arange(n_timesteps) // u).astype(np.int32)))
+    return lo, hi, w, aligned
+
+
+_table_cache = {}
+_table_lock = threading.Lock()
+
+
+def _cached(key, builder):
+    with _table_lock:
+        val = _table_cache.get(key)
+    if val is None:
+        val = builder()
+        with _table_lock:
+            _table_cache[key] = val
+    return val
+
+
+def linear_tables(n_frames, n_timesteps, device):
+    def build():
+        lo, hi, w, aligned = _linear_tables_np(int(n_frames), int(n_timesteps))
+        return (torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device),
+                torch.from_numpy(w).to(device), aligned)
+    return _cached(('lin', int(n_frames), int(n_timesteps), str(device)), build)
+
+
+def hann_window(n, device):
+    return _cached(('hann', int(n), str(device)),
+                   lambda: torch.from_numpy(_hann_window_np(int(n))).to(device))
+
+
+def _apply_window_rows(ir, window_size):
+    """ddsp.core.apply_window_to_impulse_response(causal=False) applied along the last axis.
+
+    ``ir`` is float64 [..., ir_size] (zero phase); the float32 Hann window is the one TF builds.
+    """
+    ir_size = int(ir.shape[-1])
+    if window_size <= 0 or window_size > ir_size:
+        window_size = ir_size
+    window = _hann_window_np(window_size).astype(np.float64)
+    padding = ir_size - window_size
+    if padding > 0:
+        half_idx = (window_size + 1) // 2
+        window = np.concatenate([window[half_idx:], np.zeros([padding]), window[:half_idx]], axis=0)
+    else:
+        window = np.fft.fftshift(window)
+    ir = window * ir
+    if padding > 0:
+        first_half_start = (ir_size - (half_idx - 1)) + 1
+        second_half_end = half_idx + 1
+        ir = np.concatenate([ir[..., first_half_start:], ir[..., :second_half_end]], axis=-1)
+    else:
+        ir = np.fft.fftshift(ir, axes=-1)
+    return ir
+
+
+@functools.lru_cache(maxsize=16)
+def _fir_matrix_np(n_bands, window_size):
+    """M[K, Lw] with frequency_impulse_response(mag) == mag @ M (real inverse DFT x window, shifted)."""
+    if n_bands < 2:
+        raise ValueError('frequency_impulse_response needs at least 2 frequency bands')
+    ir_size = 2 * (n_bands - 1)
+    k = np.arange(n_bands, dtype=np.float64)[:, None]
+    j = np.arange(ir_size, dtype=np.float64)[None, :]
+    coef = np.full([n_bands, 1], 2.0)
+    coef[0, 0] = 1.0
+    coef[-1, 0] = 1.0
+    basis = coef * np.cos(2.0 * np.pi * k * j / ir_size) / ir_size       # irfft of unit magnitudes
+    return np.ascontiguousarray(_apply_window_rows(basis, int(window_size)).astype(F32))
+
+
+def fir_matrix(n_bands, window_size, device):
+    return _cached(('firM', int(n_bands), int(window_size), str(device)),
+                   lambda: torch.from_numpy(_fir_matrix_np(int(n_bands), int(window_size))).to(device))
+
+
+# ----------------------------------------------------------------------------------------------------
+# upsamplers
+# ----------------------------------------------------------------------------------------------------
+def upsample_with_windows(inputs, n_timesteps, add_endpoint=True):
+    """ddsp.core.upsample_with_windows (overlapping Hann windows)."""
+    x = tf_float32(inputs)
+    if x.dim() != 3:
+        raise ValueError('Upsample_with_windows() only supports 3 dimensions, not {}.'.format(tuple(x.shape)))
+    if not add_endpoint:
+        raise NotImplementedError('add_endpoint=False is not on the DDSP-Piano path')
+    n_frames = int(x.shape[1]) + 1
+    n_intervals = n_frames - 1
+    if n_frames >= n_timesteps:
+        raise ValueError('Upsample with windows cannot be used for downsampling'
+                         'More input frames ({}) than output timesteps ({})'.format(n_frames, n_timesteps))
+    if n_timesteps % n_intervals != 0.0:
+        raise ValueError('n_timesteps / n_intervals must be an integer')
+    hop = n_timesteps // n_intervals
+    b, t, c = x.shape
+    y = torch.empty((b, n_timesteps, c), dtype=torch.float32, device=x.device)
+    win = hann_window(2 * hop, x.device)
+    _lib.check(_lib_().ddspp_resample_window(_ptr(x), _ptr(win), _ptr(y), b, t, c, hop, _stream()))
+    return y
+
+
+def resample(inputs, n_timesteps, method='linear', add_endpoint=True):
+    """ddsp.core.resample -- call sites inharm_synth.py:117-119."""
+    x = tf_float32(inputs)
+    is_1d, is_2d = x.dim() == 1, x.dim() == 2
+    if is_1d:
+        x = x[None, :, None]
+    if is_2d:
+        x = x[:, :, None]
+    x = x.contiguous()
+    n_timesteps = int(n_timesteps)
+    if method == 'linear':
+        if not add_endpoint:
+            raise NotImplementedError('align_corners=True resize is not on the DDSP-Piano path')
+        b, t, c = x.shape
+        lo, hi, w, _ = linear_tables(t, n_timesteps, x.device)
+        y = torch.empty((b, n_timesteps, c), dtype=torch.float32, device=x.device)
+        _lib.check(_lib_().ddspp_resample_linear(_ptr(x), _ptr(lo), _ptr(hi), _ptr(w), _ptr(y), b, t, c,
+                                                 n_timesteps, _stream()))
+    elif method == 'window':
+        y = upsample_with_windows(x, n_timesteps, add_endpoint)
+    elif method in ('nearest', 'cubic'):
+        raise NotImplementedError(f"resample method '{method}' is not used by DDSP-Piano")
+    else:
+        raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+            method, "['nearest', 'linear', 'cubic', 'window']"))
+    if is_1d:
+        y = y[0, :, 0]
+    if is_2d:
+        y = y[:, :, 0]
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# oscillator bank
+# ----------------------------------------------------------------------------------------------------
+def _osc_workspace(rows, n_samples, n_osc, device):
+    nbytes = int(_lib_().ddspp_osc_workspace_bytes(rows, n_samples, n_osc))
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), nbytes
+
+
+def cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=16000, sum_sinusoids=True,
+                        use_angular_cumsum=False, spans=0):
+    """ddsp_piano/modules/inharm_synth.py:49-84.  [B, N, H] envelopes -> [B, N] (or [B, N, H])."""
+    fe, ae = tf_float32(frequency_envelopes), tf_float32(amplitude_envelopes)
+    if fe.dim() != 3 or fe.shape != ae.shape:
+        raise ValueError('frequency_envelopes {} and amplitude_envelopes {} must both be '
+                         '[batch, n_samples, n_sinusoids]'.format(tuple(fe.shape), tuple(ae.shape)))
+    b, n, h = fe.shape
+    pad = (-n) % 8
+    if pad:       # the kernel walks 8-sample blocks: zero-extend the envelopes and crop the audio
+        fe = torch.nn.functional.pad(fe, (0, 0, 0, pad))
+        ae = torch.nn.functional.pad(ae, (0, 0, 0, pad))
+    npad = n + pad
+    out = torch.empty((b, npad) if sum_sinusoids else (b, npad, h), dtype=torch.float32, device=fe.device)
+    ws, nbytes = _osc_workspace(b, npad, h, fe.device)
+    _lib.check(_lib_().ddspp_cos_oscillator_bank(_ptr(fe), _ptr(ae), _ptr(out), b, npad, h, float(sample_rate),
+                                                 int(bool(sum_sinusoids)), int(bool(use_angular_cumsum)),
+                                                 int(spans), _ptr(ws), nbytes, _stream()))
+    return out[:, :n].contiguous() if pad else out
+
+
+def fused_synthesis_supported(n_frames, n_samples):
+    """True when harmonic_synthesis can run straight from frame controls."""
+    if n_samples % n_frames != 0:
+        return False
+    u = n_samples // n_frames
+    if u % 8 != 0 or n_frames + 1 >= n_samples:
+        return False
+    return _linear_tables_np(int(n_frames), int(n_samples))[3]
+
+
+def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_samples,
+                             sample_rate, use_angular_cumsum, spans=0, out=None):
+    """MultiInharmonic.get_signal for rows [R, T, .]: all sub-strings, envelopes never materialised."""
+    r, t, s = f0_hz.shape
+    h = harmonic_distribution.shape[-1]
+    u = n_samples // t
+    dev = f0_hz.device
+    _, _, wlin, _ = linear_tables(t, n_samples, dev)
+    whann = hann_window(2 * u, dev)
+    if out is None:
+        out = torch.empty((r, n_samples), dtype=torch.float32, device=dev)
+    ws, nbytes = _osc_workspace(r, n_samples, s * h, dev)
+    _lib.check(_lib_().ddspp_harmonic_synthesis(
+        _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
+        _ptr(harmonic_shifts) if harmonic_shifts is not None else ctypes.c_void_p(0),
+        _ptr(wlin), _ptr(whann), _ptr(out), r, t, s, h, u, float(sample_rate),
+        int(bool(use_angular_cumsum)), int(spans), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_distribution=None,
+                       n_samples=64000, sample_rate=16000, amp_resample_method='window', sum_sinusoids=True,
+                       use_angular_cumsum=False):
+    """ddsp_piano/modules/inharm_synth.py:87-127."""
+    frequencies = tf_float32(frequencies)
+    amplitudes = tf_float32(amplitudes)
+    if frequencies.dim() != 3 or amplitudes.dim() != 3:
+        raise ValueError('frequencies and amplitudes must be [batch, n_frames, 1]')
+    b, t, _ = frequencies.shape
+    if harmonic_distribution is not None:
+        harmonic_distribution = tf_float32(harmonic_distribution)
+        n_harmonics = int(harmonic_distribution.shape[-1])
+    else:
+        n_harmonics = 1
+    if harmonic_shifts is not None:
+        harmonic_shifts = tf_float32(harmonic_shifts)
+    n_samples = int(n_samples)
+
+    fused_ok = (sum_sinusoids and amp_resample_method == 'window' and frequencies.shape[-1] == 1
+                and amplitudes.shape[-1] == 1 and fused_synthesis_supported(t, n_samples)
+                and (harmonic_shifts is None or tuple(harmonic_shifts.shape) == (b, t, n_harmonics)))
+    if fused_ok:
+        hd = harmonic_distribution if harmonic_distribution is not None else \
+            torch.ones((b, t, 1), dtype=torch.float32, device=frequencies.device)
+        return harmonic_synthesis_fused(frequencies, amplitudes.reshape(b, t).contiguous(), hd,
+                                        harmonic_shifts, n_samples, sample_rate, use_angular_cumsum)
+
+    # general route: the reference's three operators, one kernel each
+    harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)       # :106
+    if harmonic_shifts is not None:
+        harmonic_frequencies = harmonic_frequencies * (1.0 + harmonic_shifts)       # :108
+    if harmonic_distribution is not None:
+        harmonic_amplitudes = amplitudes * harmonic_distribution                    # :112
+    else:
+        harmonic_amplitudes = amplitudes
+    frequency_envelopes = resample(harmonic_frequencies, n_samples)                  # :117
+    amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method)  # :118
+    return cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=sample_rate,
+                               sum_sinusoids=sum_sinusoids, use_angular_cumsum=use_angular_cumsum)
+
+
+# ----------------------------------------------------------------------------------------------------
+# FilteredNoise: impulse responses and the time-varying FIR
+# ----------------------------------------------------------------------------------------------------
+def frequency_impulse_response(magnitudes, window_size=0):
+    """ddsp.core.frequency_impulse_response: [..., K] magnitudes -> [..., Lw] causal linear-phase FIRs."""
+    mags = tf_float32(magnitudes)
+    k = int(mags.shape[-1])
+    m = fir_matrix(k, int(window_size), mags.device)
+    lw = int(m.shape[1])
+    frames = mags.numel() // k
+    ir = torch.empty(tuple(mags.shape[:-1]) + (lw,), dtype=torch.float32, device=mags.device)
+    _lib.check(_lib_().ddspp_fir_from_magnitudes(_ptr(mags), _ptr(m), _ptr(ir), frames, k, lw, _stream()))
+    return ir
+
+
+def get_fft_size(frame_size, ir_size, power_of_2=True):
+    """ddsp.core.get_fft_size."""
+    convolved_frame_size = ir_size + frame_size - 1
+    if power_of_2:
+        return int(2 ** math.ceil(math.log2(convolved_frame_size)))
+    return int(convolved_frame_size)
+
+
+_plan_cache = {}
+_plan_lock = threading.Lock()
+
+
+def _fftconv_plan(b, b_ir, n, l, device):
+    key = (b, b_ir, n, l, str(device))
+    with _plan_lock:
+        plan = _plan_cache.get(key)
+        if plan is None:
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(_lib_().ddspp_fftconv_plan_create(b, b_ir, n, l, ctypes.byref(handle)))
+            plan = handle
+            _plan_cache[key] = plan
+    return plan
+
+
+@atexit.register
+def _destroy_plans():
+    try:
+        lib = _lib_()
+    except Exception:  # noqa: BLE001
+        return
+    for plan in _plan_cache.values():
+        lib.ddspp_fftconv_plan_destroy(plan)
+    _plan_cache.clear()
+
+
+def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False, add_dry=False):
+    b, n = audio.shape
+    b_ir, l = ir.shape
+    if padding == 'same':
+        out_len = n
+    elif padding == 'valid':
+        out_len = l + n - 1
+    else:
+        raise ValueError('Padding must be \'valid\' or \'same\', instead of {}.'.format(padding))
+    plan = _fftconv_plan(b, b_ir, n, l, audio.device)
+    lib = _lib_()
+    nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=audio.device)
+    out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
+    _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
+                                         int(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
+                                         nbytes, _stream()))
+    return out
+
+
+def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1):
+    """ddsp.core.fft_convolve -- audio [B, N]; impulse_response [B, L] or [B, F, L].
+
+    F == 1 goes through rocFFT exactly as the reference does (fft_size = 2**ceil(log2(N + L - 1)));
+    F > 1 (one FIR per audio frame, the FilteredNoise case) is the direct time-varying FIR kernel,
+    equal to the reference's framed FFT convolution + overlap-add up to float32 round-off.
+    """
+    audio, ir = tf_float32(audio), tf_float32(impulse_response)
+    if audio.dim() != 2:
+        raise ValueError('audio must be [batch, n_samples]')
+    if ir.dim() == 2:
+        ir = ir[:, None, :]
+    if ir.dim() != 3:
+        raise ValueError('impulse_response must be [batch, ir_size] or [batch, n_frames, ir_size]')
+    batch_size_ir, n_ir_frames, ir_size = ir.shape
+    batch_size, audio_size = audio.shape
+    if batch_size_ir != batch_size and not (batch_size_ir == 1 and batch_size > 1):
+        raise ValueError('Batch size of audio ({}) and impulse response ({}) must be the same.'.format(
+            batch_size, batch_size_ir))
+    frame_size = int(math.ceil(audio_size / n_ir_frames))
+    n_audio_frames = int(math.ceil(audio_size / frame_size))
+    if n_audio_frames != n_ir_frames:
+        raise ValueError('Number of Audio frames ({}) and impulse response frames ({}) do not match. '
+                         'For small hop size = ceil(audio_size / n_ir_frames), number of impulse '
+                         'response frames must be a multiple of the audio size.'.format(
+                             n_audio_frames, n_ir_frames))
+    if padding not in ('same', 'valid'):
+        raise ValueError('Padding must be \'valid\' or \'same\', instead of {}.'.format(padding))
+    if n_ir_frames == 1:
+        return _fft_convolve_single(audio, ir[:, 0, :].contiguous(), padding, delay_compensation)
+    if padding != 'same':
+        raise NotImplementedError("framed fft_convolve supports padding='same' only")
+    if batch_size_ir == 1 and batch_size > 1:
+        ir = ir.expand(batch_size, -1, -1)
+    ir = ir.contiguous()
+    padded = n_ir_frames * frame_size
+    x = audio if padded == audio_size else torch.nn.functional.pad(audio, (0, padded - audio_size))
+    x = x.contiguous()
+    out = torch.empty((batch_size, padded), dtype=torch.float32, device=audio.device)
+    _lib.check(_lib_().ddspp_time_varying_fir(_ptr(x), _ptr(ir), _ptr(out), batch_size, padded, n_ir_frames,
+                                              ir_size, int(delay_compensation), _stream()))
+    return out if padded == audio_size else out[:, :audio_size].contiguous()
+
+
+def frequency_filter(audio, magnitudes, window_size=0, padding='same'):
+    """ddsp.core.frequency_filter -- call site filtered_noise_synth.py:41-42."""
+    impulse_response = frequency_impulse_response(magnitudes, window_size=window_size)
+    return fft_convolve(audio, impulse_response, padding=padding)
+
+
+def uniform_noise(shape, seed=0, offset=0, device=None):
+    """U(-1, 1) noise from the library's Philox4x32-10 (stand-in for the unseeded tf.random.uniform)."""
+    device = device or default_device()
+    n = int(np.prod(shape))
+    npad = (n + 3) // 4 * 4
+    out = torch.empty(npad, dtype=torch.float32, device=device)
+    _lib.check(_lib_().ddspp_uniform_noise(_ptr(out), npad, int(seed) & (2 ** 64 - 1),
+                                           int(offset) & (2 ** 64 - 1), _stream()))
+    return out[:n].reshape(shape)
+
+
+def add_signals(signals):
+    """MultiAdd.get_signal / processors.Add: ((s0 + s1) + s2) ... in one pass."""
+    sigs = [tf_float32(s) for s in signals]
+    if len(sigs) == 1:
+        return sigs[0]
+    shape = torch.broadcast_shapes(*[s.shape for s in sigs])
+    sigs = [s.expand(shape).contiguous() for s in sigs]
+    n = sigs[0].numel()
+    if n % 4 != 0:
+        out = sigs[0]
+        for s in sigs[1:]:
+            out = out + s
+        return out
+    ptrs = torch.tensor([s.data_ptr() for s in sigs], dtype=torch.int64, device=sigs[0].device)
+    out = torch.empty(shape, dtype=torch.float32, device=sigs[0].device)
+    _lib.check(_lib_().ddspp_add_signals(_ptr(ptrs), len(sigs), _ptr(out), n, _stream()))
+    return out

@@ -1,0 +1,255 @@
+// Frame-rate control conditioning (get_controls of the processors) and the signal mixer.
+//
+// Replaces InHarmonic.get_controls / MultiInharmonic.get_controls
+// (ddsp_piano/modules/inharm_synth.py:167-219, :254-270), get_inharmonic_freq (:20-46),
+// ddsp.synths.FilteredNoise.get_controls, the scale functions ddsp.core.exp_sigmoid and exp_tanh
+// (inharm_synth.py:13-17) and MultiAdd.get_signal (:308-309).
+// One wavefront conditions one (row, frame): lanes run over harmonics (coalesced 256-byte reads of
+// harmonic_distribution[row, t, :]), the normalisation sum is a wavefront reduction.
+#include "ddspp_common.h"
+
+namespace ddspp {
+
+enum { SCALE_NONE = 0, SCALE_EXP_SIGMOID = 1, SCALE_EXP_TANH = 2 };
+
+struct ScaleFn {
+    int kind;
+    float log_exponent;   // float32(log(exponent))
+    float max_value;
+    float threshold;
+    float gain;           // exp_tanh only
+};
+
+__device__ __forceinline__ float apply_scale(const ScaleFn& s, float x) {
+    if (s.kind == SCALE_EXP_SIGMOID) {
+        // max_value * sigmoid(x) ** log(exponent) + threshold          (ddsp.core.exp_sigmoid)
+        const float sg = 1.0f / (1.0f + expf(-x));
+        return s.max_value * powf(sg, s.log_exponent) + s.threshold;
+    }
+    if (s.kind == SCALE_EXP_TANH) {
+        // max_value * (0.5 * (tanh(gain * x) + 1)) ** log(exponent) + threshold   (inharm_synth.py:13-17)
+        const float pt = 0.5f * (tanhf(s.gain * x) + 1.0f);
+        return s.max_value * powf(pt, s.log_exponent) + s.threshold;
+    }
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct InharmParams {
+    const float* __restrict__ amplitudes;             // [R, T]      raw
+    const float* __restrict__ harmonic_distribution;  // [R, T, H]   raw
+    const float* __restrict__ inharm_coef;            // [R, T]
+    const float* __restrict__ f0_hz;                  // [R, T, S]
+    float* __restrict__ amp_out;                      // [R, T]
+    float* __restrict__ hd_out;                       // [R, T, H]
+    float* __restrict__ shifts_out;                   // [R, T, H]
+    int R, T, H, S;
+    float nyquist, min_frequency, n_substrings;
+    int normalize_after_nyquist_cut, normalize_below_nyquist;
+    ScaleFn scale;
+};
+
+template <int HPL>
+__global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmParams p) {
+    const int lane = threadIdx.x & 63;
+    const size_t frame = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= (size_t)p.R * p.T) return;
+    const int H = p.H;
+    const float f0 = p.f0_hz[frame * p.S];                              // f0_hz[..., 0:1]  (:264)
+    const float inharm = fmaxf(p.inharm_coef[frame], 0.0f);             // :183
+    float amp = apply_scale(p.scale, p.amplitudes[frame]);              // :185
+    float hd[HPL], shift[HPL], freq[HPL];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HPL; ++j) {
+        const int k = lane + 64 * j;
+        hd[j] = 0.0f;
+        shift[j] = 0.0f;
+        freq[j] = 0.0f;
+        if (k < H) {
+            hd[j] = apply_scale(p.scale, p.harmonic_distribution[frame * H + k]);   // :186
+            const float m = (float)(k + 1);
+            float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
+            g = g * inharm + 1.0f;                 //                                        :38
+            g = sqrtf(g);                          //                                        :39
+            freq[j] = (f0 * m) * g;                // f0_hz * int_multiplier * inharm_factor :42
+            shift[j] = g - 1.0f;                   //                                        :44
+            sum += hd[j];
+        }
+    }
+    if (!p.normalize_after_nyquist_cut) {                                // :194-198
+        const float tot = wave_sum(sum);
+        const float den = tot == 0.0f ? 1e-7f : tot;                     // core.safe_divide
+        sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) {
+            hd[j] = hd[j] / den;
+            sum += hd[j];
+        }
+    }
+    if (p.normalize_below_nyquist) {                                     // :200-208
+        sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) {
+            if (freq[j] >= p.nyquist) hd[j] = 0.0f;                      // core.remove_above_nyquist
+            sum += hd[j];
+        }
+        amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
+    }
+    if (p.normalize_after_nyquist_cut) {                                 // :210-214
+        const float tot = wave_sum(sum);
+        const float den = tot == 0.0f ? 1e-7f : tot;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) hd[j] = hd[j] / den;
+    }
+    amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
+#pragma unroll
+    for (int j = 0; j < HPL; ++j) {
+        const int k = lane + 64 * j;
+        if (k < H) {
+            p.hd_out[frame * H + k] = hd[j];
+            p.shifts_out[frame * H + k] = shift[j];
+        }
+    }
+    if (lane == 0) p.amp_out[frame] = amp;
+}
+
+__global__ void __launch_bounds__(256) scale_bias_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       size_t n, float bias, ScaleFn s) {
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256)
+        y[g] = apply_scale(s, x[g] + bias);
+}
+
+// out = (((s0 + s1) + s2) + ...) elementwise: python `sum(signals.values())` of MultiAdd.
+__global__ void __launch_bounds__(256) add_signals_kernel(const float* const* __restrict__ srcs, int nsrc,
+                                                        float* __restrict__ out, size_t n4) {
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n4; g += (size_t)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<const float4*>(srcs[0])[g];
+        for (int s = 1; s < nsrc; ++s) {
+            const float4 v = reinterpret_cast<const float4*>(srcs[s])[g];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[g] = acc;
+    }
+}
+
+// dry[b, n] = sum over voices p of (noise[b, p, n] + additive[b, p, n]), accumulated in the order of
+// the polyphonic DAG: ((add + noise_p) + additive_p)   (polyphonic_dag.py:28-37)
+__global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __restrict__ additive,
+                                                           const float* __restrict__ noise,
+                                                           float* __restrict__ out, int B, int P,
+                                                           int N, int out_stride) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)B * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < P; ++v) {
+            const size_t off = ((size_t)b * P + v) * n4 + i;
+            if (noise) {
+                const float4 z = reinterpret_cast<const float4*>(noise)[off];
+                if (v == 0) acc = z;
+                else { acc.x += z.x; acc.y += z.y; acc.z += z.z; acc.w += z.w; }
+            }
+            const float4 a = reinterpret_cast<const float4*>(additive)[off];
+            if (v == 0 && !noise) acc = a;
+            else { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        }
+        reinterpret_cast<float4*>(out + (size_t)b * out_stride)[i] = acc;
+    }
+}
+
+static unsigned stream_grid(size_t total) {
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = 256 * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace ddspp
+
+using namespace ddspp;
+
+extern "C" {
+
+// InHarmonic.get_controls / MultiInharmonic.get_controls  -- inharm_synth.py:167-219, :254-270.
+// scale_kind: 0 none, 1 core.exp_sigmoid, 2 exp_tanh; (exponent, max_value, threshold, gain) are the
+// keyword defaults of those functions unless the caller overrides them.
+int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
+                              const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                              float* harmonic_distribution_out, float* harmonic_shifts_out, int R, int T,
+                              int H, int S, float sample_rate, float min_frequency, int scale_kind,
+                              float exponent, float max_value, float threshold, float gain,
+                              int normalize_after_nyquist_cut, int normalize_below_nyquist,
+                              hipStream_t stream) {
+    DDSPP_REQUIRE(amplitudes && harmonic_distribution && inharm_coef && f0_hz && amplitudes_out &&
+                      harmonic_distribution_out && harmonic_shifts_out,
+                  "inharmonic_controls: null buffer");
+    DDSPP_REQUIRE(R > 0 && T > 0 && H > 0 && S > 0, "inharmonic_controls: bad dims");
+    DDSPP_REQUIRE(H <= 512, "inharmonic_controls: n_harmonics=%d exceeds 512", H);
+    DDSPP_REQUIRE(scale_kind >= 0 && scale_kind <= 2, "inharmonic_controls: unknown scale_fn %d", scale_kind);
+    InharmParams p{};
+    p.amplitudes = amplitudes; p.harmonic_distribution = harmonic_distribution;
+    p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
+    p.amp_out = amplitudes_out; p.hd_out = harmonic_distribution_out; p.shifts_out = harmonic_shifts_out;
+    p.R = R; p.T = T; p.H = H; p.S = S;
+    p.nyquist = sample_rate / 2.0f; p.min_frequency = min_frequency; p.n_substrings = (float)S;
+    p.normalize_after_nyquist_cut = normalize_after_nyquist_cut;
+    p.normalize_below_nyquist = normalize_below_nyquist;
+    p.scale = ScaleFn{scale_kind, logf(exponent), max_value, threshold, gain};
+    const size_t frames = (size_t)R * T;
+    const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
+    const int hpl = (H + 63) / 64;
+    if (hpl <= 1) hipLaunchKernelGGL(inharmonic_controls_kernel<1>, grid, block, 0, stream, p);
+    else if (hpl <= 2) hipLaunchKernelGGL(inharmonic_controls_kernel<2>, grid, block, 0, stream, p);
+    else if (hpl <= 4) hipLaunchKernelGGL(inharmonic_controls_kernel<4>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(inharmonic_controls_kernel<8>, grid, block, 0, stream, p);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// ddsp.synths.FilteredNoise.get_controls: magnitudes = scale_fn(magnitudes + initial_bias)
+int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_kind, float exponent,
+                     float max_value, float threshold, float gain, hipStream_t stream) {
+    DDSPP_REQUIRE(x && y, "scale_bias: null buffer");
+    DDSPP_REQUIRE(scale_kind >= 0 && scale_kind <= 2, "scale_bias: unknown scale_fn %d", scale_kind);
+    if (n == 0) return DDSPP_OK;
+    ScaleFn s{scale_kind, logf(exponent), max_value, threshold, gain};
+    hipLaunchKernelGGL(scale_bias_kernel, dim3(stream_grid(n)), dim3(256), 0, stream, x, y, n, bias, s);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// MultiAdd.get_signal / ddsp.processors.Add.get_signal  -- inharm_synth.py:308-309.
+// `srcs` is a DEVICE array of nsrc device pointers, each to n floats (n % 4 == 0, 16-byte aligned).
+int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, hipStream_t stream) {
+    DDSPP_REQUIRE(srcs && out && nsrc >= 1, "add_signals: bad arguments");
+    DDSPP_REQUIRE(n % 4 == 0, "add_signals: n must be a multiple of 4");
+    if (n == 0) return DDSPP_OK;
+    hipLaunchKernelGGL(add_signals_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, stream, srcs, nsrc, out,
+                       n / 4);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The `add` chain of polyphonic_dag.py:28-37 for all voices at once: additive/noise are
+// [B, P, N]; out rows are written with a stride (so the dry mix can land in a zero-padded FFT
+// buffer of the reverb).  noise may be null (dry additive only).
+int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
+                         int out_stride, hipStream_t stream) {
+    DDSPP_REQUIRE(additive && out, "polyphonic_mix: null buffer");
+    DDSPP_REQUIRE(B > 0 && P > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N,
+                  "polyphonic_mix: bad dims");
+    hipLaunchKernelGGL(polyphonic_mix_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
+                       additive, noise, out, B, P, N, out_stride);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// Shared host/device helpers for libddspp (gfx950 / CDNA4 only).
+//
+// Arithmetic contract: every float32 operation that feeds the oscillator
+// phase is a separately rounded IEEE op in the order the reference writes it
+// (ddsp_piano/modules/inharm_synth.py:49-127 + ddsp.core.angular_cumsum).  The translation units
+// are compiled with -ffp-contract=off; fused multiply-adds appear only where they are provably
+// exact (div_const, mod_2pi below).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DDSPP_OK 0
+#define DDSPP_EINVAL (-22)
+#define DDSPP_ENOMEM (-12)
+#define DDSPP_EHIP (-5)
+#define DDSPP_EFFT (-6)
+
+#define DDSPP_CHUNK 1000          // ddsp.core.angular_cumsum(chunk_size=1000)
+#define DDSPP_WAVE 64
+
+extern "C" void ddspp_set_error(const char* fmt, ...);
+
+#define DDSPP_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ddspp_set_error(__VA_ARGS__);        \
+            return DDSPP_EINVAL;                 \
+        }                                        \
+    } while (0)
+
+#define DDSPP_HIP_CHECK(expr)                                                          \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            ddspp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                            __FILE__, __LINE__);                                       \
+            return DDSPP_EHIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define DDSPP_LAUNCH_CHECK()                                                           \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess) {                                                        \
+            ddspp_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                       \
+            return DDSPP_EHIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+// float32(2*pi) = 6.2831855f : what TensorFlow makes of the python float `2.0 * pi`
+// (inharm_synth.py:69) and the modulus of ddsp.core.angular_cumsum.
+#define DDSPP_TWO_PI_F32 6.2831855f
+
+#ifdef __HIPCC__
+namespace ddspp {
+
+// ------------------------------------------------------------------------------------------
+// Correctly rounded x / d for a constant d, given rd = RN(1/d)  (Markstein's correction step).
+//   q  = RN(x * rd)           faithful quotient
+//   r  = x - q * d            exact in one FMA
+//   q' = RN(q + r * rd)       = RN(x / d)
+// Valid away from under/overflow; the caller enables it only for sample rates whose result was
+// checked exhaustively against IEEE division (tests/test_exact_arith.py) and falls back to the
+// IEEE divide otherwise.  Replaces `omegas / float(sample_rate)` (inharm_synth.py:70).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float div_const(float x, float d, float rd) {
+    float q = x * rd;
+    float r = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(r, rd, q);
+}
+
+// ------------------------------------------------------------------------------------------
+// floormod(x, float32(2*pi)) exactly as tf.math.floormod / np.mod compute it
+// (fmod, then `+ y` when the remainder is non-zero and negative).
+// Fast path, 0 <= x < 2^22 * 2pi:  q = floor(x * INV) with INV rounded UP by 2 ulp, so q is
+// floor(x / P) or one more, never less; r = x - q * P is then exact in one FMA because both x
+// and q * P are multiples of ulp(P) = 2^-21 and |r| < 8; a negative r gets + P (exact).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mod_2pi_slow(float x) {
+    const float P = DDSPP_TWO_PI_F32;
+    float t = fmodf(x, P);
+    if (t != 0.0f && t < 0.0f) t = t + P;
+    return t;
+}
+
+__device__ __forceinline__ float mod_2pi(float x) {
+    const float P = DDSPP_TWO_PI_F32;
+    const float INV_UP = 0x1.45f30ap-3f;   // RN(1/P) = 0x1.45f306p-3 rounded up by two more ulps
+    if (__builtin_expect(!(x >= 0.0f && x < 2.6e7f), 0)) return mod_2pi_slow(x);
+    float q = __builtin_floorf(x * INV_UP);
+    float r = __builtin_fmaf(-q, P, x);
+    return r < 0.0f ? r + P : r;
+}
+
+// cos of a phase already reduced to [0, 2pi]: hardware v_cos_f32 takes revolutions.
+__device__ __forceinline__ float cos_reduced(float r) {
+    return __builtin_amdgcn_cosf(r * 0x1.45f306p-3f);
+}
+
+// cos(floormod(s, P)) for 0 <= s < 2^22 * P without materialising the floormod:
+//   q = rint(s / P), r = s - q * P  (exact, one FMA: multiples of 2^-21 below 8 in magnitude)
+// r is floormod(s, P) or floormod(s, P) - P; cos is evaluated at r, i.e. at most P - 2pi = 1.75e-7
+// rad away from the reference's argument -- below float32 resolution of the cosine itself.
+__device__ __forceinline__ float cos_of_phase_fast(float s) {
+    const float P = DDSPP_TWO_PI_F32;
+    const float q = __builtin_rintf(s * 0x1.45f306p-3f);
+    const float r = __builtin_fmaf(-q, P, s);
+    return __builtin_amdgcn_cosf(r * 0x1.45f306p-3f);
+}
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace ddspp
+#endif

@@ -1,0 +1,171 @@
+"""Batched execution of the polyphonic ProcessorGroup.
+
+The reference walks 3*P + 1 DAG nodes one eager processor call at a time
+(ddsp_piano/modules/polyphonic_dag.py:24-40).  When the DAG handed to ProcessorGroup has exactly that
+shape, the voices become a batch dimension: rows = B*P go through ONE get_controls kernel, ONE
+fused oscillator-bank launch, ONE FIR-design + ONE time-varying-FIR launch, one mixer pass and one
+rocFFT reverb.  Results are those of the node-by-node walk (same kernels, same per-row arithmetic;
+the voice sum keeps the DAG's ((add + noise_i) + additive_i) order); tests/test_gpu_group.py checks the
+two routes against each other.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, core
+from .core import _lib_, _ptr, _stream
+from .effects import FeedbackDelayNetworkApply, Reverb
+from .synths import FilteredNoise, InHarmonic, MultiAdd
+
+
+class Plan:
+    def __init__(self, additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, n_synths):
+        self.additive, self.noise, self.add, self.reverb = additive, noise, add, reverb
+        self.additive_keys, self.noise_keys, self.reverb_keys = additive_keys, noise_keys, reverb_keys
+        self.n_synths = n_synths
+
+
+def recognise(dag):
+    """Return a Plan if ``dag`` is polyphonic_dag(...)'s node list over this package's processors."""
+    n = len(dag)
+    if n < 3:
+        return None
+    has_reverb = (n % 3) == 1
+    if n % 3 not in (0, 1):
+        return None
+    p = n // 3
+    additive, noise, add = dag[0][0], dag[1][0], dag[2][0]
+    if not (isinstance(additive, InHarmonic) and isinstance(noise, FilteredNoise) and isinstance(add, MultiAdd)):
+        return None
+    if add.name != 'add' and p > 1:
+        pass
+    additive_keys, noise_keys = [], []
+    for i in range(p):
+        a, z, m = dag[3 * i], dag[3 * i + 1], dag[3 * i + 2]
+        if a[0] is not additive or z[0] is not noise or m[0] is not add:
+            return None
+        if len(a[1]) != 4 or len(z[1]) != 1:
+            return None
+        expect = [noise.name + '/signal', additive.name + '/signal']
+        if i > 0:
+            expect = [add.name + '/signal'] + expect
+        if list(m[1]) != expect:
+            return None
+        if any('/' in k for k in list(a[1]) + list(z[1])):
+            return None
+        additive_keys.append(list(a[1]))
+        noise_keys.append(z[1][0])
+    reverb, reverb_keys = None, []
+    if has_reverb:
+        node = dag[-1]
+        reverb = node[0]
+        if not isinstance(reverb, (Reverb, FeedbackDelayNetworkApply)) or getattr(reverb, 'trainable', False):
+            return None
+        if not node[1] or node[1][0] != add.name + '/signal' or len(node[1]) != 2:
+            return None
+        reverb_keys = list(node[1][1:])
+        if any('/' in k for k in reverb_keys):
+            return None
+    return Plan(additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, p)
+
+
+def _stack_voices(tensors):
+    """[B, T, C] x P -> [B, P, T, C] contiguous; zero-copy when the P tensors are the P slices of
+    one [B, P, T, C] buffer (what a batched control network naturally produces)."""
+    t0 = tensors[0]
+    p = len(tensors)
+    if (t0.is_cuda and t0.dtype == torch.float32 and t0.dim() == 3 and
+            all(x.shape == t0.shape and x.stride() == t0.stride() and x.dtype == t0.dtype and
+                x.device == t0.device for x in tensors)):
+        b, t, c = t0.shape
+        sb, st, sc = t0.stride()
+        es = t0.element_size()
+        if sc == 1 and st == c and sb == p * t * c and all(
+                x.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and
+                x.data_ptr() == t0.data_ptr() + i * t * c * es for i, x in enumerate(tensors)):
+            return torch.as_strided(t0, (b, p, t, c), (sb, t * c, c, 1))
+    return torch.stack([core.tf_float32(x) for x in tensors], dim=1).contiguous()
+
+
+def run(plan, inputs, noise=None):
+    """Execute the polyphonic DAG with voices batched.  Returns the ddsp-style outputs dict, or None
+    when the inputs do not fit the batched kernels (caller then walks the DAG node by node)."""
+    P = plan.n_synths
+    add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
+    amp = _stack_voices(add_ctl[0])           # [B, P, T, 1]
+    hd = _stack_voices(add_ctl[1])            # [B, P, T, H]
+    inh = _stack_voices(add_ctl[2])           # [B, P, T, 1]
+    f0 = _stack_voices(add_ctl[3])            # [B, P, T, S]
+    mags = _stack_voices([inputs[k] for k in plan.noise_keys])    # [B, P, T, K]
+    B, _, T, H = hd.shape
+    S = f0.shape[-1]
+    K = mags.shape[-1]
+    if amp.shape[-1] != 1 or inh.shape[-1] != 1 or mags.shape[2] != T:
+        return None
+    additive, noise_p = plan.additive, plan.noise
+    if not isinstance(additive, InHarmonic):
+        return None
+    U = additive.upsampling
+    N = U * T
+    if not core.fused_synthesis_supported(T, N):
+        return None
+    if noise_p._n_samples(mags.reshape(B * P, T, K)) != N:
+        return None
+    if S != 1 and type(additive) is InHarmonic:
+        return None
+    R = B * P
+    dev = hd.device
+
+    # --- additive branch ------------------------------------------------------------------------
+    ctl = additive._controls(amp.reshape(R, T, 1), hd.reshape(R, T, H), inh.reshape(R, T, 1),
+                             f0.reshape(R, T, S))
+    additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
+                                                 ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
+                                                 additive.sample_rate, additive.inference)
+    # --- noise branch ---------------------------------------------------------------------------
+    nctl = noise_p.get_controls(mags.reshape(R, T, K))
+    if noise is None:
+        override = getattr(noise_p, 'noise_override', None)
+        if override:
+            noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=1)
+    if noise is None:
+        noise = noise_p.draw_noise(R, N, dev)
+    noise = core.tf_float32(noise).reshape(R, N)
+    noise_sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
+
+    # --- add chain ------------------------------------------------------------------------------
+    dry = torch.empty((B, N), dtype=torch.float32, device=dev)
+    _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), B, P, N, N,
+                                            _stream()))
+
+    additive_sig = additive_sig.reshape(B, P, N)
+    noise_sig = noise_sig.reshape(B, P, N)
+    last = P - 1
+
+    def voice(x, shape):
+        return x.reshape((B, P) + shape)[:, last]
+
+    outputs = {'inputs': inputs}
+    outputs.update(inputs)
+    outputs[additive.name] = {
+        'signal': additive_sig[:, last],
+        'controls': {'amplitudes': voice(ctl['amplitudes'], (T, 1)),
+                     'harmonic_distribution': voice(ctl['harmonic_distribution'], (T, H)),
+                     'harmonic_shifts': voice(ctl['harmonic_shifts'], (T, H)),
+                     'f0_hz': voice(ctl['f0_hz'], (T, S))}}
+    outputs[noise_p.name] = {'signal': noise_sig[:, last],
+                             'controls': {'magnitudes': voice(nctl['magnitudes'], (T, K))}}
+    add_controls = {'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
+        {'signal_0': noise_sig[:, last], 'signal_1': additive_sig[:, last]}
+    outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
+    module_outputs = outputs[plan.add.name]
+    # every voice's stems, which the reference can only get by re-running processors one by one
+    # (synthesize_from_csv.py:99-120)
+    outputs['voices'] = {'additive': additive_sig, 'noise': noise_sig}
+
+    if plan.reverb is not None:
+        rev_args = [inputs[k] for k in plan.reverb_keys]
+        module_outputs = plan.reverb(dry, *rev_args, return_outputs_dict=True)
+        outputs[plan.reverb.name] = module_outputs
+    outputs['out'] = module_outputs
+    return outputs

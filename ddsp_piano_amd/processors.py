@@ -1,0 +1,129 @@
+"""The ddsp Processor protocol (ddsp.processors.Processor / ProcessorGroup / Add, ddsp.dags.DAGLayer)
+re-stated without Keras: same constructor arguments, same ``get_controls`` -> ``get_signal`` call
+flow, same output dictionaries, so that it sits where the reference's ProcessorGroup sits
+(ddsp_piano/modules/piano_model.py:160-164; ddsp_piano/default_model.py:20-85;
+ddsp_piano/configs/maestro-v2.gin:144-153).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import core
+
+
+class Processor:
+    """ddsp.processors.Processor: ``__call__ = get_signal(**get_controls(*args, **kwargs))``."""
+
+    def __init__(self, name, trainable=False):
+        self.name = name
+        self.trainable = trainable
+
+    def __call__(self, *args, return_outputs_dict=False, **kwargs):
+        # "Convert input tensors to float32" (ddsp.processors.Processor.call)
+        args = [core.tf_float32(a) if _is_tensor_like(a) else a for a in args]
+        kwargs = {k: core.tf_float32(v) if _is_tensor_like(v) else v for k, v in kwargs.items()}
+        controls = self.get_controls(*args, **kwargs)
+        signal = self.get_signal(**controls)
+        if return_outputs_dict:
+            return dict(signal=signal, controls=controls)
+        return signal
+
+    def get_controls(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def get_signal(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+def _is_tensor_like(x):
+    if isinstance(x, torch.Tensor):
+        return True
+    try:
+        import numpy as np
+        return isinstance(x, np.ndarray)
+    except Exception:  # noqa: BLE001
+        return False
+
+
+class Add(Processor):
+    """ddsp.processors.Add (default_model.py:56-74)."""
+
+    def __init__(self, name='add'):
+        super().__init__(name=name)
+
+    def get_controls(self, signal_one, signal_two):
+        return {'signal_one': signal_one, 'signal_two': signal_two}
+
+    def get_signal(self, signal_one, signal_two):
+        return core.add_signals([signal_one, signal_two])
+
+
+def _nested_lookup(key, dictionary):
+    """ddsp.core.nested_lookup: 'a/b/c' -> dictionary['a']['b']['c']."""
+    out = dictionary
+    for k in key.split('/'):
+        out = out[k]
+    return out
+
+
+class ProcessorGroup:
+    """ddsp.processors.ProcessorGroup(dag, name): string-keyed DAG of processors.
+
+    ``dag`` is a list of ``(processor, [input_key, ...])``; keys are looked up, '/'-nested, in the
+    running outputs dict that starts as the input features.  ``outputs[processor.name]`` is
+    overwritten each time a processor is reused (polyphonic_dag.py re-uses three objects for all
+    voices), exactly as in ddsp.
+    """
+
+    def __init__(self, dag, name='processor_group', fast_path=True):
+        self.dag = [tuple(node) for node in dag]
+        self.name = name
+        self.fast_path = fast_path
+        self._processors = []
+        for node in self.dag:
+            p = node[0]
+            if not isinstance(p, Processor):
+                raise TypeError(f'DAG node {node!r} does not start with a Processor')
+            if all(p is not q for q in self._processors):
+                self._processors.append(p)
+                setattr(self, p.name, p)
+        self._plan = None
+
+    @property
+    def processors(self):
+        """Unique processors in first-seen DAG order (synthesize_from_csv.py:99 takes [:2])."""
+        return list(self._processors)
+
+    def __call__(self, inputs, return_outputs_dict=False, **kwargs):
+        outputs = self.get_controls(inputs, **kwargs)
+        signal = self.get_signal(outputs)
+        if return_outputs_dict:
+            return dict(signal=signal, controls=outputs)
+        return signal
+
+    def get_controls(self, inputs, **kwargs):
+        """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag)."""
+        if self.fast_path:
+            from . import polyphonic
+            if self._plan is None:
+                self._plan = polyphonic.recognise(self.dag) or False
+            if self._plan:
+                outputs = polyphonic.run(self._plan, inputs, **kwargs)
+                if outputs is not None:
+                    return outputs
+        return self._run_dag(inputs)
+
+    def _run_dag(self, inputs):
+        outputs = {'inputs': inputs}
+        outputs.update(inputs)
+        module_outputs = None
+        for node in self.dag:
+            processor, input_keys = node[0], node[1]
+            args = [_nested_lookup(k, outputs) for k in input_keys]
+            module_outputs = processor(*args, return_outputs_dict=True)
+            outputs[processor.name] = module_outputs
+        outputs['out'] = module_outputs
+        return outputs
+
+    def get_signal(self, outputs):
+        return outputs['out']['signal']

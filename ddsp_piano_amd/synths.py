@@ -1,0 +1,195 @@
+"""Synth processors of the reference, same constructor / get_controls / get_signal signatures:
+
+  InHarmonic, MultiInharmonic, MultiAdd      ddsp_piano/modules/inharm_synth.py:130-309
+  FilteredNoise                              ddsp.synths.FilteredNoise (default_model.py:44)
+  DynamicSizeFilteredNoise                   ddsp_piano/modules/filtered_noise_synth.py:12-42
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+from . import _lib, core
+from .core import _lib_, _ptr, _stream
+from .processors import Processor
+
+
+class InHarmonic(Processor):
+    """inharm_synth.py:130-244."""
+
+    def __init__(self, frame_rate=250, sample_rate=16000, min_frequency=20, scale_fn=core.exp_sigmoid,
+                 normalize_after_nyquist_cut=True, normalize_below_nyquist=True, inference=False,
+                 name='inharmonic'):
+        self.frame_rate = frame_rate
+        self.sample_rate = sample_rate
+        self.min_frequency = min_frequency
+        self.normalize_after_nyquist_cut = normalize_after_nyquist_cut
+        self.scale_fn = scale_fn
+        self.normalize_below_nyquist = normalize_below_nyquist
+        self.inference = inference
+        super().__init__(name=name)
+
+    @property
+    def upsampling(self):
+        return int(self.sample_rate / self.frame_rate)               # :163-165
+
+    def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+        """One fused kernel for :183-214 (+ :269); f0_hz may carry several sub-strings."""
+        amplitudes = core.tf_float32(amplitudes)
+        harmonic_distribution = core.tf_float32(harmonic_distribution)
+        inharm_coef = core.tf_float32(inharm_coef)
+        f0_hz = core.tf_float32(f0_hz)
+        if harmonic_distribution.dim() != 3:
+            raise ValueError('harmonic_distribution must be [batch, time, n_harmonics]')
+        b, t, h = harmonic_distribution.shape
+        s = f0_hz.shape[-1]
+        for name, x in (('amplitudes', amplitudes), ('inharm_coef', inharm_coef)):
+            if tuple(x.shape) != (b, t, 1):
+                raise ValueError(f'{name} must have shape {(b, t, 1)}, got {tuple(x.shape)}')
+        if f0_hz.dim() != 3 or tuple(f0_hz.shape[:2]) != (b, t):
+            raise ValueError(f'f0_hz must be [{b}, {t}, n_substrings], got {tuple(f0_hz.shape)}')
+        kind = core.scale_kind(self.scale_fn)
+        if kind is None:            # arbitrary python scale_fn: apply it, then let the kernel do the rest
+            amplitudes = core.tf_float32(self.scale_fn(amplitudes))
+            harmonic_distribution = core.tf_float32(self.scale_fn(harmonic_distribution))
+            kind = core.scale_kind(None)
+        code, prm = kind
+        amp_out = torch.empty_like(amplitudes)
+        hd_out = torch.empty_like(harmonic_distribution)
+        shifts_out = torch.empty_like(harmonic_distribution)
+        _lib.check(_lib_().ddspp_inharmonic_controls(
+            _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
+            _ptr(hd_out), _ptr(shifts_out), b, t, h, s, float(self.sample_rate), float(self.min_frequency),
+            code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+            int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
+        return {'amplitudes': amp_out, 'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out,
+                'f0_hz': f0_hz}
+
+    def get_controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+        """inharm_synth.py:167-219."""
+        f0_hz = core.tf_float32(f0_hz)
+        if f0_hz.shape[-1] != 1:
+            raise ValueError('InHarmonic expects f0_hz of shape [batch, time, 1]')
+        return self._controls(amplitudes, harmonic_distribution, inharm_coef, f0_hz)
+
+    def _synthesize(self, amplitudes, harmonic_distribution, harmonic_shifts, f0_hz):
+        amplitudes = core.tf_float32(amplitudes)
+        harmonic_distribution = core.tf_float32(harmonic_distribution)
+        harmonic_shifts = core.tf_float32(harmonic_shifts)
+        f0_hz = core.tf_float32(f0_hz)
+        b, t, s = f0_hz.shape
+        n_samples = self.upsampling * t                                # :240
+        if core.fused_synthesis_supported(t, n_samples) and amplitudes.shape[-1] == 1:
+            return core.harmonic_synthesis_fused(f0_hz, amplitudes.reshape(b, t).contiguous(),
+                                                 harmonic_distribution, harmonic_shifts, n_samples,
+                                                 self.sample_rate, self.inference)
+        audio = None
+        for sub in range(s):                                           # :279-292
+            a = core.harmonic_synthesis(frequencies=f0_hz[..., sub:sub + 1], amplitudes=amplitudes,
+                                        harmonic_shifts=harmonic_shifts,
+                                        harmonic_distribution=harmonic_distribution, n_samples=n_samples,
+                                        sample_rate=self.sample_rate, use_angular_cumsum=self.inference)
+            audio = a if audio is None else audio + a
+        return audio
+
+    def get_signal(self, amplitudes, harmonic_distribution, harmonic_shifts, f0_hz):
+        """inharm_synth.py:221-244."""
+        return self._synthesize(amplitudes, harmonic_distribution, harmonic_shifts, f0_hz)
+
+
+class MultiInharmonic(InHarmonic):
+    """Inharmonic synthesizer with multiple F0 controls -- inharm_synth.py:247-293."""
+
+    def __init__(self, name='multi_inharmonic', **kwargs):
+        super().__init__(name=name, **kwargs)
+
+    def get_controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+        return self._controls(amplitudes, harmonic_distribution, inharm_coef, f0_hz)    # :254-270
+
+    def get_signal(self, amplitudes, harmonic_distribution, harmonic_shifts, f0_hz):
+        return self._synthesize(amplitudes, harmonic_distribution, harmonic_shifts, f0_hz)  # :272-293
+
+
+class MultiAdd(Processor):
+    """Sum arbitrary number of signals -- inharm_synth.py:296-309."""
+
+    def __init__(self, name='add'):
+        super().__init__(name=name)
+
+    def get_controls(self, *signals):
+        return {f'signal_{i}': s for i, s in enumerate(signals)}
+
+    def get_signal(self, **signals):
+        return core.add_signals(list(signals.values()))
+
+
+class FilteredNoise(Processor):
+    """ddsp.synths.FilteredNoise(n_samples, window_size, scale_fn, initial_bias, name).
+
+    The reference draws an unseeded ``tf.random.uniform([B, n_samples], -1, 1)`` per call.  Here the
+    draw comes from the library's Philox generator keyed by ``seed`` with a per-call counter, or from
+    the explicit ``noise=`` argument of get_signal (what the parity tests use).
+    """
+
+    def __init__(self, n_samples=64000, window_size=257, scale_fn=core.exp_sigmoid, initial_bias=-5.0,
+                 name='filtered_noise', seed=0):
+        super().__init__(name=name)
+        self.n_samples = n_samples
+        self.window_size = window_size
+        self.scale_fn = scale_fn
+        self.initial_bias = initial_bias
+        self.seed = seed
+        self._calls = itertools.count()
+
+    def get_controls(self, magnitudes):
+        magnitudes = core.tf_float32(magnitudes)
+        if self.scale_fn is not None:
+            kind = core.scale_kind(self.scale_fn)
+            if kind is None:
+                magnitudes = core.tf_float32(self.scale_fn(magnitudes + self.initial_bias))
+            else:
+                code, prm = kind
+                out = torch.empty_like(magnitudes)
+                _lib.check(_lib_().ddspp_scale_bias(_ptr(magnitudes), _ptr(out), magnitudes.numel(),
+                                                    float(self.initial_bias), code, prm['exponent'],
+                                                    prm['max_value'], prm['threshold'], prm['gain'],
+                                                    _stream()))
+                magnitudes = out
+        return {'magnitudes': magnitudes}
+
+    def _n_samples(self, magnitudes):
+        return int(self.n_samples)
+
+    def draw_noise(self, batch_size, n_samples, device):
+        call = next(self._calls)
+        return core.uniform_noise((batch_size, n_samples), seed=self.seed, offset=call << 40, device=device)
+
+    def get_signal(self, magnitudes, noise=None):
+        magnitudes = core.tf_float32(magnitudes)
+        batch_size = int(magnitudes.shape[0])
+        n_samples = self._n_samples(magnitudes)
+        if noise is None:
+            noise = self.draw_noise(batch_size, n_samples, magnitudes.device)
+        else:
+            noise = core.tf_float32(noise)
+            if tuple(noise.shape) != (batch_size, n_samples):
+                raise ValueError(f'noise must be {(batch_size, n_samples)}, got {tuple(noise.shape)}')
+        return core.frequency_filter(noise, magnitudes, window_size=self.window_size)
+
+
+class DynamicSizeFilteredNoise(FilteredNoise):
+    """filtered_noise_synth.py:12-42: n_samples = upsampling * n_frames."""
+
+    def __init__(self, frame_rate=250, sample_rate=16000, **kwargs):
+        kwargs.setdefault('name', 'filtered_noise')
+        super().__init__(**kwargs)
+        self.frame_rate = frame_rate
+        self.sample_rate = sample_rate
+
+    @property
+    def upsampling(self):
+        return int(self.sample_rate / self.frame_rate)
+
+    def _n_samples(self, magnitudes):
+        return self.upsampling * int(magnitudes.shape[1])             # :35-37

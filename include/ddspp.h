@@ -1,0 +1,148 @@
+/* libddspp -- C-ABI of the MI355X (gfx950) DDSP-Piano synthesis hot path.
+ *
+ * The reference (lrenault/ddsp-piano @ v2) is pure Python over TensorFlow + ddsp==3.7.0 and has no
+ * FFI of its own; each entry point below therefore names the reference
+ * *function* (file:line under /root/reference, or the un-vendored ddsp 3.7.0 function reached
+ * from that call site) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless noted;
+ *   - `R` ("rows") is batch x voices flattened, `T` control frames, `U` samples per frame,
+ *     `N = T * U` audio samples, `H` harmonics, `S` sub-strings, `K` noise bands, `L` IR taps;
+ *   - functions only enqueue work on `stream` and return 0, or a negative errno-style code after
+ *     storing a message for ddspp_last_error(); nothing is thrown across the boundary;
+ *   - the caller owns all buffers, including workspaces; the library owns only rocFFT plans
+ *     behind ddspp_fftconv_plan.
+ */
+#ifndef DDSPP_H_
+#define DDSPP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define DDSPP_OK 0
+#define DDSPP_EINVAL (-22)
+#define DDSPP_ENOMEM (-12)
+#define DDSPP_EHIP (-5)
+#define DDSPP_EFFT (-6)
+
+#define DDSPP_SCALE_NONE 0
+#define DDSPP_SCALE_EXP_SIGMOID 1 /* ddsp.core.exp_sigmoid */
+#define DDSPP_SCALE_EXP_TANH 2    /* ddsp_piano/modules/inharm_synth.py:13-17 */
+
+int ddspp_version(void);
+const char* ddspp_target_arch(void);
+const char* ddspp_last_error(void);
+
+/* ---- frame -> sample control upsamplers ------------------------------------------------------ */
+
+/* ddsp.core.resample(x, N, method='linear') -- call site inharm_synth.py:117.
+ * x[R,T,C] -> y[R,N,C];  y[n] = x[lo[n]] + (x[hi[n]] - x[lo[n]]) * w[n]  with the legacy-bilinear
+ * (align_corners=False, no half-pixel) tables lo/hi (int32[N]) and w (float32[N]). */
+int ddspp_resample_linear(const float* x, const int* lo, const int* hi, const float* w, float* y, int R,
+                          int T, int C, int N, hipStream_t stream);
+
+/* ddsp.core.resample(x, N, method='window') = ddsp.core.upsample_with_windows(add_endpoint=True)
+ * -- call site inharm_synth.py:118-119.  window = tf.signal.hann_window(2U) as float32[2U]. */
+int ddspp_resample_window(const float* x, const float* window, float* y, int R, int T, int C, int U,
+                          hipStream_t stream);
+
+/* ---- oscillator bank ------------------------------------------------------------------------- */
+
+size_t ddspp_osc_workspace_bytes(int R, int N, int V);
+
+/* cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate, sum_sinusoids,
+ * use_angular_cumsum) -- inharm_synth.py:49-84 (+ ddsp.core.remove_above_nyquist / angular_cumsum).
+ * envelopes [R,N,H] -> audio [R,N] (sum_sinusoids) or [R,N,H].  spans = 0 lets the library pick how
+ * many runs of 1000-sample chunks each row is cut into (1 = every envelope read exactly once). */
+int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amplitude_envelopes,
+                              float* audio, int R, int N, int H, float sample_rate, int sum_sinusoids,
+                              int use_angular_cumsum, int spans, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream);
+
+/* harmonic_synthesis(...) summed over sub-strings = MultiInharmonic.get_signal
+ * -- inharm_synth.py:87-127, :221-244, :272-293.
+ * f0_hz[R,T,S], amplitudes[R,T], harmonic_distribution[R,T,H], harmonic_shifts[R,T,H] (or NULL)
+ * -> audio[R, T*U].  wlin = float32[T*U] linear weights, whann = float32[2U] Hann window. */
+int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
+                             const float* harmonic_distribution, const float* harmonic_shifts,
+                             const float* wlin, const float* whann, float* audio, int R, int T, int S,
+                             int H, int U, float sample_rate, int use_angular_cumsum, int spans,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* ---- get_controls ---------------------------------------------------------------------------- */
+
+/* InHarmonic.get_controls / MultiInharmonic.get_controls -- inharm_synth.py:167-219, :254-270
+ * (+ get_inharmonic_freq :20-46).  amplitudes[R,T], harmonic_distribution[R,T,H], inharm_coef[R,T],
+ * f0_hz[R,T,S] -> amplitudes_out[R,T] (already divided by S), harmonic_distribution_out[R,T,H],
+ * harmonic_shifts_out[R,T,H]. */
+int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
+                              const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                              float* harmonic_distribution_out, float* harmonic_shifts_out, int R, int T,
+                              int H, int S, float sample_rate, float min_frequency, int scale_kind,
+                              float exponent, float max_value, float threshold, float gain,
+                              int normalize_after_nyquist_cut, int normalize_below_nyquist,
+                              hipStream_t stream);
+
+/* ddsp.synths.FilteredNoise.get_controls: y = scale_fn(x + initial_bias), elementwise. */
+int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_kind, float exponent,
+                     float max_value, float threshold, float gain, hipStream_t stream);
+
+/* ---- mixers ---------------------------------------------------------------------------------- */
+
+/* MultiAdd.get_signal (inharm_synth.py:308-309) / ddsp.processors.Add: out = ((s0 + s1) + s2) ...
+ * srcs = DEVICE array of nsrc device pointers. */
+int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, hipStream_t stream);
+
+/* the whole `add` chain of polyphonic_dag.py:28-37: additive/noise [B,P,N] -> out rows of
+ * out_stride floats (noise may be NULL). */
+int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
+                         int out_stride, hipStream_t stream);
+
+/* ---- FilteredNoise --------------------------------------------------------------------------- */
+
+/* ddsp.core.frequency_impulse_response(magnitudes[frames,K], window_size) as magnitudes @ M with the
+ * host-built float32 matrix M[K,Lw] -> ir[frames,Lw]. */
+int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, float* ir, size_t frames, int K,
+                              int Lw, hipStream_t stream);
+
+/* ddsp.core.fft_convolve(audio[R,N], impulse_response[R,T,Lw], padding='same', delay_compensation)
+ * in the framed case (frame = hop = N / T); reached from filtered_noise_synth.py:41-42 through
+ * ddsp.core.frequency_filter.  delay_compensation < 0 -> (Lw - 1) // 2 - 1. */
+int ddspp_time_varying_fir(const float* audio, const float* impulse_response, float* out, int R, int N,
+                           int T, int Lw, int delay_compensation, hipStream_t stream);
+
+/* stand-in for the reference's unseeded tf.random.uniform([B, N], -1, 1)
+ * (filtered_noise_synth.py:39-40): Philox4x32-10, counter = offset + i / 4, key = seed. */
+int ddspp_uniform_noise(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t stream);
+
+/* ---- reverb ---------------------------------------------------------------------------------- */
+
+typedef struct FftConvPlan ddspp_fftconv_plan;
+
+/* ddsp.core.get_fft_size(N, L, power_of_2=True) */
+int ddspp_fft_size(int N, int L);
+
+/* ddsp.core.fft_convolve, single IR frame (ddsp.effects.Reverb.get_signal; fdn_reverb.py:407-410).
+ * B_ir is B or 1 (a batch-1 IR is shared by all rows). */
+int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan** out_plan);
+int ddspp_fftconv_plan_destroy(ddspp_fftconv_plan* plan);
+size_t ddspp_fftconv_workspace_bytes(const ddspp_fftconv_plan* plan);
+int ddspp_fftconv_fft_size(const ddspp_fftconv_plan* plan);
+int ddspp_fftconv_execute(ddspp_fftconv_plan* plan, const float* audio, int audio_stride, const float* ir,
+                          float* out, int out_len, int delay, int mask_dry, int add_dry, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDSPP_H_ */

@@ -1,0 +1,652 @@
+"""CPU oracle for the DDSP-Piano synthesis hot path (TEST INFRASTRUCTURE ONLY).
+
+    *** PARITY UNPINNED ***
+    The reference (lrenault/ddsp-piano @ v2) is Python on top of TensorFlow and
+    the un-vendored pip package ``ddsp==3.7.0`` (README.md:11-15).  Neither is
+    importable in the build container or on the GPU box, and the reference ships
+    no tests / golden vectors.  This file is therefore a
+    float32-faithful *restatement*: functions that live in /root/reference cite
+    the file:line they follow; functions that live in ``ddsp`` restate the
+    published ddsp 3.7.0 algorithm (ddsp/core.py, synths.py, effects.py,
+    processors.py) and are anchored on the reference's call sites.  It is pinned
+    only by analytic known-answer tests and by scipy/numpy cross-checks
+    (tests/test_oracle_kat.py), never by TF outputs.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product (``ddsp_piano_amd``) never
+does: it fails loudly when its HIP library is missing.
+
+float32 contract (what "faithful" means here):
+  * every elementwise op is a separately rounded IEEE float32 op, in the order
+    the reference writes it (no FMA contraction);
+  * ``cumsum`` is a sequential float32 scan along time (Eigen scan order on CPU);
+  * ``%`` is floormod = fmod + sign fix-up with float32(2*pi) = 6.2831855;
+  * FFTs are evaluated in float64 and rounded once to float32 (TF/pocketfft and
+    rocFFT both deviate from this by ~1e-7 relative, well inside 1e-4 RMS);
+  * transcendental functions (cos, exp, log, tanh, pow) are numpy's float32
+    versions; TF's Eigen versions differ in the last ulp.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.fft as sfft
+
+F32 = np.float32
+TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2.0 * pi`
+
+
+def tf_float32(x):
+    """ddsp.core.tf_float32: cast/convert to float32."""
+    return np.asarray(x, dtype=F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# scale functions / small helpers
+# ----------------------------------------------------------------------------------------------
+def safe_divide(numerator, denominator, eps=1e-7):
+    """ddsp.core.safe_divide: ``a / where(b == 0, eps, b)`` (call sites inharm_synth.py:195,211)."""
+    numerator = tf_float32(numerator)
+    denominator = tf_float32(denominator)
+    safe = np.where(denominator == 0.0, F32(eps), denominator).astype(F32)
+    return (numerator / safe).astype(F32)
+
+
+def _sigmoid_f32(x):
+    x = tf_float32(x)
+    return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
+    """ddsp.core.exp_sigmoid: ``max_value * sigmoid(x) ** log(exponent) + threshold``.
+
+    Default scale_fn of InHarmonic (inharm_synth.py:149) and FilteredNoise.
+    """
+    x = tf_float32(x)
+    p = F32(np.log(F32(exponent)))
+    return (F32(max_value) * np.power(_sigmoid_f32(x), p, dtype=F32) + F32(threshold)).astype(F32)
+
+
+def positive_tanh(x):
+    """inharm_synth.py:8-10."""
+    x = tf_float32(x)
+    return (F32(0.5) * (np.tanh(x, dtype=F32) + F32(1.0))).astype(F32)
+
+
+def exp_tanh(x, max_value=2.0, exponent=10.0, gain=1.0, threshold=1e-7):
+    """inharm_synth.py:13-17."""
+    p = F32(np.log(F32(exponent)))
+    y = F32(max_value) * np.power(positive_tanh(F32(gain) * tf_float32(x)), p, dtype=F32)
+    return (y + F32(threshold)).astype(F32)
+
+
+def remove_above_nyquist(frequency_envelopes, amplitude_envelopes, sample_rate=16000):
+    """ddsp.core.remove_above_nyquist: ``where(f >= sr / 2, 0, a)`` (note ``>=``)."""
+    f = tf_float32(frequency_envelopes)
+    a = tf_float32(amplitude_envelopes)
+    return np.where(f >= F32(sample_rate / 2.0), F32(0.0), a).astype(F32)
+
+
+def get_harmonic_frequencies(frequencies, n_harmonics):
+    """ddsp.core.get_harmonic_frequencies: ``f0 * linspace(1, H, H)``."""
+    f_ratios = np.linspace(1.0, float(n_harmonics), int(n_harmonics)).astype(F32)
+    return (tf_float32(frequencies) * f_ratios[None, None, :]).astype(F32)
+
+
+def get_inharmonic_freq(f0_hz, inharm_coef, n_harmonics):
+    """inharm_synth.py:20-46."""
+    f0_hz = tf_float32(f0_hz)
+    inharm_coef = tf_float32(inharm_coef)
+    int_multiplier = np.linspace(1.0, float(n_harmonics), int(n_harmonics)).astype(F32)
+    int_multiplier = int_multiplier[None, None, :]
+    inharm_factor = np.power(int_multiplier, F32(2.0), dtype=F32)          # :37
+    inharm_factor = (inharm_factor * inharm_coef).astype(F32) + F32(1.0)   # :38
+    inharm_factor = np.sqrt(inharm_factor, dtype=F32)                      # :39
+    inharmonic_freq = ((f0_hz * int_multiplier).astype(F32) * inharm_factor).astype(F32)  # :42
+    harmonic_shifts = (inharm_factor - F32(1.0)).astype(F32)               # :44
+    return inharmonic_freq, harmonic_shifts
+
+
+# ----------------------------------------------------------------------------------------------
+# frame -> sample upsamplers (ddsp.core.resample / upsample_with_windows)
+# ----------------------------------------------------------------------------------------------
+def hann_window(n, periodic=True):
+    """tf.signal.hann_window restated in float32 (window_ops._raised_cosine_window).
+
+    ``even = 1 - n % 2; denom = n + periodic * even - 1; 0.5 - 0.5 * cos(2*pi*i / denom)`` with
+    every op in float32.
+    """
+    n = int(n)
+    if n == 1:
+        return np.ones([1], F32)
+    even = 1 - n % 2
+    denom = F32(n + int(periodic) * even - 1)
+    count = np.arange(n, dtype=F32)
+    cos_arg = ((TWO_PI_F32 * count).astype(F32) / denom).astype(F32)
+    return (F32(0.5) - (F32(0.5) * np.cos(cos_arg, dtype=F32)).astype(F32)).astype(F32)
+
+
+def linear_resample_positions(n_frames, n_timesteps):
+    """Legacy (TF1, align_corners=False, no half-pixel centres) bilinear source positions.
+
+    ``scale = float32(T) / float32(N); pos = float32(n) * scale; lo = floor(pos);
+    hi = min(ceil(pos), T - 1); w = pos - floor(pos)`` -- all float32 (resize_bilinear CPU kernel,
+    reached through ddsp.core.resample -> tf.compat.v1.image.resize).
+    """
+    scale = F32(n_frames) / F32(n_timesteps)
+    pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
+    fl = np.floor(pos).astype(F32)
+    lo = fl.astype(np.int64)
+    hi = np.minimum(np.ceil(pos).astype(np.int64), n_frames - 1)
+    w = (pos - fl).astype(F32)
+    return lo, hi, w
+
+
+def resample_linear(inputs, n_timesteps):
+    """ddsp.core.resample(method='linear'): [B,T,C] -> [B,N,C] (call site inharm_synth.py:117)."""
+    x = tf_float32(inputs)
+    lo, hi, w = linear_resample_positions(x.shape[1], n_timesteps)
+    top = x[:, lo, :]
+    bot = x[:, hi, :]
+    return (top + ((bot - top).astype(F32) * w[None, :, None]).astype(F32)).astype(F32)
+
+
+def overlap_and_add(frames, frame_step):
+    """tf.signal.overlap_and_add: [..., F, W] -> [..., (F - 1) * step + W]."""
+    frames = tf_float32(frames)
+    n_frames, frame_len = frames.shape[-2], frames.shape[-1]
+    out_len = (n_frames - 1) * frame_step + frame_len
+    out = np.zeros(frames.shape[:-2] + (out_len,), F32)
+    for f in range(n_frames):
+        out[..., f * frame_step: f * frame_step + frame_len] += frames[..., f, :]
+    return out
+
+
+def upsample_with_windows(inputs, n_timesteps, add_endpoint=True):
+    """ddsp.core.upsample_with_windows (overlapping Hann windows), literal restatement."""
+    x = tf_float32(inputs)
+    if x.ndim != 3:
+        raise ValueError('Upsample_with_windows() only supports 3 dimensions, not {}.'.format(x.shape))
+    if add_endpoint:
+        x = np.concatenate([x, x[:, -1:, :]], axis=1)
+    n_frames = int(x.shape[1])
+    n_intervals = n_frames - 1
+    if n_frames >= n_timesteps:
+        raise ValueError('Upsample with windows cannot be used for downsampling'
+                         'More input frames ({}) than output timesteps ({})'.format(n_frames, n_timesteps))
+    if n_timesteps % n_intervals != 0.0:
+        raise ValueError('n_timesteps / n_intervals must be an integer')
+    hop_size = n_timesteps // n_intervals
+    window = hann_window(2 * hop_size)
+    xt = np.transpose(x, [0, 2, 1])                       # [B, C, T+1]
+    # two-term OLA evaluated half by half (a + b is order independent for two float32 terms)
+    out = np.zeros(xt.shape[:2] + (n_frames + 1, hop_size), F32)
+    out[:, :, :n_frames, :] += (xt[..., None] * window[:hop_size]).astype(F32)
+    out[:, :, 1:, :] += (xt[..., None] * window[hop_size:]).astype(F32)
+    out = out.reshape(xt.shape[0], xt.shape[1], -1)
+    out = np.transpose(out, [0, 2, 1])
+    return np.ascontiguousarray(out[:, hop_size:-hop_size, :])
+
+
+def resample(inputs, n_timesteps, method='linear', add_endpoint=True):
+    """ddsp.core.resample; call sites inharm_synth.py:117-119."""
+    x = tf_float32(inputs)
+    is_1d = x.ndim == 1
+    is_2d = x.ndim == 2
+    if is_1d:
+        x = x[None, :, None]
+    if is_2d:
+        x = x[:, :, None]
+    if method == 'linear':
+        if not add_endpoint:
+            raise NotImplementedError('oracle restates align_corners=False only')
+        y = resample_linear(x, n_timesteps)
+    elif method == 'window':
+        y = upsample_with_windows(x, n_timesteps, add_endpoint)
+    else:
+        raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+            method, "['nearest', 'linear', 'cubic', 'window']"))
+    if is_1d:
+        y = y[0, :, 0]
+    if is_2d:
+        y = y[:, :, 0]
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# oscillator bank (inharm_synth.py:49-127 + ddsp.core.angular_cumsum)
+# ----------------------------------------------------------------------------------------------
+def angular_cumsum(angular_frequency, chunk_size=1000):
+    """ddsp.core.angular_cumsum: chunked float32 cumsum with 2*pi wrapping."""
+    x = tf_float32(angular_frequency)
+    n_batch, length = x.shape[0], x.shape[1]
+    rest = x.shape[2:]
+    remainder = length % chunk_size
+    if remainder:
+        pad = chunk_size - remainder
+        x = np.concatenate([x, np.zeros((n_batch, pad) + rest, F32)], axis=1)
+    length_p = x.shape[1]
+    n_chunks = length_p // chunk_size
+    chunks = x.reshape((n_batch, n_chunks, chunk_size) + rest)
+    phase = np.cumsum(chunks, axis=2, dtype=F32)                       # sequential float32 scan
+    offsets = np.mod(phase[:, :, -1:, ...], TWO_PI_F32).astype(F32)
+    offsets = np.concatenate([np.zeros_like(offsets[:, :1]), offsets[:, :-1]], axis=1)
+    offsets = np.mod(np.cumsum(offsets, axis=1, dtype=F32), TWO_PI_F32).astype(F32)
+    phase = (phase + offsets).astype(F32)
+    phase = np.mod(phase, TWO_PI_F32).astype(F32)
+    phase = phase.reshape((n_batch, length_p) + rest)
+    return phase[:, :length]
+
+
+def cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=16000,
+                        sum_sinusoids=True, use_angular_cumsum=False):
+    """inharm_synth.py:49-84."""
+    fe = tf_float32(frequency_envelopes)
+    ae = remove_above_nyquist(fe, amplitude_envelopes, sample_rate)       # :65-67
+    omegas = (fe * TWO_PI_F32).astype(F32)                                # :69
+    omegas = (omegas / F32(float(sample_rate))).astype(F32)               # :70
+    if use_angular_cumsum:
+        phases = angular_cumsum(omegas)                                   # :75
+    else:
+        phases = np.cumsum(omegas, axis=1, dtype=F32)                     # :77
+    wavs = np.cos(phases, dtype=F32)                                      # :80
+    audio = (ae * wavs).astype(F32)                                       # :81
+    if sum_sinusoids:
+        audio = np.sum(audio, axis=-1, dtype=F32)                         # :83
+    return audio
+
+
+def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_distribution=None,
+                       n_samples=64000, sample_rate=16000, amp_resample_method='window',
+                       sum_sinusoids=True, use_angular_cumsum=False):
+    """inharm_synth.py:87-127."""
+    frequencies = tf_float32(frequencies)
+    amplitudes = tf_float32(amplitudes)
+    if harmonic_distribution is not None:
+        harmonic_distribution = tf_float32(harmonic_distribution)
+        n_harmonics = int(harmonic_distribution.shape[-1])
+    else:
+        n_harmonics = 1
+    harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)          # :106
+    if harmonic_shifts is not None:
+        harmonic_frequencies = (harmonic_frequencies *
+                                (F32(1.0) + tf_float32(harmonic_shifts)).astype(F32)).astype(F32)  # :108
+    if harmonic_distribution is not None:
+        harmonic_amplitudes = (amplitudes * harmonic_distribution).astype(F32)         # :112
+    else:
+        harmonic_amplitudes = amplitudes
+    frequency_envelopes = resample(harmonic_frequencies, n_samples)                     # :117
+    amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method)  # :118
+    return cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=sample_rate,
+                               sum_sinusoids=sum_sinusoids, use_angular_cumsum=use_angular_cumsum)
+
+
+# ----------------------------------------------------------------------------------------------
+# Processor protocol (ddsp.processors)
+# ----------------------------------------------------------------------------------------------
+class Processor:
+    def __init__(self, name, trainable=False):
+        self.name = name
+        self.trainable = trainable
+
+    def __call__(self, *args, return_outputs_dict=False, **kwargs):
+        args = [tf_float32(a) for a in args]
+        kwargs = {k: tf_float32(v) for k, v in kwargs.items()}
+        controls = self.get_controls(*args, **kwargs)
+        signal = self.get_signal(**controls)
+        if return_outputs_dict:
+            return dict(signal=signal, controls=controls)
+        return signal
+
+    def get_controls(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def get_signal(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class InHarmonic(Processor):
+    """inharm_synth.py:130-244."""
+
+    def __init__(self, frame_rate=250, sample_rate=16000, min_frequency=20, scale_fn=exp_sigmoid,
+                 normalize_after_nyquist_cut=True, normalize_below_nyquist=True, inference=False,
+                 name='inharmonic'):
+        self.frame_rate = frame_rate
+        self.sample_rate = sample_rate
+        self.min_frequency = min_frequency
+        self.normalize_after_nyquist_cut = normalize_after_nyquist_cut
+        self.scale_fn = scale_fn
+        self.normalize_below_nyquist = normalize_below_nyquist
+        self.inference = inference
+        super().__init__(name=name)
+
+    @property
+    def upsampling(self):
+        return int(self.sample_rate / self.frame_rate)                    # :163-165
+
+    def get_controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+        amplitudes = tf_float32(amplitudes)
+        harmonic_distribution = tf_float32(harmonic_distribution)
+        f0_hz = tf_float32(f0_hz)
+        inharm_coef = np.maximum(tf_float32(inharm_coef), F32(0.0))       # :183
+        if self.scale_fn is not None:
+            amplitudes = self.scale_fn(amplitudes)                        # :185
+            harmonic_distribution = self.scale_fn(harmonic_distribution)  # :186
+        n_harmonics = int(harmonic_distribution.shape[-1])
+        inharmonic_freq, harmonic_shifts = get_inharmonic_freq(f0_hz, inharm_coef, n_harmonics)
+        if not self.normalize_after_nyquist_cut:                          # :194-198
+            harmonic_distribution = safe_divide(
+                harmonic_distribution,
+                np.sum(harmonic_distribution, axis=-1, keepdims=True, dtype=F32))
+        if self.normalize_below_nyquist:                                  # :200-208
+            harmonic_distribution = remove_above_nyquist(inharmonic_freq, harmonic_distribution,
+                                                         self.sample_rate)
+            amplitudes = (amplitudes * (f0_hz > F32(self.min_frequency)).astype(F32)).astype(F32)
+        if self.normalize_after_nyquist_cut:                              # :210-214
+            harmonic_distribution = safe_divide(
+                harmonic_distribution,
+                np.sum(harmonic_distribution, axis=-1, keepdims=True, dtype=F32))
+        return {'amplitudes': amplitudes, 'harmonic_distribution': harmonic_distribution,
+                'harmonic_shifts': harmonic_shifts, 'f0_hz': f0_hz}
+
+    def get_signal(self, amplitudes, harmonic_distribution, harmonic_shifts, f0_hz):
+        return harmonic_synthesis(frequencies=f0_hz, amplitudes=amplitudes,
+                                  harmonic_shifts=harmonic_shifts,
+                                  harmonic_distribution=harmonic_distribution,
+                                  n_samples=self.upsampling * f0_hz.shape[1],   # :240
+                                  sample_rate=self.sample_rate,
+                                  use_angular_cumsum=self.inference)
+
+
+class MultiInharmonic(InHarmonic):
+    """inharm_synth.py:247-293."""
+
+    def __init__(self, name='multi_inharmonic', **kwargs):
+        super().__init__(name=name, **kwargs)
+
+    def get_controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+        f0_hz = tf_float32(f0_hz)
+        controls = super().get_controls(amplitudes, harmonic_distribution, inharm_coef,
+                                        f0_hz[..., 0:1])                  # :260-265
+        controls['f0_hz'] = f0_hz                                         # :267
+        controls['amplitudes'] = (controls['amplitudes'] / F32(f0_hz.shape[-1])).astype(F32)  # :269
+        return controls
+
+    def get_signal(self, amplitudes, harmonic_distribution, harmonic_shifts, f0_hz):
+        n_substrings = f0_hz.shape[-1]
+        audio = super().get_signal(amplitudes, harmonic_distribution, harmonic_shifts,
+                                   f0_hz[..., 0:1])                       # :279-284
+        for substring in range(1, n_substrings):                          # :286-292
+            audio = (audio + super().get_signal(amplitudes, harmonic_distribution, harmonic_shifts,
+                                                f0_hz[..., substring:substring + 1])).astype(F32)
+        return audio
+
+
+class MultiAdd(Processor):
+    """inharm_synth.py:296-309: python ``sum`` of the signals (0 + s0 + s1 + ...)."""
+
+    def __init__(self, name='add'):
+        super().__init__(name=name)
+
+    def get_controls(self, *signals):
+        return {f'signal_{i}': s for i, s in enumerate(signals)}
+
+    def get_signal(self, **signals):
+        vals = list(signals.values())
+        out = tf_float32(vals[0])
+        for v in vals[1:]:
+            out = (out + tf_float32(v)).astype(F32)
+        return out
+
+
+class Add(Processor):
+    """ddsp.processors.Add (used by default_model.py:56-74)."""
+
+    def __init__(self, name='add'):
+        super().__init__(name=name)
+
+    def get_controls(self, signal_one, signal_two):
+        return {'signal_one': signal_one, 'signal_two': signal_two}
+
+    def get_signal(self, signal_one, signal_two):
+        return (tf_float32(signal_one) + tf_float32(signal_two)).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# FilteredNoise (ddsp.synths.FilteredNoise / ddsp.core.frequency_filter)
+# ----------------------------------------------------------------------------------------------
+def get_fft_size(frame_size, ir_size, power_of_2=True):
+    """ddsp.core.get_fft_size."""
+    convolved_frame_size = ir_size + frame_size - 1
+    if power_of_2:
+        return int(2 ** np.ceil(np.log2(convolved_frame_size)))
+    return int(convolved_frame_size)
+
+
+def apply_window_to_impulse_response(impulse_response, window_size=0, causal=False):
+    """ddsp.core.apply_window_to_impulse_response (zero-phase in, causal linear-phase out)."""
+    ir = tf_float32(impulse_response)
+    if causal:
+        ir = np.fft.fftshift(ir, axes=-1)
+    ir_size = int(ir.shape[-1])
+    if (window_size <= 0) or (window_size > ir_size):
+        window_size = ir_size
+    window = hann_window(window_size)
+    padding = ir_size - window_size
+    if padding > 0:
+        half_idx = (window_size + 1) // 2
+        window = np.concatenate([window[half_idx:], np.zeros([padding], F32), window[:half_idx]], axis=0)
+    else:
+        window = np.fft.fftshift(window, axes=-1)
+    ir = (window * ir).astype(F32)
+    if padding > 0:
+        first_half_start = (ir_size - (half_idx - 1)) + 1
+        second_half_end = half_idx + 1
+        ir = np.concatenate([ir[..., first_half_start:], ir[..., :second_half_end]], axis=-1)
+    else:
+        ir = np.fft.fftshift(ir, axes=-1)
+    return np.ascontiguousarray(ir)
+
+
+def frequency_impulse_response(magnitudes, window_size=0):
+    """ddsp.core.frequency_impulse_response: irfft(complex(mag, 0)) then window."""
+    mags = tf_float32(magnitudes)
+    ir = sfft.irfft(mags.astype(np.float64), axis=-1).astype(F32)      # length 2 (K - 1)
+    return apply_window_to_impulse_response(ir, window_size)
+
+
+def crop_and_compensate_delay(audio, audio_size, ir_size, padding, delay_compensation):
+    """ddsp.core.crop_and_compensate_delay."""
+    if padding == 'valid':
+        crop_size = ir_size + audio_size - 1
+    elif padding == 'same':
+        crop_size = audio_size
+    else:
+        raise ValueError('Padding must be \'valid\' or \'same\', instead of {}.'.format(padding))
+    total_size = int(audio.shape[-1])
+    crop = total_size - crop_size
+    start = (ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation
+    end = crop - start
+    return audio[:, start:total_size - end] if end != 0 else audio[:, start:0]
+
+
+def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1):
+    """ddsp.core.fft_convolve (call site fdn_reverb.py:409; used by Reverb and frequency_filter)."""
+    audio = tf_float32(audio)
+    ir = tf_float32(impulse_response)
+    if ir.ndim == 2:
+        ir = ir[:, None, :]
+    batch_size_ir, n_ir_frames, ir_size = ir.shape
+    batch_size, audio_size = audio.shape
+    if batch_size_ir == 1 and batch_size > 1:
+        ir = np.tile(ir, [batch_size, 1, 1])
+        batch_size_ir = batch_size
+    if batch_size != batch_size_ir:
+        raise ValueError('Batch size of audio ({}) and impulse response ({}) must be the same.'.format(
+            batch_size, batch_size_ir))
+    frame_size = int(np.ceil(audio_size / n_ir_frames))
+    hop_size = frame_size
+    n_audio_frames = int(np.ceil(audio_size / hop_size))                 # tf.signal.frame(pad_end=True)
+    if n_audio_frames != n_ir_frames:
+        raise ValueError('Number of Audio frames ({}) and impulse response frames ({}) do not match. '
+                         'For small hop size = ceil(audio_size / n_ir_frames), number of impulse '
+                         'response frames must be a multiple of the audio size.'.format(
+                             n_audio_frames, n_ir_frames))
+    padded = np.zeros([batch_size, n_audio_frames * hop_size], F32)
+    padded[:, :audio_size] = audio
+    audio_frames = padded.reshape(batch_size, n_audio_frames, frame_size)
+    fft_size = get_fft_size(frame_size, ir_size, power_of_2=True)
+    audio_fft = sfft.rfft(audio_frames.astype(np.float64), fft_size, axis=-1)
+    ir_fft = sfft.rfft(ir.astype(np.float64), fft_size, axis=-1)
+    audio_frames_out = sfft.irfft(audio_fft * ir_fft, fft_size, axis=-1).astype(F32)
+    audio_out = overlap_and_add(audio_frames_out, hop_size)
+    return np.ascontiguousarray(
+        crop_and_compensate_delay(audio_out, audio_size, ir_size, padding, delay_compensation))
+
+
+def frequency_filter(audio, magnitudes, window_size=0, padding='same'):
+    """ddsp.core.frequency_filter (call site filtered_noise_synth.py:41-42)."""
+    impulse_response = frequency_impulse_response(magnitudes, window_size=window_size)
+    return fft_convolve(audio, impulse_response, padding=padding)
+
+
+class FilteredNoise(Processor):
+    """ddsp.synths.FilteredNoise + DynamicSizeFilteredNoise (filtered_noise_synth.py:12-42).
+
+    The reference draws ``tf.random.uniform([B, U*T], -1, 1)`` unseeded (:39-40); the oracle takes
+    the noise as an explicit argument so that the deterministic part can be compared.
+    """
+
+    def __init__(self, frame_rate=250, sample_rate=16000, window_size=257, scale_fn=exp_sigmoid,
+                 initial_bias=-5.0, name='filtered_noise'):
+        super().__init__(name=name)
+        self.frame_rate = frame_rate
+        self.sample_rate = sample_rate
+        self.window_size = window_size
+        self.scale_fn = scale_fn
+        self.initial_bias = initial_bias
+
+    @property
+    def upsampling(self):
+        return int(self.sample_rate / self.frame_rate)
+
+    def get_controls(self, magnitudes):
+        magnitudes = tf_float32(magnitudes)
+        if self.scale_fn is not None:
+            magnitudes = self.scale_fn((magnitudes + F32(self.initial_bias)).astype(F32))
+        return {'magnitudes': magnitudes}
+
+    def get_signal(self, magnitudes, noise=None):
+        batch_size, n_frames = magnitudes.shape[0], magnitudes.shape[1]
+        n_samples = self.upsampling * n_frames
+        if noise is None:
+            raise ValueError('oracle FilteredNoise needs the noise tensor [B, U*T] explicitly')
+        noise = tf_float32(noise)
+        assert noise.shape == (batch_size, n_samples)
+        return frequency_filter(noise, magnitudes, window_size=self.window_size)
+
+
+# ----------------------------------------------------------------------------------------------
+# Reverb (ddsp.effects.Reverb) and FDN apply step (fdn_reverb.py:407-410)
+# ----------------------------------------------------------------------------------------------
+class Reverb(Processor):
+    def __init__(self, trainable=False, reverb_length=48000, add_dry=True, name='reverb'):
+        super().__init__(name=name, trainable=trainable)
+        self._reverb_length = reverb_length
+        self._add_dry = add_dry
+
+    @staticmethod
+    def _mask_dry_ir(ir):
+        ir = tf_float32(ir)
+        if ir.ndim == 1:
+            ir = ir[None, :]
+        if ir.ndim == 3:
+            ir = ir[:, :, 0]
+        dry_mask = np.zeros([ir.shape[0], 1], F32)
+        return np.concatenate([dry_mask, ir[:, 1:]], axis=1)
+
+    def get_controls(self, audio, ir=None):
+        if self.trainable:
+            raise NotImplementedError('trainable Reverb is out of scope (SURVEY.md 8a-11)')
+        if ir is None:
+            raise ValueError('Must provide "ir" tensor if Reverb trainable=False.')
+        return {'audio': audio, 'ir': ir}
+
+    def get_signal(self, audio, ir):
+        audio, ir = tf_float32(audio), tf_float32(ir)
+        ir = self._mask_dry_ir(ir)
+        wet = fft_convolve(audio, ir, padding='same', delay_compensation=0)
+        return (wet + audio).astype(F32) if self._add_dry else wet
+
+
+def fdn_get_signal(audio, ir):
+    """FeedbackDelayNetwork.get_signal, fdn_reverb.py:407-410: no dry mask, no add-dry."""
+    ir = tf_float32(ir)[None, :]
+    return fft_convolve(audio, ir, delay_compensation=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# ProcessorGroup / DAG (ddsp.processors.ProcessorGroup, ddsp.dags.DAGLayer)
+# ----------------------------------------------------------------------------------------------
+def _nested_lookup(key, d):
+    out = d
+    for k in key.split('/'):
+        out = out[k]
+    return out
+
+
+class ProcessorGroup:
+    def __init__(self, dag, name='processor_group'):
+        self.dag = list(dag)
+        self.name = name
+        self.processors = []
+        for node in self.dag:
+            p = node[0]
+            if p not in self.processors:
+                self.processors.append(p)
+
+    def __call__(self, inputs, return_outputs_dict=False, extra_kwargs=None):
+        """extra_kwargs: {processor_name: [kwargs per call]} -- oracle-only hook to pass noise."""
+        outputs = {'inputs': inputs}
+        outputs.update(inputs)
+        counters = {}
+        module_outputs = None
+        for node in self.dag:
+            processor, input_keys = node[0], node[1]
+            args = [_nested_lookup(k, outputs) for k in input_keys]
+            kw = {}
+            if extra_kwargs and processor.name in extra_kwargs:
+                i = counters.get(processor.name, 0)
+                kw = extra_kwargs[processor.name][i]
+                counters[processor.name] = i + 1
+            controls = processor.get_controls(*[tf_float32(a) for a in args])
+            signal = processor.get_signal(**controls, **kw)
+            module_outputs = {'signal': signal, 'controls': controls}
+            outputs[processor.name] = module_outputs
+        outputs['out'] = module_outputs
+        if return_outputs_dict:
+            return {'signal': module_outputs['signal'], 'controls': outputs}
+        return module_outputs['signal']
+
+
+def polyphonic_dag(additive, noise, reverb=None,
+                   additive_controls=('amps', 'harmonic_distribution', 'f0_hz'),
+                   noise_controls=('noise_magnitudes',), reverb_controls=(), n_synths=16):
+    """polyphonic_dag.py:5-42."""
+    add = MultiAdd(name='add')
+    dag = [(additive, [c + '_0' for c in additive_controls]),
+           (noise, [c + '_0' for c in noise_controls]),
+           (add, [noise.name + '/signal', additive.name + '/signal'])]
+    for i in range(1, n_synths):
+        dag.append((additive, [c + f'_{i}' for c in additive_controls]))
+        dag.append((noise, [c + f'_{i}' for c in noise_controls]))
+        dag.append((add, ['add/signal', noise.name + '/signal', additive.name + '/signal']))
+    if reverb is not None:
+        dag.append((reverb, ['add/signal'] + list(reverb_controls)))
+    return dag
+
+
+def midi_to_hz(notes):
+    """ddsp.core.midi_to_hz."""
+    return 440.0 * (2.0 ** ((np.asarray(notes, np.float64) - 69.0) / 12.0))

@@ -1,0 +1,117 @@
+"""GPU parity: the whole polyphonic ProcessorGroup (batched route and node-by-node route) vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from util import O, rms, rms_err, synth_controls, synth_ir
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _features(rng, B, P, T, H, K, S, L):
+    feats = {}
+    for i in range(P):
+        c = synth_controls(rng, B, T, H, S=S, K=K)
+        for k, v in c.items():
+            feats[f'{k}_{i}'] = v
+    feats['reverb_ir'] = synth_ir(rng, B, L)
+    return feats
+
+
+def _build(mod, P, sr, inference=True, scale=None, with_reverb=True):
+    kw = {}
+    if scale is not None:
+        kw['scale_fn'] = scale
+    additive = mod.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=inference, **kw)
+    if mod is O:
+        noise = mod.FilteredNoise(name='noise', frame_rate=250, sample_rate=sr, **kw)
+    else:
+        noise = mod.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr, **kw)
+    reverb = mod.Reverb(name='reverb') if with_reverb else None
+    dag = mod.polyphonic_dag(additive, noise, reverb,
+                             additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
+                             noise_controls=['magnitudes'], reverb_controls=['reverb_ir'] if with_reverb else [],
+                             n_synths=P)
+    return dag, noise
+
+
+@pytest.mark.parametrize('B,P,T,H,K,S,sr,L', [
+    (2, 3, 50, 128, 96, 1, 24000, 4000),     # maestro-v2 dims, down-sized
+    (1, 2, 50, 96, 64, 2, 16000, 3000),      # dafx22 dims (two sub-strings), SURVEY 8c down-sized C2
+    (2, 16, 20, 96, 64, 1, 24000, 2000),     # full polyphony
+])
+def test_processor_group_matches_oracle(B, P, T, H, K, S, sr, L):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(1234)
+    feats = _features(rng, B, P, T, H, K, S, L)
+    N = T * (sr // 250)
+    noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
+
+    odag, _ = _build(O, P, sr)
+    oref = O.ProcessorGroup(odag)(feats, return_outputs_dict=True,
+                                  extra_kwargs={'noise': [{'noise': z} for z in noises]})
+    gfeats = {k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}
+
+    for fast in (True, False):
+        gdag, gnoise = _build(dp, P, sr)
+        gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
+        if not fast:       # node-by-node route: feed the same noise through get_signal
+            orig = gnoise.get_signal
+            gnoise.get_signal = lambda magnitudes, _o=orig, _n=gnoise: _o(magnitudes, noise=_n.noise_override.pop(0))
+        pg = dp.ProcessorGroup(gdag, fast_path=fast)
+        out = pg(gfeats, return_outputs_dict=True)
+        sig = out['signal'].cpu().numpy()
+        ref = oref['signal']
+        assert sig.shape == ref.shape == (B, N)
+        err = rms_err(sig, ref)
+        assert err < TOL * max(1.0, rms(ref)), f'fast={fast}: {err:.3e} vs rms {rms(ref):.3e}'
+        ctl = out['controls']
+        dry = ctl['add']['signal'].cpu().numpy()
+        assert rms_err(dry, oref['controls']['add']['signal']) < TOL
+        # the reused processors leave the LAST voice behind (polyphonic_dag.py re-uses three objects)
+        assert rms_err(ctl['additive']['signal'].cpu().numpy(), oref['controls']['additive']['signal']) < TOL
+        assert rms_err(ctl['noise']['signal'].cpu().numpy(), oref['controls']['noise']['signal']) < TOL
+        assert 'reverb_ir' in ctl and 'amplitudes_0' in ctl and ctl['out'] is ctl['reverb']
+        assert [p.name for p in pg.processors] == ['additive', 'noise', 'add', 'reverb']
+
+
+def test_fast_path_zero_copy_views_and_no_reverb():
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import polyphonic
+    rng = np.random.default_rng(5)
+    B, P, T, H, K, sr = 2, 4, 20, 64, 32, 16000
+    base = {k: torch.as_tensor(rng.normal(0, 1, [B, P, T, c]).astype(np.float32), device='cuda')
+            for k, c in (('amplitudes', 1), ('harmonic_distribution', H), ('magnitudes', K))}
+    base['inharm_coef'] = torch.full((B, P, T, 1), 1e-4, device='cuda')
+    base['f0_hz'] = torch.as_tensor(rng.uniform(50, 2000, [B, P, 1, 1]).astype(np.float32), device='cuda').expand(B, P, T, 1).contiguous()
+    feats = {f'{k}_{i}': v[:, i] for k, v in base.items() for i in range(P)}
+    stacked = polyphonic._stack_voices([feats[f'harmonic_distribution_{i}'] for i in range(P)])
+    assert stacked.data_ptr() == base['harmonic_distribution'].data_ptr()      # no copy made
+    dag, _ = _build(dp, P, sr, with_reverb=False)
+    a = dp.ProcessorGroup(dag, fast_path=True)
+    dagb, _ = _build(dp, P, sr, with_reverb=False)
+    b = dp.ProcessorGroup(dagb, fast_path=False)
+    noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * 64]).astype(np.float32), device='cuda')
+    a.noise.noise_override = [noise[:, i] for i in range(P)]
+    b.noise.noise_override = [noise[:, i] for i in range(P)]
+    orig = b.noise.get_signal
+    b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
+    ya, yb = a(feats), b(feats)
+    assert ya.shape == (B, T * 64)
+    assert (ya - yb).abs().max().item() < 2e-6
+
+
+def test_standalone_processors_like_synthesize_from_csv():
+    """synthesize_from_csv.py:99-120 calls processors[:2] outside the group."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(9)
+    dag, _ = _build(dp, 2, 24000)
+    pg = dp.ProcessorGroup(dag)
+    additive, noise = pg.processors[:2]
+    c = {k: torch.as_tensor(v, device='cuda') for k, v in synth_controls(rng, 1, 30, 128, K=96).items()}
+    sig = additive.get_signal(**additive.get_controls(c['amplitudes'], c['harmonic_distribution'],
+                                                      c['inharm_coef'], c['f0_hz']))
+    nz = noise.get_signal(**noise.get_controls(c['magnitudes']))
+    assert sig.shape == nz.shape == (1, 30 * 96)
+    assert pg.processors[0].sample_rate == 24000        # piano_model.py:70-72

@@ -1,0 +1,147 @@
+"""GPU parity: FilteredNoise (FIR design + time-varying FIR) and the rocFFT reverb vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from util import O, rms, rms_err, synth_ir
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(x):
+    return torch.as_tensor(x, device='cuda')
+
+
+@pytest.mark.parametrize('K,window_size', [(96, 257), (64, 257), (32, 257), (128, 257), (200, 257), (65, 0),
+                                           (129, 257)])
+def test_frequency_impulse_response(K, window_size):
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(K)
+    mags = rng.uniform(0, 2, [2, 13, K]).astype(np.float32)
+    ref = O.frequency_impulse_response(mags, window_size)
+    got = core.frequency_impulse_response(_dev(mags), window_size).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('B,T,U,K', [(2, 40, 96, 96), (2, 30, 64, 64), (3, 50, 32, 32), (1, 20, 128, 128),
+                                     (2, 12, 192, 96), (2, 750, 96, 96), (1, 9, 100, 20)])
+def test_frequency_filter_matches_oracle(B, T, U, K):
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(T + U)
+    mags = rng.uniform(0, 1, [B, T, K]).astype(np.float32) ** 4
+    noise = rng.uniform(-1, 1, [B, T * U]).astype(np.float32)
+    ref = O.frequency_filter(noise, mags, window_size=257)
+    got = core.frequency_filter(_dev(noise), _dev(mags), window_size=257).cpu().numpy()
+    err = rms_err(got, ref)
+    assert err < TOL * max(1.0, rms(ref)), f'{err:.3e} vs rms {rms(ref):.3e}'
+
+
+def test_tiled_and_generic_fir_agree(monkeypatch):
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(2)
+    B, T, U, K = 2, 60, 96, 96
+    mags = _dev(rng.uniform(0, 1, [B, T, K]).astype(np.float32))
+    noise = _dev(rng.uniform(-1, 1, [B, T * U]).astype(np.float32))
+    a = core.frequency_filter(noise, mags, window_size=257)
+    monkeypatch.setenv('DDSPP_FIR_GENERIC', '1')
+    b = core.frequency_filter(noise, mags, window_size=257)
+    assert (a - b).abs().max().item() < 2e-6
+
+
+def test_flat_magnitudes_delay_noise_by_two_samples():
+    """KAT: a flat spectrum yields the input delayed by 2 samples, gain 1."""
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(0)
+    noise = rng.uniform(-1, 1, [1, 40 * 96]).astype(np.float32)
+    got = core.frequency_filter(_dev(noise), torch.ones(1, 40, 96, device='cuda'), 257).cpu().numpy()
+    assert np.abs(got[0, 2:] - noise[0, :-2]).max() < 2e-6
+
+
+def test_filtered_noise_processor():
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(6)
+    B, T, K, sr = 2, 30, 96, 24000
+    raw = rng.normal(0, 1, [B, T, K]).astype(np.float32)
+    noise = rng.uniform(-1, 1, [B, T * 96]).astype(np.float32)
+    o = O.FilteredNoise(frame_rate=250, sample_rate=sr)
+    g = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=sr)
+    octl = o.get_controls(raw)
+    gctl = g.get_controls(_dev(raw))
+    np.testing.assert_allclose(gctl['magnitudes'].cpu().numpy(), octl['magnitudes'], rtol=2e-5, atol=1e-9)
+    ref = o.get_signal(octl['magnitudes'], noise=noise)
+    got = g.get_signal(_dev(octl['magnitudes']), noise=_dev(noise)).cpu().numpy()
+    assert rms_err(got, ref) < TOL
+    # unseeded draw: right shape, right range, different on every call
+    a, b = g(_dev(raw)), g(_dev(raw))
+    assert a.shape == (B, T * 96) and not torch.equal(a, b)
+
+
+def test_uniform_noise_statistics():
+    from ddsp_piano_amd import core
+    x = core.uniform_noise((4, 100000), seed=3).cpu().numpy()
+    assert x.min() >= -1.0 and x.max() < 1.0
+    assert abs(x.mean()) < 5e-3 and abs(x.std() - 1 / np.sqrt(3)) < 5e-3
+    y = core.uniform_noise((4, 100000), seed=3).cpu().numpy()
+    z = core.uniform_noise((4, 100000), seed=4).cpu().numpy()
+    assert np.array_equal(x, y) and not np.array_equal(x, z)
+
+
+@pytest.mark.parametrize('B,N,L,add_dry', [(2, 7200, 4800, True), (3, 24000, 24000, True),
+                                           (2, 72000, 48000, False), (1, 72000, 72000, True)])
+def test_reverb_matches_oracle(B, N, L, add_dry):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(N + L)
+    audio = rng.normal(0, 0.1, [B, N]).astype(np.float32)
+    ir = synth_ir(rng, B, L)
+    ref = O.Reverb(add_dry=add_dry).get_signal(audio, ir)
+    got = dp.Reverb(add_dry=add_dry).get_signal(_dev(audio), _dev(ir)).cpu().numpy()
+    err = rms_err(got, ref)
+    assert err < TOL * max(1.0, rms(ref)), f'{err:.3e} vs rms {rms(ref):.3e}'
+
+
+def test_reverb_kats():
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(1)
+    audio = rng.normal(0, 1, [2, 4096]).astype(np.float32)
+    d = 37
+    ir = np.zeros([2, 512], np.float32)
+    ir[:, d] = 1.0
+    ir[:, 0] = 5.0                                  # the dry tap is masked away
+    got = dp.Reverb().get_signal(_dev(audio), _dev(ir)).cpu().numpy()
+    ref = audio.copy()
+    ref[:, d:] += audio[:, :-d]
+    assert np.abs(got - ref).max() < 1e-5
+    # ir with only the masked tap: out = dry
+    ir0 = np.zeros([2, 512], np.float32)
+    ir0[:, 0] = 1.0
+    assert np.abs(dp.Reverb().get_signal(_dev(audio), _dev(ir0)).cpu().numpy() - audio).max() < 1e-5
+    # shared 1-D impulse response, 3-D [B, L, 1] impulse response
+    one = dp.Reverb().get_signal(_dev(audio), _dev(ir[0])).cpu().numpy()
+    three = dp.Reverb().get_signal(_dev(audio), _dev(ir[:, :, None])).cpu().numpy()
+    assert np.abs(one - ref).max() < 1e-5 and np.abs(three - ref).max() < 1e-5
+    with pytest.raises(ValueError):
+        dp.Reverb().get_controls(_dev(audio))        # non-trainable reverb needs an ir
+    with pytest.raises(ValueError):
+        dp.Reverb().get_signal(_dev(audio), _dev(np.zeros([3, 512], np.float32)))
+
+
+def test_fdn_apply_and_fft_convolve_valid():
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(12)
+    audio = rng.normal(0, 1, [2, 3000]).astype(np.float32)
+    ir = (rng.normal(0, 1, [2000]) * np.exp(-np.arange(2000) / 300.0)).astype(np.float32)
+    ref = O.fdn_get_signal(audio, ir)
+    got = dp.FeedbackDelayNetworkApply().get_signal(_dev(audio), _dev(ir)).cpu().numpy()
+    assert rms_err(got, ref) < TOL * rms(ref)
+    refv = O.fft_convolve(audio, np.tile(ir[None], [2, 1]), padding='valid', delay_compensation=0)
+    gotv = core.fft_convolve(_dev(audio), _dev(np.tile(ir[None], [2, 1])), padding='valid',
+                             delay_compensation=0).cpu().numpy()
+    assert gotv.shape == refv.shape == (2, 4999)
+    assert rms_err(gotv, refv) < TOL * rms(refv)
+    with pytest.raises(ValueError):
+        core.fft_convolve(_dev(audio), _dev(np.zeros([3, 10], np.float32)))
+    with pytest.raises(ValueError):
+        core.fft_convolve(_dev(audio), _dev(np.zeros([2, 7, 10], np.float32)))   # frame-count mismatch

@@ -1,0 +1,202 @@
+"""GPU parity: oscillator bank, upsamplers and harmonic_synthesis against the CPU oracle.
+
+Tolerance: BASELINE.json north_star -- audio within 1e-4 RMS (float32) of the reference on identical
+inputs.  The phase arithmetic is bit-faithful, so the observed error is float32 round-off of cos and
+of the harmonic sum (~1e-7); tests assert 1e-5 RMS to leave no room for an order-of-operations slip.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import O, rms, rms_err, synth_controls
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(x):
+    return torch.as_tensor(x, device='cuda')
+
+
+def _envelopes(rng, B, N, H, sr, fmax_scale=1.3):
+    """Slowly varying positive frequency envelopes (some above Nyquist) and amplitudes."""
+    f0 = rng.uniform(30.0, sr / 2 * fmax_scale / H, [B, 1, 1])
+    k = np.arange(1, H + 1)[None, None, :]
+    vib = 1.0 + 0.01 * np.sin(2 * np.pi * 5.0 * np.arange(N)[None, :, None] / sr + rng.uniform(0, 6, [B, 1, 1]))
+    fe = (f0 * k * vib).astype(np.float32)
+    ae = (rng.uniform(0, 1, [B, N, H]) / H).astype(np.float32)
+    return fe, ae
+
+
+@pytest.mark.parametrize('B,N,H,sr,angular,spans', [
+    (2, 4000, 64, 16000, True, 1),
+    (2, 4000, 64, 16000, True, 4),
+    (1, 24000, 64, 24000, True, 0),       # BASELINE config 1 shape: 1 s, 64 harmonics
+    (3, 7000, 96, 24000, True, 3),        # partial last chunk, VPL=2 with idle lanes
+    (2, 5000, 128, 24000, True, 2),
+    (1, 3000, 192, 32000, True, 0),       # VPL=3
+    (2, 2400, 48, 8000, True, 0),
+    (2, 4000, 64, 16000, False, 0),       # plain tf.cumsum (training path), short
+    (1, 2048, 7, 22050, True, 0),         # odd sinusoid count
+])
+def test_cos_oscillator_bank_matches_oracle(B, N, H, sr, angular, spans):
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(1234 + N + H)
+    fe, ae = _envelopes(rng, B, N, H, sr)
+    ref = O.cos_oscillator_bank(fe, ae, sample_rate=sr, use_angular_cumsum=angular)
+    got = core.cos_oscillator_bank(_dev(fe), _dev(ae), sample_rate=sr, use_angular_cumsum=angular,
+                                   spans=spans).cpu().numpy()
+    assert got.shape == ref.shape
+    err = rms_err(got, ref)
+    assert err < TOL, f'rms err {err:.3e} (signal rms {rms(ref):.3e})'
+
+
+def test_spans_are_bitwise_equivalent():
+    """Cutting time into spans (pre-pass + offset scan) must not change a single bit of the phase."""
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(7)
+    fe, ae = _envelopes(rng, 2, 12000, 96, 24000)
+    a = core.cos_oscillator_bank(_dev(fe), _dev(ae), 24000, use_angular_cumsum=True, spans=1)
+    b = core.cos_oscillator_bank(_dev(fe), _dev(ae), 24000, use_angular_cumsum=True, spans=12)
+    c = core.cos_oscillator_bank(_dev(fe), _dev(ae), 24000, use_angular_cumsum=True, spans=5)
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_unsummed_sinusoids():
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(11)
+    fe, ae = _envelopes(rng, 1, 3000, 64, 16000)
+    ref = O.cos_oscillator_bank(fe, ae, 16000, sum_sinusoids=False, use_angular_cumsum=True)
+    got = core.cos_oscillator_bank(_dev(fe), _dev(ae), 16000, sum_sinusoids=False,
+                                   use_angular_cumsum=True).cpu().numpy()
+    assert got.shape == ref.shape == (1, 3000, 64)
+    assert np.abs(got - ref).max() < 2e-6
+
+
+def test_above_nyquist_partials_contribute_exactly_zero():
+    from ddsp_piano_amd import core
+    N, H, sr = 2000, 64, 16000
+    fe = np.full([1, N, H], 9000.0, np.float32)       # >= sr / 2 everywhere
+    fe[..., 0] = 8000.0                                # exactly Nyquist is removed too (>=)
+    ae = np.ones([1, N, H], np.float32)
+    got = core.cos_oscillator_bank(_dev(fe), _dev(ae), sr, use_angular_cumsum=True).cpu().numpy()
+    assert np.all(got == 0.0)
+
+
+def test_negative_and_huge_frequencies_take_the_generic_path():
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(5)
+    N, H, sr = 3000, 64, 16000
+    fe = rng.uniform(-3000.0, 3000.0, [1, N, H]).astype(np.float32)
+    fe[0, :, 3] = 3.0e9                                 # phase beyond the fast-mod range
+    fe[0, :, 5] = 1e-33                                 # denormal-quotient territory for the division
+    ae = (rng.uniform(0, 1, [1, N, H]) / H).astype(np.float32)
+    ref = O.cos_oscillator_bank(fe, ae, sr, use_angular_cumsum=True)
+    got = core.cos_oscillator_bank(_dev(fe), _dev(ae), sr, use_angular_cumsum=True).cpu().numpy()
+    assert rms_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize('T,U,C', [(50, 96, 128), (40, 64, 96), (25, 32, 48), (30, 96, 1), (20, 100, 6)])
+def test_resample_kernels_are_bit_exact(T, U, C):
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(T * U + C)
+    x = rng.normal(0, 1, [2, T, C]).astype(np.float32)
+    N = T * U
+    lin = core.resample(_dev(x), N).cpu().numpy()
+    win = core.resample(_dev(x), N, method='window').cpu().numpy()
+    assert np.array_equal(lin, O.resample(x, N))
+    assert np.array_equal(win, O.resample(x, N, method='window'))
+
+
+def test_resample_linear_non_integer_ratio():
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, [2, 37, 8]).astype(np.float32)
+    got = core.resample(_dev(x), 1000).cpu().numpy()
+    assert np.array_equal(got, O.resample(x, 1000))
+
+
+def test_resample_errors_mirror_ddsp():
+    from ddsp_piano_amd import core
+    x = torch.zeros(1, 10, 4, device='cuda')
+    with pytest.raises(ValueError):
+        core.resample(x, 95, method='window')        # n_timesteps % n_intervals != 0
+    with pytest.raises(ValueError):
+        core.resample(x, 10, method='window')        # more frames than time steps
+    with pytest.raises(ValueError):
+        core.resample(x, 100, method='bogus')
+    with pytest.raises(ValueError):
+        core.upsample_with_windows(torch.zeros(10, 4, device='cuda'), 100)
+
+
+@pytest.mark.parametrize('B,T,H,S,sr,fr,angular', [
+    (2, 60, 128, 1, 24000, 250, True),    # maestro-v2 dims
+    (2, 60, 96, 2, 16000, 250, True),     # dafx22 dims: two sub-strings
+    (1, 250, 64, 1, 24000, 250, True),    # BASELINE config 1: 1 s mono, 64 harmonics
+    (2, 40, 48, 1, 8000, 250, True),
+    (1, 30, 192, 1, 32000, 250, True),
+    (2, 20, 96, 2, 16000, 250, False),    # training path (plain cumsum), short
+])
+def test_multi_inharmonic_get_signal_matches_oracle(B, T, H, S, sr, fr, angular):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(99 + T + H)
+    raw = synth_controls(rng, B, T, H, S=S, silent_frac=0.0)
+    osynth = O.MultiInharmonic(frame_rate=fr, sample_rate=sr, inference=angular)
+    gsynth = dp.MultiInharmonic(frame_rate=fr, sample_rate=sr, inference=angular)
+    ctl = osynth.get_controls(raw['amplitudes'], raw['harmonic_distribution'], raw['inharm_coef'], raw['f0_hz'])
+    ref = osynth.get_signal(**ctl)
+    got = gsynth.get_signal(**{k: _dev(v) for k, v in ctl.items()}).cpu().numpy()
+    assert got.shape == ref.shape == (B, T * (sr // fr))
+    err = rms_err(got, ref)
+    assert err < TOL, f'rms err {err:.3e} (signal rms {rms(ref):.3e})'
+
+
+def test_fused_route_equals_three_operator_route_bitwise_phase():
+    """harmonic_synthesis fused from frame controls vs resample -> resample -> cos_oscillator_bank."""
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(21)
+    B, T, H, U, sr = 2, 40, 96, 96, 24000
+    raw = synth_controls(rng, B, T, H, silent_frac=0.0)
+    ctl = O.InHarmonic(sample_rate=sr, inference=True).get_controls(
+        raw['amplitudes'], raw['harmonic_distribution'], raw['inharm_coef'], raw['f0_hz'])
+    f0, amp, hd, sh = (_dev(ctl[k]) for k in ('f0_hz', 'amplitudes', 'harmonic_distribution', 'harmonic_shifts'))
+    fused = core.harmonic_synthesis(f0, amp, sh, hd, n_samples=T * U, sample_rate=sr, use_angular_cumsum=True)
+    hf = core.get_harmonic_frequencies(f0, H) * (1.0 + sh)
+    fe = core.resample(hf, T * U)
+    ae = core.resample(amp * hd, T * U, method='window')
+    three = core.cos_oscillator_bank(fe, ae, sr, use_angular_cumsum=True)
+    # identical phases; amplitudes differ by at most one fused rounding
+    assert (fused - three).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('scale,na,nb', [('exp_sigmoid', True, True), ('exp_tanh', False, True),
+                                         (None, True, False), ('exp_sigmoid', False, False)])
+def test_inharmonic_get_controls(scale, na, nb):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(4)
+    B, T, H, S, sr = 3, 25, 128, 2, 24000
+    raw = synth_controls(rng, B, T, H, S=S)
+    if scale is None:
+        raw['amplitudes'] = np.abs(raw['amplitudes'])
+        raw['harmonic_distribution'] = np.abs(raw['harmonic_distribution'])
+    ofn = {'exp_sigmoid': O.exp_sigmoid, 'exp_tanh': O.exp_tanh, None: None}[scale]
+    gfn = {'exp_sigmoid': dp.exp_sigmoid, 'exp_tanh': dp.exp_tanh, None: None}[scale]
+    kw = dict(sample_rate=sr, normalize_after_nyquist_cut=na, normalize_below_nyquist=nb)
+    ref = O.MultiInharmonic(scale_fn=ofn, **kw).get_controls(**raw)
+    got = dp.MultiInharmonic(scale_fn=gfn, **kw).get_controls(**{k: _dev(v) for k, v in raw.items()})
+    assert set(got) == set(ref)
+    assert np.array_equal(got['harmonic_shifts'].cpu().numpy(), ref['harmonic_shifts'])   # exact ops only
+    assert np.array_equal(got['f0_hz'].cpu().numpy(), ref['f0_hz'])
+    for k in ('amplitudes', 'harmonic_distribution'):
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k], rtol=2e-5, atol=1e-9)
+
+
+def test_custom_python_scale_fn():
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(8)
+    raw = synth_controls(rng, 2, 10, 64)
+    ref = O.InHarmonic(scale_fn=lambda x: np.exp(np.minimum(x, 3.0)).astype(np.float32)).get_controls(**raw)
+    got = dp.InHarmonic(scale_fn=lambda x: torch.exp(torch.clamp(x, max=3.0))).get_controls(
+        **{k: _dev(v) for k, v in raw.items()})
+    np.testing.assert_allclose(got['harmonic_distribution'].cpu().numpy(), ref['harmonic_distribution'],
+                               rtol=2e-5, atol=1e-9)

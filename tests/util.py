@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests (test infrastructure; may import the oracle)."""
+import numpy as np
+
+from oracle import ddsp_oracle as O
+
+
+def rms(x):
+    x = np.asarray(x, np.float64)
+    return float(np.sqrt(np.mean(x * x)))
+
+
+def rms_err(a, b):
+    return rms(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+
+
+def synth_controls(rng, B, T, H, S=1, K=None, silent_frac=0.25, midi_lo=21, midi_hi=108):
+    """Synthetic post-network controls of one voice, SURVEY.md 8(d) recipe (raw, pre scale_fn)."""
+    m = rng.integers(midi_lo, midi_hi + 1, size=[B, 1, 1]).astype(np.float64)
+    f0 = 440.0 * 2.0 ** ((m - 69.0) / 12.0)
+    detune = 2.0 ** (0.3 * np.arange(S)[None, None, :] / 1200.0)
+    f0 = np.broadcast_to(f0 * detune, [B, T, S]).copy()
+    silent = rng.random([B, 1, 1]) < silent_frac
+    f0 = np.where(silent, 0.0, f0)
+    inharm = np.exp(-0.105 * m - 6.87) + np.exp(0.094 * m - 13.70)
+    inharm = np.broadcast_to(inharm, [B, T, 1]).copy()
+    decay = np.exp(-np.arange(T)[None, :, None] / (0.4 * T))
+    amps = rng.normal(-1.0, 1.0, [B, 1, 1]) * np.ones([1, T, 1]) + 3.0 * (decay - 1.0)
+    hd = rng.normal(0.0, 1.0, [B, T, H]) - 0.05 * np.arange(1, H + 1)[None, None, :]
+    kernel = np.ones(5) / 5.0
+    hd = np.apply_along_axis(lambda v: np.convolve(np.pad(v, 2, mode='edge'), kernel, 'valid'), 1, hd)
+    out = dict(amplitudes=amps.astype(np.float32), harmonic_distribution=hd.astype(np.float32),
+               inharm_coef=inharm.astype(np.float32), f0_hz=f0.astype(np.float32))
+    if K:
+        out['magnitudes'] = rng.normal(0.0, 1.0, [B, T, K]).astype(np.float32)
+    return out
+
+
+def synth_ir(rng, B, L):
+    n = np.arange(L)
+    ir = rng.normal(0.0, 1.0, [B, L]) * np.exp(-6.9 * n / L)[None, :] * 0.02
+    ir[:, 1] = 3.0
+    return ir.astype(np.float32)
+
+
+__all__ = ['O', 'rms', 'rms_err', 'synth_controls', 'synth_ir']
