@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py -- DDSP-Piano synthesis hot path on MI355X: audio samples / second, full chain.
+
+One "step" = one pass of the polyphonic ProcessorGroup (get_controls -> inharmonic oscillator bank
+-> FilteredNoise -> add chain -> reverb) over one batch of synthetic control envelopes that already
+sit in HBM, plus -- when more than one GPU takes part -- the final RCCL all-gather of the audio.
+
+Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments x 3 s, poly=16,
+24 kHz, 250 Hz controls, maestro-v2 dims (H=128 harmonics, K=96 noise bands, S=1), 3 s reverb IR;
+8 GPUs x 64 = the batch=512 of config 4.  The JSON line also carries
+  * roofline     : the operator-boundary cos_oscillator_bank kernel (8 B read per
+                   oscillator-sample + 4 B written per sample) timed with HIP events on materialised
+                   [rows, N, H] envelopes of the same workload, against 8 TB/s;
+  * cpu_baseline : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for
+                   the TF/ddsp reference here) timed on this host on one 3 s, poly=16 segment;
+  * single_stream: the same chain at batch=1 (BASELINE config 2), real-time factor.
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via torch.distributed.run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='segments per GPU')
+    ap.add_argument('--poly', type=int, default=16)
+    ap.add_argument('--harmonics', type=int, default=128)
+    ap.add_argument('--bands', type=int, default=96)
+    ap.add_argument('--substrings', type=int, default=1)
+    ap.add_argument('--seconds', type=float, default=3.0)
+    ap.add_argument('--sample-rate', type=int, default=24000)
+    ap.add_argument('--ir-seconds', type=float, default=3.0)
+    ap.add_argument('--roofline-rows', type=int, default=0, help='rows (segments x voices) of the '
+                    'materialised oscillator-bank measurement; 0 = all rows that fit')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-single-stream', action='store_true')
+    ap.add_argument('--cpu-voices', type=int, default=16)
+    return ap.parse_args()
+
+
+def make_features(B, P, T, H, K, S, L, device, seed):
+    """Synthetic post-network controls, generated on the GPU; per-voice keys are
+    views of one [B, P, T, C] buffer, which is how a batched control network hands them over."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+
+    midi = torch.randint(21, 109, (B, P, 1, 1), generator=g, device=device).to(torch.float32)
+    f0 = 440.0 * torch.pow(2.0, (midi - 69.0) / 12.0)
+    silent = torch.rand(B, P, 1, 1, generator=g, device=device) < 0.25
+    f0 = torch.where(silent, torch.zeros_like(f0), f0)
+    detune = torch.pow(2.0, 0.3 * torch.arange(S, device=device, dtype=torch.float32) / 1200.0)
+    f0 = (f0 * detune.view(1, 1, 1, S)).expand(B, P, T, S).contiguous()
+    inharm = (torch.exp(-0.105 * midi - 6.87) + torch.exp(0.094 * midi - 13.70)).expand(B, P, T, 1).contiguous()
+    decay = torch.exp(-torch.arange(T, device=device, dtype=torch.float32) / (0.4 * T)).view(1, 1, T, 1)
+    amps = (randn(B, P, 1, 1) - 1.0) + 3.0 * (decay - 1.0)
+    amps = amps.expand(B, P, T, 1).contiguous()
+    hd = randn(B, P, T, H) - 0.05 * torch.arange(1, H + 1, device=device, dtype=torch.float32).view(1, 1, 1, H)
+    hd = torch.nn.functional.avg_pool2d(hd.view(B * P, 1, T, H), (5, 1), stride=1, padding=(2, 0),
+                                        count_include_pad=False).view(B, P, T, H).contiguous()
+    mags = randn(B, P, T, K)
+    n = torch.arange(L, device=device, dtype=torch.float32)
+    ir = randn(B, L) * torch.exp(-6.9 * n / L).view(1, L) * 0.02
+    ir[:, 1] = 3.0
+    base = dict(amplitudes=amps, harmonic_distribution=hd, inharm_coef=inharm, f0_hz=f0, magnitudes=mags)
+    feats = {f'{k}_{i}': v[:, i] for k, v in base.items() for i in range(P)}
+    feats['reverb_ir'] = ir.contiguous()
+    return feats, base
+
+
+def build_group(dp, P, sr, frame_rate=250):
+    additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True)
+    noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr)
+    reverb = dp.Reverb(name='reverb', trainable=False)
+    dag = dp.polyphonic_dag(additive, noise, reverb,
+                            additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
+                            noise_controls=['magnitudes'], reverb_controls=['reverb_ir'], n_synths=P)
+    return dp.ProcessorGroup(dag)
+
+
+def time_steps(fn, steps, warmup, dist=None):
+    for _ in range(warmup):
+        fn()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def measure_roofline(dp, base, args, T, U, device):
+    """cos_oscillator_bank at the operator boundary on materialised envelopes (HBM-bound kernel)."""
+    from ddsp_piano_amd import core
+    B, P = base['f0_hz'].shape[:2]
+    H = base['harmonic_distribution'].shape[-1]
+    N = T * U
+    rows_all = B * P
+    free, _ = torch.cuda.mem_get_info()
+    per_row = 2 * N * H * 4 + N * 4
+    rows_fit = int(free * 0.85 // per_row)
+    rows = min(rows_all, rows_fit) if args.roofline_rows <= 0 else min(args.roofline_rows, rows_all, rows_fit)
+    if rows < 1:
+        return None
+    additive = dp.MultiInharmonic(sample_rate=args.sample_rate, inference=True)
+    sl = slice(0, rows)
+    ctl = additive._controls(base['amplitudes'].reshape(rows_all, T, 1)[sl],
+                             base['harmonic_distribution'].reshape(rows_all, T, H)[sl],
+                             base['inharm_coef'].reshape(rows_all, T, 1)[sl],
+                             base['f0_hz'].reshape(rows_all, T, -1)[sl][..., :1].contiguous())
+    hf = core.get_harmonic_frequencies(ctl['f0_hz'], H) * (1.0 + ctl['harmonic_shifts'])
+    ha = ctl['amplitudes'] * ctl['harmonic_distribution']
+    fe = core.resample(hf, N)
+    ae = core.resample(ha, N, method='window')
+    del hf, ha
+    out = torch.empty((rows, N), dtype=torch.float32, device=device)
+    ws, nbytes = core._osc_workspace(rows, N, H, device)
+    lib = core._lib_()
+    stream = torch.cuda.current_stream()
+
+    def launch():
+        rc = lib.ddspp_cos_oscillator_bank(core._ptr(fe), core._ptr(ae), core._ptr(out), rows, N, H,
+                                           float(args.sample_rate), 1, 1, 1, core._ptr(ws), nbytes,
+                                           core._stream())
+        assert rc == 0, core._lib.last_error()
+
+    launch()
+    torch.cuda.synchronize()
+    reps = 5
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        launch()
+        e1.record(stream)
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.mean(times))
+    alg_bytes = rows * (N * H * 8 + N * 4)
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'osc_traffic.json')
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return {'bound': 'hbm', 'achieved': alg_bytes / t / 1e9, 'peak': HBM_PEAK_BYTES / 1e9, 'unit': 'GB/s',
+            'frac': alg_bytes / t / HBM_PEAK_BYTES, 'traffic': traffic,
+            'kernel': 'osc_kernel<VPL=%d,materialised,angular,sum> (ddspp_cos_oscillator_bank, spans=1)' % ((H + 63) // 64),
+            'rows': rows, 'n_samples': N, 'n_harmonics': H, 'algorithmic_bytes_per_launch': alg_bytes,
+            'ms_per_launch': t * 1e3, 'ms_min': float(np.min(times)) * 1e3}
+
+
+def measure_cpu_baseline(args, T, U):
+    """The oracle (numpy restatement of the TF/ddsp reference) on one poly=`cpu_voices` segment."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ddsp_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import synth_controls, synth_ir
+    rng = np.random.default_rng(20240)
+    H, K, S, sr = args.harmonics, args.bands, args.substrings, args.sample_rate
+    P = args.cpu_voices
+    N = T * U
+    L = int(args.ir_seconds * sr)
+    voices = [synth_controls(rng, 1, T, H, S=S, K=K) for _ in range(P)]
+    noises = [rng.uniform(-1, 1, [1, N]).astype(np.float32) for _ in range(P)]
+    ir = synth_ir(rng, 1, L)
+    additive = O.MultiInharmonic(frame_rate=250, sample_rate=sr, inference=True)
+    noise = O.FilteredNoise(frame_rate=250, sample_rate=sr)
+    reverb = O.Reverb()
+    cores = os.cpu_count() or 1
+
+    def voice(i):
+        c = voices[i]
+        a = additive(c['amplitudes'], c['harmonic_distribution'], c['inharm_coef'], c['f0_hz'])
+        z = noise.get_signal(**noise.get_controls(c['magnitudes']), noise=noises[i])
+        return a, z
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        sigs = list(ex.map(voice, range(P)))
+    mix = None
+    for a, z in sigs:
+        mix = (z + a) if mix is None else ((mix + z) + a)
+    out = reverb.get_signal(mix, ir)
+    dt = time.perf_counter() - t0
+    assert out.shape == (1, N)
+    return {'value': N / dt, 'unit': 'audio samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 segment x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, {sr} Hz, full chain '
+                      f'(numpy oracle, {cores} threads over voices), {dt:.1f} s of CPU',
+            'rtf': N / dt / sr}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist_mod.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        dist = dist_mod
+    if args.gpus != world and rank == 0:
+        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import parallel
+
+    sr = args.sample_rate
+    U = sr // 250
+    T = int(round(args.seconds * 250))
+    N = T * U
+    B, P, H, K, S = args.batch, args.poly, args.harmonics, args.bands, args.substrings
+    L = int(args.ir_seconds * sr)
+    feats, base = make_features(B, P, T, H, K, S, L, device, seed=20240 + rank)
+    pg = build_group(dp, P, sr)
+    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        audio = pg(feats)
+        if world > 1:
+            parallel.gather_audio(audio, gathered)
+        return audio
+
+    dt = time_steps(step, args.steps, args.warmup, dist)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_samples = world * B * N * args.steps
+    value = total_samples / dt
+
+    extra = {}
+    if rank == 0 and not args.no_single_stream:
+        f1, _ = make_features(1, P, T, H, K, S, L, device, seed=7)
+        pg1 = build_group(dp, P, sr)
+        d1 = time_steps(lambda: pg1(f1), 20, 3)
+        extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
+                                  'rtf': (N * 20 / d1) / sr}
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        del feats
+        torch.cuda.empty_cache()
+        roof = measure_roofline(dp, base, args, T, U, device)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = measure_cpu_baseline(args, T, U)
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        line = {
+            'metric': 'audio samples/sec synthesized (24 kHz, poly=16), full chain; real-time factor in rtf',
+            'value': value, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'rtf': value / sr,
+            'config': {'workload': f'BASELINE config 3 per GPU: batch={B} x {args.seconds:g} s segments, '
+                                   f'poly={P}, {sr} Hz, 250 Hz controls, H={H}, K={K}, S={S}, '
+                                   f'{args.ir_seconds:g} s reverb IR (L={L}); global batch {world * B}'
+                                   + (' = config 4' if world * B == 512 else ''),
+                       'global_batch': world * B, 'segment_samples': N, 'parallelism': f'batch-shard x{world}'
+                                                                                       + (' + RCCL all-gather' if world > 1 else '')},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,75 @@
+"""Multi-GPU execution of the synthesis path: shard the batch, gather the audio.
+
+Segments (batch rows) are independent units, so the 8 x MI355X node is used data-parallel: one process
+per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), rank r synthesises the contiguous block
+of rows shard_range(B, world, r), and the only collective is the final all-gather of the [B/G, N]
+float32 audio (18.4 MB per GPU at batch 64 x 3 s).  This mirrors what the reference does with
+tf.distribute.MirroredStrategy + ``strategy.gather(outputs, axis=0)``
+(train_single_phase.py:88-102, evaluate_model.py:32-46) without any gradient traffic.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch, world_size, rank):
+    """Contiguous block of rows owned by ``rank`` (blocks differ by at most one row)."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} outside world of size {world_size}')
+    base, rem = divmod(int(global_batch), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_features(features, world_size, rank, batch_axis=0):
+    """Slice every tensor of a ProcessorGroup feature dict to this rank's rows (views, no copies)."""
+    sizes = {v.shape[batch_axis] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() > 0}
+    if len(sizes) != 1:
+        raise ValueError(f'features disagree on the batch size: {sorted(sizes)}')
+    lo, hi = shard_range(sizes.pop(), world_size, rank)
+    out = {}
+    for k, v in features.items():
+        out[k] = v.narrow(batch_axis, lo, hi - lo) if isinstance(v, torch.Tensor) and v.dim() > 0 else v
+    return out
+
+
+def gather_audio(local_audio, out=None, group=None):
+    """All-gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order)."""
+    world = dist.get_world_size(group)
+    local_audio = local_audio.contiguous()
+    if out is None:
+        out = torch.empty((world * local_audio.shape[0],) + tuple(local_audio.shape[1:]),
+                          dtype=local_audio.dtype, device=local_audio.device)
+    try:
+        dist.all_gather_into_tensor(out, local_audio, group=group)
+    except (RuntimeError, NotImplementedError):
+        chunks = list(out.chunk(world, dim=0))
+        dist.all_gather(chunks, local_audio, group=group)
+    return out
+
+
+def gather_audio_uneven(local_audio, global_batch, group=None):
+    """All-gather when global_batch % world != 0: pad to the largest shard, gather, drop the padding."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    biggest = max(shard_range(global_batch, world, r)[1] - shard_range(global_batch, world, r)[0]
+                  for r in range(world))
+    pad = biggest - local_audio.shape[0]
+    x = torch.nn.functional.pad(local_audio, (0, 0, 0, pad)) if pad else local_audio
+    full = gather_audio(x, group=group)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(global_batch, world, r)
+        rows.append(full[r * biggest: r * biggest + (hi - lo)])
+    return torch.cat(rows, dim=0)
+
+
+def synthesize_sharded(processor_group, features, group=None):
+    """features hold the GLOBAL batch on every rank; returns the global audio on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = {v.shape[0] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() > 0}
+    global_batch = sizes.pop()
+    local = processor_group(shard_features(features, world, rank))
+    if global_batch % world == 0:
+        return gather_audio(local, group=group)
+    return gather_audio_uneven(local, global_batch, group=group)

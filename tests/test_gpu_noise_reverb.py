@@ -144,4 +144,4 @@ def test_fdn_apply_and_fft_convolve_valid():
     with pytest.raises(ValueError):
         core.fft_convolve(_dev(audio), _dev(np.zeros([3, 10], np.float32)))
     with pytest.raises(ValueError):
-        core.fft_convolve(_dev(audio), _dev(np.zeros([2, 7, 10], np.float32)))   # frame-count mismatch
+        core.fft_convolve(_dev(audio), _dev(np.zeros([2, 1999, 10], np.float32)))   # frame-count mismatch
