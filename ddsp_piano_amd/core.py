@@ -251,9 +251,41 @@ def _fir_matrix_np(n_bands, window_size):
     return np.ascontiguousarray(_apply_window_rows(basis, int(window_size)).astype(F32))
 
 
+@functools.lru_cache(maxsize=16)
+def _fir_symmetry_np(n_bands, window_size):
+    """(uniq, mirror): taps to evaluate and the tap each one is mirrored onto (-1 = none).
+
+    The windowed zero-phase response is even, so the causal FIR satisfies ir[c + m] == ir[c - m]
+    about its centre tap c; the pairing is verified numerically on the basis matrix itself."""
+    m = _fir_matrix_np(n_bands, window_size).astype(np.float64)
+    lw = m.shape[1]
+    tol = 1e-6 * float(np.abs(m).max())
+    for c in (lw // 2, (lw - 1) // 2):
+        ok = True
+        for d in range(1, lw):
+            lo, hi = c - d, c + d
+            if lo < 0 and hi >= lw:
+                break
+            if lo >= 0 and hi < lw and np.abs(m[:, lo] - m[:, hi]).max() > tol:
+                ok = False
+                break
+        if ok:
+            uniq, mirror = [], []
+            for i in range(lw):
+                j = 2 * c - i
+                if i >= c or j >= lw:          # keep the upper half, and lower taps with no partner
+                    uniq.append(i)
+                    mirror.append(j if (i > c and 0 <= j < lw) else -1)
+            return np.asarray(uniq, np.int32), np.asarray(mirror, np.int32)
+    return np.arange(lw, dtype=np.int32), np.full([lw], -1, np.int32)
+
+
 def fir_matrix(n_bands, window_size, device):
-    return _cached(('firM', int(n_bands), int(window_size), str(device)),
-                   lambda: torch.from_numpy(_fir_matrix_np(int(n_bands), int(window_size))).to(device))
+    def build():
+        uniq, mirror = _fir_symmetry_np(int(n_bands), int(window_size))
+        return (torch.from_numpy(_fir_matrix_np(int(n_bands), int(window_size))).to(device),
+                torch.from_numpy(uniq).to(device), torch.from_numpy(mirror).to(device))
+    return _cached(('firM', int(n_bands), int(window_size), str(device)), build)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -420,11 +452,12 @@ def frequency_impulse_response(magnitudes, window_size=0):
     """ddsp.core.frequency_impulse_response: [..., K] magnitudes -> [..., Lw] causal linear-phase FIRs."""
     mags = tf_float32(magnitudes)
     k = int(mags.shape[-1])
-    m = fir_matrix(k, int(window_size), mags.device)
+    m, uniq, mirror = fir_matrix(k, int(window_size), mags.device)
     lw = int(m.shape[1])
     frames = mags.numel() // k
     ir = torch.empty(tuple(mags.shape[:-1]) + (lw,), dtype=torch.float32, device=mags.device)
-    _lib.check(_lib_().ddspp_fir_from_magnitudes(_ptr(mags), _ptr(m), _ptr(ir), frames, k, lw, _stream()))
+    _lib.check(_lib_().ddspp_fir_from_magnitudes(_ptr(mags), _ptr(m), _ptr(uniq), _ptr(mirror),
+                                                 int(uniq.numel()), _ptr(ir), frames, k, lw, _stream()))
     return ir
 
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ float div_const(float x, float d, float rd) {
 // floor(x / P) or one more, never less; r = x - q * P is then exact in one FMA because both x
 // and q * P are multiples of ulp(P) = 2^-21 and |r| < 8; a negative r gets + P (exact).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mod_2pi_slow(float x) {
+__device__ __attribute__((noinline)) float mod_2pi_slow(float x) {
     const float P = DDSPP_TWO_PI_F32;
     float t = fmodf(x, P);
     if (t != 0.0f && t < 0.0f) t = t + P;

@@ -28,26 +28,40 @@ namespace ddspp {
 // ------------------------------------------------------------------------------------------------
 // impulse responses from magnitudes
 // ------------------------------------------------------------------------------------------------
-template <int KP>
-__global__ void __launch_bounds__(256) fir_from_magnitudes_kernel(const float* __restrict__ mags,
-                                                                const float* __restrict__ M,
-                                                                float* __restrict__ ir, size_t frames,
-                                                                int K, int Lw, int frames_per_block) {
-    const int tap = threadIdx.x;
-    float col[KP];
+// Lane j computes the unique tap uniq[j] (and writes its mirror image when the FIR is symmetric:
+// the zero-phase -> linear-phase construction makes ir[c + m] == ir[c - m]).  The K magnitudes of a
+// frame are wave-uniform: they arrive through scalar loads, 16 at a time, and feed the FMAs as SGPR
+// operands; the tap's column of M stays in K VGPRs for the whole run of frames.
+template <int K, int THREADS>
+__global__ void __launch_bounds__(THREADS) fir_from_magnitudes_kernel(const float* __restrict__ mags,
+                                                                    const float* __restrict__ M,
+                                                                    const int* __restrict__ uniq,
+                                                                    const int* __restrict__ mirror,
+                                                                    float* __restrict__ ir, int frames,
+                                                                    int Lw, int n_uniq,
+                                                                    int frames_per_block) {
+    const int j = threadIdx.x;
+    const bool active = j < n_uniq;
+    const int tap = active ? uniq[j] : 0;
+    const int mir = active ? mirror[j] : -1;
+    float col[K];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) col[k] = (k < K && tap < Lw) ? M[(size_t)k * Lw + tap] : 0.0f;
-    const size_t f0 = (size_t)blockIdx.x * frames_per_block;
-    const size_t f1 = min(f0 + (size_t)frames_per_block, frames);
-    for (size_t f = f0; f < f1; ++f) {
-        const float* mg = mags + f * K;       // wave-uniform address -> scalar loads
-        float acc = 0.0f;
+    for (int k = 0; k < K; ++k) col[k] = active ? M[(size_t)k * Lw + tap] : 0.0f;
+    const int f0 = blockIdx.x * frames_per_block;
+    const int f1 = min(f0 + frames_per_block, frames);
+    for (int f = f0; f < f1; ++f) {
+        const float* __restrict__ mg = mags + (size_t)f * K;       // wave-uniform address
+        float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const float m = (k < K) ? mg[k] : 0.0f;
-            acc = __builtin_fmaf(m, col[k], acc);
+        for (int k = 0; k < K; k += 2) {
+            acc0 = __builtin_fmaf(mg[k], col[k], acc0);
+            acc1 = __builtin_fmaf(mg[k + 1], col[k + 1], acc1);
         }
-        if (tap < Lw) ir[f * Lw + tap] = acc;
+        const float acc = acc0 + acc1;
+        if (active) {
+            ir[(size_t)f * Lw + tap] = acc;
+            if (mir >= 0) ir[(size_t)f * Lw + mir] = acc;
+        }
     }
 }
 
@@ -112,32 +126,47 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
         if (np0 >= N) break;
         const int m0 = np0 + delay;               // z index of lane 0, e = 0
         int jb = max(m0 - (Lw - 1), 0) / 4;
-        const int jb_end = min(m0 + FIR_PASS - 1, N - 1) / 4;   // inclusive
+        const int jb_end = min(m0 + FIR_PASS - 1, N - 1) / 4 + 1;   // exclusive
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int f = (4 * jb) / U;
-        int jr = jb - f * bpf;                    // block position inside the frame
-        // block index (before clamping) of the lower 16-byte block this lane reads for `jb`
-        // positions: pos = tap + padl, tap = (m0 - 4 jb) + 4 a + d, d in [-3, 4]
-        int b0 = (m0 - 4 * jb - 3 + padl) / 4 + lane;      // (.. ) is a multiple of 4 by choice of padl
-        const float* Gf = G + (f - f_lo) * gstride;
-        float4 hi = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 + 1, 0), nb - 1));
-        for (; jb <= jb_end; ++jb) {
-            const float4 lo = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0, 0), nb - 1));
-            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * jb);   // wave-uniform
-            const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        // block index (before clamping) of the lower 16-byte block this lane reads for `jb`:
+        // positions pos = tap + padl, tap = (m0 - 4 jb) + 4 a + d, d in [-3, 4]
+        int b0 = (m0 - 4 * jb - 3 + padl) / 4 + lane;      // (..) is a multiple of 4 by choice of padl
+        while (jb < jb_end) {
+            const int f = (4 * jb) / U;                     // all blocks up to jb_stop share this FIR
+            const int jb_stop = min((f + 1) * bpf, jb_end);
+            const float* Gf = G + (f - f_lo) * gstride;
+            float4 hi = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 + 1, 0), nb - 1));
+            // four input blocks per trip: their noise samples (wave-uniform scalar loads) and their
+            // tap blocks are all requested before the first FMA needs them
+            for (; jb + 4 <= jb_stop; jb += 4, b0 -= 4) {
+                float4 xv[4], tb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const float4*>(xr + 4 * (jb + u));
+                    tb[u] = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 - u, 0), nb - 1));
+                }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
-            hi = lo;
-            --b0;
-            if (++jr == bpf) {                     // next input block belongs to the next frame
-                jr = 0;
-                ++f;
-                if (f > f_hi) break;
-                Gf = G + (f - f_lo) * gstride;
-                hi = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 + 1, 0), nb - 1));
+                for (int u = 0; u < 4; ++u) {
+                    const float4 lo = tb[u];
+                    const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+                    hi = lo;
+                }
+            }
+            for (; jb < jb_stop; ++jb, --b0) {
+                const float4 lo = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0, 0), nb - 1));
+                const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * jb);
+                const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+                hi = lo;
             }
         }
         const int n = np0 + 4 * lane;
@@ -215,19 +244,34 @@ extern "C" {
 
 // ddsp.core.frequency_impulse_response(magnitudes, window_size) as one product with the host-built
 // matrix M[K, Lw] (ddsp_piano_amd/core.py: irfft basis x window, shifted to causal form).
-int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, float* ir, size_t frames, int K,
-                              int Lw, hipStream_t stream) {
+// uniq[n_uniq] / mirror[n_uniq] (device int32, may be NULL): the taps to compute and where each
+// one is mirrored to (-1: nowhere); NULL means every tap is computed.
+int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, const int* uniq, const int* mirror,
+                              int n_uniq, float* ir, size_t frames, int K, int Lw, hipStream_t stream) {
     DDSPP_REQUIRE(magnitudes && M && ir, "fir_from_magnitudes: null buffer");
     DDSPP_REQUIRE(K > 0 && Lw > 0, "fir_from_magnitudes: bad dims");
+    DDSPP_REQUIRE(frames < (1ull << 31), "fir_from_magnitudes: too many frames");
     if (frames == 0) return DDSPP_OK;
-    const bool tiled = (Lw <= 256) && (K <= 128) && !env_int("DDSPP_FIR_GENERIC", 0);
+    const bool tiled = uniq && mirror && n_uniq > 0 && n_uniq <= 256 &&
+                       (K == 32 || K == 64 || K == 96 || K == 128) && !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
         const int fpb = 64;
-        const dim3 grid((unsigned)((frames + fpb - 1) / fpb)), block(256);
-        if (K <= 32) hipLaunchKernelGGL(fir_from_magnitudes_kernel<32>, grid, block, 0, stream, magnitudes, M, ir, frames, K, Lw, fpb);
-        else if (K <= 64) hipLaunchKernelGGL(fir_from_magnitudes_kernel<64>, grid, block, 0, stream, magnitudes, M, ir, frames, K, Lw, fpb);
-        else if (K <= 96) hipLaunchKernelGGL(fir_from_magnitudes_kernel<96>, grid, block, 0, stream, magnitudes, M, ir, frames, K, Lw, fpb);
-        else hipLaunchKernelGGL(fir_from_magnitudes_kernel<128>, grid, block, 0, stream, magnitudes, M, ir, frames, K, Lw, fpb);
+        const dim3 grid((unsigned)((frames + fpb - 1) / fpb));
+        const int nf = (int)frames;
+#define DDSPP_FIR_LAUNCH(KK)                                                                              \
+        do {                                                                                              \
+            if (n_uniq <= 128)                                                                            \
+                hipLaunchKernelGGL((fir_from_magnitudes_kernel<KK, 128>), grid, dim3(128), 0, stream,     \
+                                   magnitudes, M, uniq, mirror, ir, nf, Lw, n_uniq, fpb);                 \
+            else                                                                                          \
+                hipLaunchKernelGGL((fir_from_magnitudes_kernel<KK, 256>), grid, dim3(256), 0, stream,     \
+                                   magnitudes, M, uniq, mirror, ir, nf, Lw, n_uniq, fpb);                 \
+        } while (0)
+        if (K == 32) DDSPP_FIR_LAUNCH(32);
+        else if (K == 64) DDSPP_FIR_LAUNCH(64);
+        else if (K == 96) DDSPP_FIR_LAUNCH(96);
+        else DDSPP_FIR_LAUNCH(128);
+#undef DDSPP_FIR_LAUNCH
     } else {
         hipLaunchKernelGGL(fir_from_magnitudes_generic_kernel, dim3(stream_grid(frames * Lw)), dim3(256), 0,
                            stream, magnitudes, M, ir, frames, K, Lw);

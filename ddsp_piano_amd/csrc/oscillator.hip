@@ -85,17 +85,28 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
     const int n_begin = c0 * DDSPP_CHUNK;
     const int n_end = min(c1 * DDSPP_CHUNK, N);
+    const float nyq = p.nyq;
 
-    // ---- per-lane oscillator identity ---------------------------------------------------------
-    int vk[VPL], vs[VPL];
+    // ---- per-lane oscillator identity.  Lanes past the last oscillator load a clamped (valid)
+    // address and are silenced arithmetically: no load ever sits behind a branch, so the compiler
+    // keeps counted vmcnt waits and the prefetched blocks really stay in flight.
+    // Oscillator index of (lane, j): the fused source keeps harmonics 64 j .. 64 j + 63 together in group
+    // j (the upper groups go silent first, see act[]); the materialised source gives each lane VPL
+    // adjacent sinusoids so that one 4/8/16-byte load per lane fetches them (the host picks such a
+    // VPL only when H % VPL == 0).
+    constexpr bool CONTIG = !FUSED && (VPL == 1 || VPL == 2 || VPL == 4);
+    int vk[VPL], vs[VPL], vcol[VPL], vidx[VPL];
     bool valid[VPL];
     float kmul[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        const int v = lane + 64 * j;
+        const int v = CONTIG ? lane * VPL + j : lane + 64 * j;
+        vidx[j] = v;
         valid[j] = v < V;
-        vs[j] = valid[j] ? v / H : 0;
-        vk[j] = valid[j] ? v - vs[j] * H : 0;
+        const int vc = (CONTIG && VPL > 1) ? min(lane * VPL, V - VPL) + j : min(v, V - 1);
+        vs[j] = vc / H;
+        vk[j] = vc - vs[j] * H;
+        vcol[j] = vc;
         kmul[j] = (float)(vk[j] + 1);              // linspace(1, H, H)
     }
 
@@ -111,7 +122,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         const int span = c0 / p.cps;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            asum[j] = p.astart[((size_t)row * p.spans + span) * p.VP + lane + 64 * j];
+            asum[j] = p.astart[((size_t)row * p.spans + span) * p.VP + vidx[j]];
             off[j] = mod_2pi(asum[j]);
         }
     }
@@ -119,28 +130,73 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     // ---- fused source: frame controls ----------------------------------------------------------
     // hf(t, v) = (f0[t, s] * k) * (1 + shift[t, k])     inharm_synth.py:106-108
     // ha(t, v) = amp[t] * hd[t, k]                      inharm_synth.py:112
+    // x0/a0 = frame t, x1/a1 = frame min(t + 1, T - 1); the raw values of the frame after that are
+    // requested one whole frame early (q_*), so their HBM/L2 latency hides behind 96 samples of work.
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
+    float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp = 0.0f;
     int t = 0, r = 0;
-    auto frame_ctl = [&](int tt, float* xf, float* xa) {
-        const float amp_t = p.amp[(size_t)row * T + tt];
+    auto frame_request = [&](int tt) {
+        const size_t fr = (size_t)row * T + tt;
+        q_amp = p.amp[fr];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            float f = 0.0f, a = 0.0f;
-            if (valid[j]) {
-                const float f0t = p.f0[((size_t)row * T + tt) * S + vs[j]];
-                f = f0t * kmul[j];
-                if (p.shifts) f = f * (1.0f + p.shifts[((size_t)row * T + tt) * H + vk[j]]);
-                if (MODE != MODE_PREPASS) a = amp_t * p.hd[((size_t)row * T + tt) * H + vk[j]];
-            }
-            xf[j] = f;
-            xa[j] = a;
+            q_f0[j] = p.f0[fr * S + vs[j]];
+            q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : 0.0f;
+            q_hd[j] = (MODE != MODE_PREPASS) ? p.hd[fr * H + vk[j]] : 0.0f;
         }
     };
+    auto frame_finish = [&](float* xf, float* xa) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            float f = q_f0[j] * kmul[j];
+            if (p.shifts) f = f * (1.0f + q_sh[j]);
+            const float a = q_amp * q_hd[j];
+            xf[j] = valid[j] ? f : 0.0f;
+            xa[j] = (valid[j] && MODE != MODE_PREPASS) ? a : 0.0f;
+        }
+    };
+
+    // ---- per-frame / per-block classification (wave-uniform) -----------------------------------
+    //   vals_ok   every frequency is >= 0 and either 0 or comfortably normal  -> exact fast forms of
+    //             the constant division and of the 2*pi reduction are valid (ddspp_common.h)
+    //   need_mask some oscillator crosses Nyquist inside the frame pair        -> per-sample mask
+    //   act[j]    some lane of group j has a non-zero amplitude                -> otherwise the group
+    //             contributes exactly 0 and only its phase is advanced
+    bool vals_ok = false, need_mask = true;
+    bool act[VPL];
+    float phlim[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        act[j] = true;
+        phlim[j] = 0.0f;
+    }
+    auto classify_frame = [&]() {
+        bool ok = true, msk = false;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
+            ok = ok && (lo > 1e-28f || (lo == 0.0f && (hi == 0.0f || hi > 1e-24f))) && (hi < 3.0e38f);
+            if (lo >= nyq) {            // above Nyquist for the whole frame pair: mask once, here
+                a0[j] = 0.0f;
+                a1[j] = 0.0f;
+            }
+            msk = msk || (lo < nyq && hi >= nyq);
+            phlim[j] = 2.5e7f - hi * (8.1f * DDSPP_TWO_PI_F32) * p.rsr;
+            act[j] = __any(a0[j] != 0.0f || a1[j] != 0.0f);
+        }
+        vals_ok = __all(ok);
+        need_mask = __any(msk);
+    };
+
     if (FUSED) {
         t = n_begin / U;
         r = n_begin - t * U;
-        frame_ctl(t, x0, a0);
-        frame_ctl(min(t + 1, T - 1), x1, a1);
+        frame_request(t);
+        frame_finish(x0, a0);
+        frame_request(min(t + 1, T - 1));
+        frame_finish(x1, a1);
+        frame_request(min(t + 2, T - 1));
+        classify_frame();
     }
 
     int cpos = 0;                      // position inside the current 1000-sample chunk
@@ -148,32 +204,41 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     const float* fe_row = FUSED ? nullptr : p.fe + (size_t)row * N * H;
     const float* ae_row = FUSED ? nullptr : p.ae + (size_t)row * N * H;
 
-    // materialised source: register double buffer, next block prefetched while this one computes
-    float fbuf[2][BLK][VPL], abuf[2][BLK][VPL];
+    // materialised source: ring of register buffers, NBUF - 1 blocks (8 KB each at H = 128) are in
+    // flight per wavefront while one is being consumed.
+    constexpr int NBUF = FUSED ? 1 : (VPL <= 2 ? 4 : (VPL <= 4 ? 2 : 1));
+    float fbuf[NBUF][BLK][VPL], abuf[NBUF][BLK][VPL];
     auto load_block = [&](int n0, float (*fb)[VPL], float (*ab)[VPL]) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) {
+            const size_t base = (size_t)min(n0 + i, n_end - 1) * H;       // clamped: never out of the span
+            if (CONTIG && VPL > 1) {
+                typedef float vecf __attribute__((ext_vector_type(VPL)));
+                const size_t o = base + vcol[0];
+                const vecf f = *reinterpret_cast<const vecf*>(fe_row + o);
+                vecf a = {};
+                if (MODE != MODE_PREPASS) a = *reinterpret_cast<const vecf*>(ae_row + o);
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                float f = 0.0f, a = 0.0f;
-                if (valid[j] && n0 + i < n_end) {
-                    const size_t idx = (size_t)(n0 + i) * H + lane + 64 * j;
-                    f = fe_row[idx];
-                    if (MODE != MODE_PREPASS) a = ae_row[idx];
+                for (int j = 0; j < VPL; ++j) {
+                    fb[i][j] = f[j];
+                    ab[i][j] = a[j];
                 }
-                fb[i][j] = f;
-                ab[i][j] = a;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    fb[i][j] = fe_row[base + vcol[j]];
+                    ab[i][j] = (MODE != MODE_PREPASS) ? ae_row[base + vcol[j]] : 0.0f;
+                }
             }
         }
     };
 
-    // One block of BLK samples.  FDIV / FMOD select the exact fast forms of the constant division
-    // and of the 2*pi reduction (ddspp_common.h); they are chosen per block, wave-uniformly, from
-    // conservative bounds on the block's frequencies and phases (block_class below).
+    // One block of BLK samples.
     auto process_block = [&](int n0, int tpos, const float (*fb)[VPL], const float (*ab)[VPL],
-                             auto fdiv_tag, auto fmod_tag) {
+                             auto fdiv_tag, auto fmod_tag, auto mask_tag) {
         constexpr bool FDIV = decltype(fdiv_tag)::value;
         constexpr bool FMOD = decltype(fmod_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value;
         float fe[BLK][VPL], ae[BLK][VPL];
         if (FUSED) {
             // per-sample scalar weights (wave-uniform -> scalar loads)
@@ -200,8 +265,8 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             for (int i = 0; i < BLK; ++i)
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
-                    fe[i][j] = fb[i][j];
-                    ae[i][j] = ab[i][j];
+                    fe[i][j] = valid[j] ? fb[i][j] : 0.0f;
+                    ae[i][j] = valid[j] ? ab[i][j] : 0.0f;
                 }
         }
         // sequential float32 phase scan
@@ -214,26 +279,34 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                 pv[i][j] = ph[j];
             }
         if (MODE == MODE_PREPASS) return;
+        float acc[BLK];
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) {
-            float acc = 0.0f;
+        for (int i = 0; i < BLK; ++i) acc[i] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const float a = (fe[i][j] >= p.nyq) ? 0.0f : ae[i][j];   // remove_above_nyquist
-                float c;
-                if (MODE == MODE_MAIN) {
-                    const float s = pv[i][j] + off[j];                    // phase + offsets
-                    c = FMOD ? cos_of_phase_fast(s) : cos_reduced(mod_2pi(s));   // % 2pi ; cos
-                } else {
-                    c = cosf(pv[i][j]);                                   // plain tf.cumsum path
+        for (int j = 0; j < VPL; ++j) {
+            if (act[j]) {                  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    const float a = (MASK && fe[i][j] >= nyq) ? 0.0f : ae[i][j];   // remove_above_nyquist
+                    float c;
+                    if (MODE == MODE_MAIN) {
+                        const float s = pv[i][j] + off[j];                        // phase + offsets
+                        c = FMOD ? cos_of_phase_fast(s) : cos_reduced(mod_2pi(s));   // % 2pi ; cos
+                    } else {
+                        c = cosf(pv[i][j]);                                       // plain tf.cumsum path
+                    }
+                    if (SUM) acc[i] = __builtin_fmaf(a, c, acc[i]);
+                    else if (valid[j]) p.out[((size_t)row * N + n0 + i) * V + vidx[j]] = a * c;
                 }
-                if (SUM) {
-                    acc = __builtin_fmaf(a, c, acc);
-                } else if (valid[j]) {
-                    p.out[((size_t)row * N + n0 + i) * V + lane + 64 * j] = a * c;
-                }
+            } else if (!SUM) {
+#pragma unroll
+                for (int i = 0; i < BLK; ++i)
+                    if (valid[j]) p.out[((size_t)row * N + n0 + i) * V + vidx[j]] = 0.0f;
             }
-            if (SUM) tile[(tpos + i) * TSTRIDE + lane] = acc;
+        }
+        if (SUM) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) tile[(tpos + i) * TSTRIDE + lane] = acc[i];
         }
     };
 
@@ -254,68 +327,52 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    // 2 = frequencies are all >= 0 and either 0 or comfortably normal, and the phase stays below
-    //     2^22 * 2pi through the block: exact fast division (if the rate is whitelisted) + fast mod
-    // 0 = anything else (negative / denormal frequencies, huge phases): IEEE divide, generic floormod
-    auto block_class = [&](const float (*fb)[VPL]) -> int {
+    // materialised source: the same classification, from the block's own envelope samples
+    auto classify_block = [&](const float (*fb)[VPL], const float (*ab)[VPL]) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            float lo, hi;
-            if (FUSED) {
-                lo = fminf(x0[j], x1[j]);
-                hi = fmaxf(x0[j], x1[j]);
-            } else {
-                lo = hi = fb[0][j];
+            float lo = fb[0][j], hi = fb[0][j], amax = fabsf(ab[0][j]);
+            bool tiny = false;
 #pragma unroll
-                for (int i = 1; i < BLK; ++i) {
-                    lo = fminf(lo, fb[i][j]);
-                    hi = fmaxf(hi, fb[i][j]);
-                }
+            for (int i = 0; i < BLK; ++i) {
+                lo = fminf(lo, fb[i][j]);
+                hi = fmaxf(hi, fb[i][j]);
+                amax = fmaxf(amax, fabsf(ab[i][j]));
+                tiny = tiny || (fb[i][j] != 0.0f && fb[i][j] < 1e-28f);
             }
-            ok = ok && (lo == 0.0f || lo > 1e-28f) && (hi == hi) &&
-                 (ph[j] + hi * (8.1f * DDSPP_TWO_PI_F32) * p.rsr < 2.5e7f);
-            // a block whose lowest frequency is 0 may still hold tiny positive ones: only the fused
-            // source can guarantee monotone interpolation between x0 and x1
-            if (!FUSED && lo == 0.0f) {
-#pragma unroll
-                for (int i = 0; i < BLK; ++i) ok = ok && (fb[i][j] == 0.0f || fb[i][j] > 1e-28f);
-            }
-            if (FUSED && lo == 0.0f) ok = ok && (hi == 0.0f || hi > 1e-24f);
+            ok = ok && (lo >= 0.0f) && !tiny && (hi < 3.0e38f);
+            phlim[j] = 2.5e7f - hi * (8.1f * DDSPP_TWO_PI_F32) * p.rsr;
+            act[j] = __any(valid[j] && !(amax == 0.0f));
         }
-        return __all(ok) ? 2 : 0;
+        vals_ok = __all(ok || !valid[0]) && __all(ok);
+        need_mask = true;
     };
 
     int tpos = 0;                      // position inside the LDS tile
     int tile_n0 = n_begin;
-    if (!FUSED) load_block(n_begin, fbuf[0], abuf[0]);
-    int cur = 0;
 
-    for (int n0 = n_begin; n0 < n_end; n0 += BLK) {
-        if (!FUSED) {
-            // prefetch the next block into the other register buffer
-            if (cur == 0) load_block(n0 + BLK, fbuf[1], abuf[1]);
-            else load_block(n0 + BLK, fbuf[0], abuf[0]);
+    // everything that happens for one block of BLK samples starting at n0, whose envelopes (for the
+    // materialised source) sit in fb / ab
+    auto do_block = [&](int n0, const float (*fb)[VPL], const float (*ab)[VPL]) {
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (!FUSED) classify_block(fb, ab);
+        bool fast = vals_ok;
+        if (MODE != MODE_PLAIN) {
+            bool ph_ok = true;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) ph_ok = ph_ok && (ph[j] < phlim[j]);
+            fast = fast && __all(ph_ok);
         }
-        {
-            const float (*fbc)[VPL] = cur == 0 ? fbuf[0] : fbuf[1];
-            const float (*abc)[VPL] = cur == 0 ? abuf[0] : abuf[1];
-            using T_ = std::true_type;
-            using F_ = std::false_type;
-            const int cls = block_class(fbc);
-            if (cur == 0) {
-                if (cls == 2 && p.fastdiv) process_block(n0, tpos, fbuf[0], abuf[0], T_{}, T_{});
-                else if (cls == 2) process_block(n0, tpos, fbuf[0], abuf[0], F_{}, T_{});
-                else process_block(n0, tpos, fbuf[0], abuf[0], F_{}, F_{});
-            } else {
-                if (cls == 2 && p.fastdiv) process_block(n0, tpos, fbuf[1], abuf[1], T_{}, T_{});
-                else if (cls == 2) process_block(n0, tpos, fbuf[1], abuf[1], F_{}, T_{});
-                else process_block(n0, tpos, fbuf[1], abuf[1], F_{}, F_{});
-            }
-            (void)fbc; (void)abc;
+        if (fast && p.fastdiv) {
+            if (FUSED && !need_mask) process_block(n0, tpos, fb, ab, T_{}, T_{}, F_{});
+            else process_block(n0, tpos, fb, ab, T_{}, T_{}, T_{});
+        } else if (fast) {
+            process_block(n0, tpos, fb, ab, F_{}, T_{}, T_{});
+        } else {
+            process_block(n0, tpos, fb, ab, F_{}, F_{}, T_{});
         }
-        if (!FUSED) cur ^= 1;
-
         // ---- tile bookkeeping -----------------------------------------------------------------
         if (SUM && MODE != MODE_PREPASS) {
             tpos += BLK;
@@ -333,7 +390,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                 if (MODE == MODE_PREPASS) {
 #pragma unroll
                     for (int j = 0; j < VPL; ++j)
-                        p.ework[((size_t)row * p.npre + chunk) * p.VP + lane + 64 * j] = mod_2pi(ph[j]);
+                        p.ework[((size_t)row * p.npre + chunk) * p.VP + vidx[j]] = mod_2pi(ph[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) {
@@ -357,7 +414,26 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                     x0[j] = x1[j];
                     a0[j] = a1[j];
                 }
-                frame_ctl(min(t + 1, T - 1), x1, a1);
+                frame_finish(x1, a1);                       // raw values requested one frame ago
+                frame_request(min(t + 2, T - 1));
+                classify_frame();
+            }
+        }
+    };
+
+    if (FUSED) {
+        for (int n0 = n_begin; n0 < n_end; n0 += BLK) do_block(n0, fbuf[0], abuf[0]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) load_block(n_begin + b * BLK, fbuf[b], abuf[b]);
+        for (int n0 = n_begin; n0 < n_end; n0 += NBUF * BLK) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                const int nb0 = n0 + b * BLK;
+                if (nb0 < n_end) {
+                    load_block(nb0 + (NBUF - 1) * BLK, fbuf[(b + NBUF - 1) % NBUF], abuf[(b + NBUF - 1) % NBUF]);
+                    do_block(nb0, fbuf[b], abuf[b]);
+                }
             }
         }
     }
@@ -405,6 +481,18 @@ static int pick_vpl(int V) {
     return 0;
 }
 
+// materialised source: prefer a VPL that divides H (vector loads, lane owns VPL adjacent sinusoids)
+static int pick_vpl_materialised(int H) {
+    const int need = (H + 63) / 64;
+    const int contig[] = {1, 2, 4};
+    for (int a : contig)
+        if (a >= need && H % a == 0) return a;
+    const int strided[] = {3, 6, 8};
+    for (int a : strided)
+        if (a >= need) return a;
+    return 0;
+}
+
 struct Plan {
     int vpl, VP, nchunks, spans, cps, npre;
     size_t ework_floats, astart_floats;
@@ -412,7 +500,7 @@ struct Plan {
 
 static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_req) {
     Plan pl{};
-    pl.vpl = pick_vpl(V);
+    pl.vpl = fused ? pick_vpl(V) : pick_vpl_materialised(V);
     pl.VP = pl.vpl * 64;
     pl.nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     int spans = 1;
@@ -491,7 +579,7 @@ extern "C" {
 // oscillators per row (V = n_substrings * n_harmonics for the fused entry point).
 size_t ddspp_osc_workspace_bytes(int R, int N, int V) {
     if (R <= 0 || N <= 0 || V <= 0) return 0;
-    const int vpl = pick_vpl(V);
+    const int vpl = pick_vpl(V) > pick_vpl_materialised(V) ? pick_vpl(V) : pick_vpl_materialised(V);
     if (!vpl) return 0;
     const size_t nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     return 2 * (size_t)R * nchunks * vpl * 64 * sizeof(float) + 256;
@@ -505,7 +593,7 @@ int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amp
                               size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(frequency_envelopes && amplitude_envelopes && audio, "cos_oscillator_bank: null buffer");
     DDSPP_REQUIRE(R > 0 && N > 0 && H > 0, "cos_oscillator_bank: bad dims R=%d N=%d H=%d", R, N, H);
-    DDSPP_REQUIRE(pick_vpl(H) != 0, "cos_oscillator_bank: n_sinusoids=%d exceeds 512", H);
+    DDSPP_REQUIRE(pick_vpl_materialised(H) != 0, "cos_oscillator_bank: n_sinusoids=%d exceeds 512", H);
     DDSPP_REQUIRE(N % BLK == 0, "cos_oscillator_bank: n_samples=%d must be a multiple of %d", N, BLK);
     DDSPP_REQUIRE(sample_rate > 0.f, "cos_oscillator_bank: bad sample_rate");
     Plan pl = make_plan(R, N, H, use_angular_cumsum != 0, false,

@@ -111,9 +111,10 @@ int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, 
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
 /* ddsp.core.frequency_impulse_response(magnitudes[frames,K], window_size) as magnitudes @ M with the
- * host-built float32 matrix M[K,Lw] -> ir[frames,Lw]. */
-int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, float* ir, size_t frames, int K,
-                              int Lw, hipStream_t stream);
+ * host-built float32 matrix M[K,Lw] -> ir[frames,Lw].  uniq/mirror (device int32[n_uniq], or NULL):
+ * the taps to evaluate and the tap each result is mirrored to (-1: none) -- the FIRs are symmetric. */
+int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, const int* uniq, const int* mirror,
+                              int n_uniq, float* ir, size_t frames, int K, int Lw, hipStream_t stream);
 
 /* ddsp.core.fft_convolve(audio[R,N], impulse_response[R,T,Lw], padding='same', delay_compensation)
  * in the framed case (frame = hop = N / T); reached from filtered_noise_synth.py:41-42 through
