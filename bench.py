@@ -170,7 +170,8 @@ def measure_roofline(dp, base, args, T, U, device):
             traffic = None
     return {'bound': 'hbm', 'achieved': alg_bytes / t / 1e9, 'peak': HBM_PEAK_BYTES / 1e9, 'unit': 'GB/s',
             'frac': alg_bytes / t / HBM_PEAK_BYTES, 'traffic': traffic,
-            'kernel': 'osc_kernel<VPL=%d,materialised,angular,sum> (ddspp_cos_oscillator_bank, spans=1)' % ((H + 63) // 64),
+            'kernel': 'ddspp::osc_kernel<VPL, materialised, MODE_MAIN, sum> (ddspp_cos_oscillator_bank, spans=1: '
+                      'every envelope byte read once)',
             'rows': rows, 'n_samples': N, 'n_harmonics': H, 'algorithmic_bytes_per_launch': alg_bytes,
             'ms_per_launch': t * 1e3, 'ms_min': float(np.min(times)) * 1e3}
 

@@ -41,7 +41,9 @@ struct OscParams {
     float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
     float* __restrict__ ework;         // [R, npre, VP]  chunk end phase mod 2pi
     const float* __restrict__ astart;  // [R, spans, VP] running offset sum at span start
+    float* __restrict__ partial;       // [R, groups, N] per-group audio when groups > 1
     int R, N, T, U, H, S, V, VP;
+    int groups, vgrp;                  // oscillators of a row are split over `groups` wavefronts
     int spans, cps, nchunks, npre;
     float sr, rsr, nyq;
     int fastdiv;                       // sample rate is in the exhaustively checked list
@@ -62,25 +64,29 @@ __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
 
 template <int VPL, bool FUSED, int MODE, bool SUM>
 __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
-    __shared__ float lds_tile[4][TILE * TSTRIDE];
+    // one workgroup = the `groups` wavefronts of one (row, span): they walk the same samples, so
+    // their per-tile partial sums can be combined through LDS behind a single barrier per tile
+    extern __shared__ float lds_dyn[];
 
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int task = wave_uniform(blockIdx.x * 4 + wib);
+    const int grp = wave_uniform(threadIdx.x >> 6);
+    const int task = blockIdx.x;
     int row, c0, c1;
     if (MODE == MODE_PREPASS) {
-        if (task >= p.R * p.npre) return;
         row = task / p.npre;
         c0 = task - row * p.npre;
         c1 = c0 + 1;
     } else {
-        if (task >= p.R * p.spans) return;
         row = task / p.spans;
         const int span = task - row * p.spans;
         c0 = span * p.cps;
         c1 = min(c0 + p.cps, p.nchunks);
     }
-    float* tile = lds_tile[wib];
+    const int vbase = grp * p.vgrp;                       // first oscillator of this wavefront
+    const int vlast = min(vbase + p.vgrp, p.V) - 1;       // last one (inclusive)
+    float* tile = lds_dyn + grp * (TILE * TSTRIDE);
+    float* comb = lds_dyn + p.groups * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
+    int comb_buf = 0;
 
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
     const int n_begin = c0 * DDSPP_CHUNK;
@@ -100,10 +106,10 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     float kmul[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        const int v = CONTIG ? lane * VPL + j : lane + 64 * j;
+        const int v = vbase + (CONTIG ? lane * VPL + j : lane + 64 * j);
         vidx[j] = v;
-        valid[j] = v < V;
-        const int vc = (CONTIG && VPL > 1) ? min(lane * VPL, V - VPL) + j : min(v, V - 1);
+        valid[j] = v <= vlast;
+        const int vc = (CONTIG && VPL > 1) ? min(vbase + lane * VPL, vlast + 1 - VPL) + j : min(v, vlast);
         vs[j] = vc / H;
         vk[j] = vc - vs[j] * H;
         vcol[j] = vc;
@@ -199,6 +205,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         classify_frame();
     }
 
+    float* out_row = p.out + (size_t)row * N;
     int cpos = 0;                      // position inside the current 1000-sample chunk
     int chunk = c0;
     const float* fe_row = FUSED ? nullptr : p.fe + (size_t)row * N * H;
@@ -321,7 +328,19 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) s += src[i];
         s += __shfl_xor(s, 32);
-        if (lane < count) p.out[(size_t)row * N + nt0 + lane] = s;
+        if (p.groups == 1) {
+            if (lane < count) out_row[nt0 + lane] = s;
+        } else {
+            float* cb = comb + comb_buf * (p.groups * 32);
+            if (lane < 32) cb[grp * 32 + lane] = s;
+            __syncthreads();
+            if (grp == 0 && lane < count) {
+                float tot = cb[lane];
+                for (int g = 1; g < p.groups; ++g) tot += cb[g * 32 + lane];
+                out_row[nt0 + lane] = tot;
+            }
+            comb_buf ^= 1;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -494,14 +513,36 @@ static int pick_vpl_materialised(int H) {
 }
 
 struct Plan {
-    int vpl, VP, nchunks, spans, cps, npre;
-    size_t ework_floats, astart_floats;
+    int vpl, VP, nchunks, spans, cps, npre, groups, vgrp;
+    size_t ework_floats, astart_floats, partial_floats;
 };
 
-static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_req) {
+static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_req, int groups_req,
+                      bool sum) {
     Plan pl{};
-    pl.vpl = fused ? pick_vpl(V) : pick_vpl_materialised(V);
-    pl.VP = pl.vpl * 64;
+    // Split a row's oscillators over several wavefronts when the rows alone leave SIMDs with a
+    // single wavefront (nothing to overlap its memory waits with).  Groups are multiples of 64.
+    int groups = 1;
+    const int max_groups = min((V + 63) / 64, 4);          // one workgroup (<= 256 threads) per row
+    if (groups_req > 0) groups = groups_req;
+    else if (sum && !fused) {
+        // HBM-bound source: two wavefronts per SIMD overlap one's vmcnt waits with the other's ALU work
+        const int want = env_int("DDSPP_OSC_GROUP_WAVES", 2048);
+        groups = (want + R - 1) / R;
+    } else if (sum) {
+        // ALU-bound source: spans give finer, better balanced tasks; split rows only for tiny batches
+        const long long tasks = (long long)R * ((N + DDSPP_CHUNK - 1) / DDSPP_CHUNK);
+        const int want = env_int("DDSPP_OSC_GROUP_WAVES_FUSED", 4096);
+        groups = tasks >= want ? 1 : (int)((want + tasks - 1) / tasks);
+    }
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1 || !sum) groups = 1;
+    pl.vgrp = ((V + groups - 1) / groups + 63) / 64 * 64;
+    if (groups == 1) pl.vgrp = V;
+    pl.groups = (V + pl.vgrp - 1) / pl.vgrp;
+    pl.vpl = fused ? pick_vpl(pl.vgrp) : pick_vpl_materialised(pl.vgrp);
+    pl.VP = pl.groups * pl.vgrp > pl.vpl * 64 ? (pl.groups * pl.vgrp + 63) / 64 * 64 : pl.vpl * 64;
+    R = R * pl.groups;
     pl.nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     int spans = 1;
     if (angular) {
@@ -511,7 +552,7 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
             // enough wavefronts to occupy 256 CUs; the fused source is ALU bound and likes more
             // waves, the materialised source pays one extra read of `fe` per pre-passed chunk and
             // is kept at one span whenever the rows alone give >= 4 waves per CU.
-            const int target = fused ? env_int("DDSPP_OSC_TARGET_WAVES_FUSED", 4096)
+            const int target = fused ? env_int("DDSPP_OSC_TARGET_WAVES_FUSED", 8192)
                                      : env_int("DDSPP_OSC_TARGET_WAVES", 1024);
             spans = (target + R - 1) / R;
         }
@@ -521,38 +562,49 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
     pl.cps = (pl.nchunks + spans - 1) / spans;
     pl.spans = (pl.nchunks + pl.cps - 1) / pl.cps;
     pl.npre = pl.spans > 1 ? (pl.spans - 1) * pl.cps : 0;
-    pl.ework_floats = (size_t)R * pl.npre * pl.VP;
-    pl.astart_floats = (size_t)R * pl.spans * pl.VP;
+    const int rows = R / pl.groups;
+    pl.ework_floats = (size_t)rows * pl.npre * pl.VP;
+    pl.astart_floats = (size_t)rows * pl.spans * pl.VP;
+    pl.partial_floats = 0;
     return pl;
 }
 
 template <int VPL, bool FUSED>
 static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t stream) {
-    const int nblk_main = (p.R * p.spans + 3) / 4;
+    const int nblk_main = p.R * p.spans;
+    const dim3 blk(64 * p.groups);
+    const size_t lds = ((size_t)p.groups * (TILE * TSTRIDE) + 2 * p.groups * 32) * sizeof(float);
     if (angular) {
         if (p.spans > 1) {
-            const int nblk_pre = (p.R * p.npre + 3) / 4;
-            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), dim3(256),
-                               0, stream, p);
+            const int nblk_pre = p.R * p.npre;
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), blk, lds,
+                               stream, p);
             const size_t nthr = (size_t)p.R * p.VP;
             hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256),
                                0, stream, p.ework, const_cast<float*>(p.astart), p.R, p.npre, p.VP,
                                p.spans, p.cps);
         }
         if (sum)
-            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true>), dim3(nblk_main), dim3(256), 0,
-                               stream, p);
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true>), dim3(nblk_main), blk, lds, stream, p);
         else
-            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, false>), dim3(nblk_main), dim3(256),
-                               0, stream, p);
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, false>), dim3(nblk_main), blk, lds, stream,
+                               p);
     } else {
         if (sum)
-            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, true>), dim3(nblk_main), dim3(256),
-                               0, stream, p);
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, true>), dim3(nblk_main), blk, lds, stream,
+                               p);
         else
-            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, false>), dim3(nblk_main), dim3(256),
-                               0, stream, p);
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, false>), dim3(nblk_main), blk, lds, stream,
+                               p);
     }
+}
+
+static unsigned stream_grid(size_t total) {
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = 256 * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
 }
 
 template <bool FUSED>
@@ -582,7 +634,8 @@ size_t ddspp_osc_workspace_bytes(int R, int N, int V) {
     const int vpl = pick_vpl(V) > pick_vpl_materialised(V) ? pick_vpl(V) : pick_vpl_materialised(V);
     if (!vpl) return 0;
     const size_t nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
-    return 2 * (size_t)R * nchunks * vpl * 64 * sizeof(float) + 256;
+    const size_t vp = ((size_t)V + 127) / 64 * 64 + (size_t)vpl * 64;
+    return 2 * (size_t)R * nchunks * vp * sizeof(float) + 1024;
 }
 
 // cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate, sum_sinusoids,
@@ -597,8 +650,9 @@ int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amp
     DDSPP_REQUIRE(N % BLK == 0, "cos_oscillator_bank: n_samples=%d must be a multiple of %d", N, BLK);
     DDSPP_REQUIRE(sample_rate > 0.f, "cos_oscillator_bank: bad sample_rate");
     Plan pl = make_plan(R, N, H, use_angular_cumsum != 0, false,
-                        spans > 0 ? spans : env_int("DDSPP_OSC_SPANS", 0));
-    const size_t need = (pl.ework_floats + pl.astart_floats) * sizeof(float);
+                        spans > 0 ? spans : env_int("DDSPP_OSC_SPANS", 0), env_int("DDSPP_OSC_GROUPS", 0),
+                        sum_sinusoids != 0);
+    const size_t need = (pl.ework_floats + pl.astart_floats + pl.partial_floats) * sizeof(float);
     DDSPP_REQUIRE(pl.spans == 1 || (workspace && workspace_bytes >= need),
                   "cos_oscillator_bank: workspace too small (%zu < %zu)", workspace_bytes, need);
     OscParams p{};
@@ -607,6 +661,8 @@ int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amp
     p.out = audio;
     p.ework = (float*)workspace;
     p.astart = p.ework ? p.ework + pl.ework_floats : nullptr;
+    p.partial = p.ework ? p.ework + pl.ework_floats + pl.astart_floats : nullptr;
+    p.groups = pl.groups; p.vgrp = pl.vgrp;
     p.R = R; p.N = N; p.T = 0; p.U = BLK; p.H = H; p.S = 1; p.V = H; p.VP = pl.VP;
     p.spans = pl.spans; p.cps = pl.cps; p.nchunks = pl.nchunks; p.npre = pl.npre;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
@@ -635,8 +691,9 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
     DDSPP_REQUIRE((long long)T * U < (1ll << 31), "harmonic_synthesis: too many samples");
     const int N = T * U;
     Plan pl = make_plan(R, N, V, use_angular_cumsum != 0, true,
-                        spans > 0 ? spans : env_int("DDSPP_OSC_SPANS_FUSED", 0));
-    const size_t need = (pl.ework_floats + pl.astart_floats) * sizeof(float);
+                        spans > 0 ? spans : env_int("DDSPP_OSC_SPANS_FUSED", 0),
+                        env_int("DDSPP_OSC_GROUPS_FUSED", 0), true);
+    const size_t need = (pl.ework_floats + pl.astart_floats + pl.partial_floats) * sizeof(float);
     DDSPP_REQUIRE(pl.spans == 1 || (workspace && workspace_bytes >= need),
                   "harmonic_synthesis: workspace too small (%zu < %zu)", workspace_bytes, need);
     OscParams p{};
@@ -645,6 +702,8 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
     p.out = audio;
     p.ework = (float*)workspace;
     p.astart = p.ework ? p.ework + pl.ework_floats : nullptr;
+    p.partial = p.ework ? p.ework + pl.ework_floats + pl.astart_floats : nullptr;
+    p.groups = pl.groups; p.vgrp = pl.vgrp;
     p.R = R; p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = pl.VP;
     p.spans = pl.spans; p.cps = pl.cps; p.nchunks = pl.nchunks; p.npre = pl.npre;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
