@@ -89,6 +89,11 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     int comb_buf = 0;
 
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
+    // wave-uniform read-only tables: the constant address space makes the compiler fetch them with
+    // scalar loads (s_load_dwordx8 -> SGPR operands) instead of per-lane vector loads
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
+    const cfloat_p whann_c = (cfloat_p)(uintptr_t)p.whann;
     const int n_begin = c0 * DDSPP_CHUNK;
     const int n_end = min(c1 * DDSPP_CHUNK, N);
     const float nyq = p.nyq;
@@ -168,16 +173,17 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     //   need_mask some oscillator crosses Nyquist inside the frame pair        -> per-sample mask
     //   act[j]    some lane of group j has a non-zero amplitude                -> otherwise the group
     //             contributes exactly 0 and only its phase is advanced
-    bool vals_ok = false, need_mask = true;
+    bool vals_ok = false, need_mask = true, const_freq = false;
     bool act[VPL];
-    float phlim[VPL];
+    float phlim[VPL], om_c[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         act[j] = true;
         phlim[j] = 0.0f;
+        om_c[j] = 0.0f;
     }
     auto classify_frame = [&]() {
-        bool ok = true, msk = false;
+        bool ok = true, msk = false, cst = true;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
@@ -187,11 +193,14 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                 a1[j] = 0.0f;
             }
             msk = msk || (lo < nyq && hi >= nyq);
+            cst = cst && (x0[j] == x1[j]);
+            om_c[j] = omega_of<false>(x0[j], p.sr, p.rsr);   // == omega of every sample when x0 == x1
             phlim[j] = 2.5e7f - hi * (8.1f * DDSPP_TWO_PI_F32) * p.rsr;
             act[j] = __any(a0[j] != 0.0f || a1[j] != 0.0f);
         }
         vals_ok = __all(ok);
         need_mask = __any(msk);
+        const_freq = __all(cst);
     };
 
     if (FUSED) {
@@ -242,26 +251,29 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 
     // One block of BLK samples.
     auto process_block = [&](int n0, int tpos, const float (*fb)[VPL], const float (*ab)[VPL],
-                             auto fdiv_tag, auto fmod_tag, auto mask_tag) {
+                             auto fdiv_tag, auto fmod_tag, auto mask_tag, auto cfreq_tag) {
         constexpr bool FDIV = decltype(fdiv_tag)::value;
         constexpr bool FMOD = decltype(fmod_tag)::value;
         constexpr bool MASK = decltype(mask_tag)::value;
+        // CFREQ: every oscillator keeps its frequency through the frame pair (x0 == x1, the normal
+        // state of a held piano note): fe == x0 exactly, so omega is the per-frame constant om_c.
+        constexpr bool CFREQ = decltype(cfreq_tag)::value;
         float fe[BLK][VPL], ae[BLK][VPL];
         if (FUSED) {
             // per-sample scalar weights (wave-uniform -> scalar loads)
             float wl[BLK], w0[BLK], w1[BLK];
 #pragma unroll
             for (int i = 0; i < BLK; ++i) {
-                wl[i] = p.wlin[n0 + i];
-                w0[i] = p.whann[U + r + i];
-                w1[i] = p.whann[r + i];
+                if (!CFREQ) wl[i] = wlin_c[n0 + i];
+                w0[i] = whann_c[U + r + i];
+                w1[i] = whann_c[r + i];
             }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const float dx = x1[j] - x0[j];
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
-                    fe[i][j] = x0[j] + dx * wl[i];                    // legacy bilinear (core.resample)
+                    if (!CFREQ) fe[i][j] = x0[j] + dx * wl[i];        // legacy bilinear (core.resample)
                     // Hann overlap-add of frames t and t+1 (core.upsample_with_windows); the second
                     // product is fused: <= 1 ulp on an amplitude, never on a phase.
                     if (MODE != MODE_PREPASS) ae[i][j] = __builtin_fmaf(a1[j], w1[i], a0[j] * w0[i]);
@@ -282,7 +294,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         for (int i = 0; i < BLK; ++i)
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
-                ph[j] = ph[j] + omega_of<FDIV>(fe[i][j], p.sr, p.rsr);
+                ph[j] = ph[j] + (CFREQ ? om_c[j] : omega_of<FDIV>(fe[i][j], p.sr, p.rsr));
                 pv[i][j] = ph[j];
             }
         if (MODE == MODE_PREPASS) return;
@@ -294,7 +306,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             if (act[j]) {                  // wave-uniform
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
-                    const float a = (MASK && fe[i][j] >= nyq) ? 0.0f : ae[i][j];   // remove_above_nyquist
+                    const float a = (MASK && !CFREQ && fe[i][j] >= nyq) ? 0.0f : ae[i][j];   // remove_above_nyquist
                     float c;
                     if (MODE == MODE_MAIN) {
                         const float s = pv[i][j] + off[j];                        // phase + offsets
@@ -384,13 +396,15 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             for (int j = 0; j < VPL; ++j) ph_ok = ph_ok && (ph[j] < phlim[j]);
             fast = fast && __all(ph_ok);
         }
-        if (fast && p.fastdiv) {
-            if (FUSED && !need_mask) process_block(n0, tpos, fb, ab, T_{}, T_{}, F_{});
-            else process_block(n0, tpos, fb, ab, T_{}, T_{}, T_{});
+        if (FUSED && fast && const_freq) {
+            process_block(n0, tpos, fb, ab, F_{}, T_{}, F_{}, T_{});
+        } else if (fast && p.fastdiv) {
+            if (FUSED && !need_mask) process_block(n0, tpos, fb, ab, T_{}, T_{}, F_{}, F_{});
+            else process_block(n0, tpos, fb, ab, T_{}, T_{}, T_{}, F_{});
         } else if (fast) {
-            process_block(n0, tpos, fb, ab, F_{}, T_{}, T_{});
+            process_block(n0, tpos, fb, ab, F_{}, T_{}, T_{}, F_{});
         } else {
-            process_block(n0, tpos, fb, ab, F_{}, F_{}, T_{});
+            process_block(n0, tpos, fb, ab, F_{}, F_{}, T_{}, F_{});
         }
         // ---- tile bookkeeping -----------------------------------------------------------------
         if (SUM && MODE != MODE_PREPASS) {
