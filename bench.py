@@ -177,7 +177,9 @@ def measure_roofline(dp, base, args, T, U, device):
 
 
 def measure_cpu_baseline(args, T, U):
-    """The oracle (numpy restatement of the TF/ddsp reference) on one poly=`cpu_voices` segment."""
+    """The oracle (float32-faithful numpy restatement of the TF/ddsp reference -- TF itself cannot be
+    installed here) on a bounded sample of the same workload: whole 3 s, poly-16 segments, one
+    thread per voice task, sized for roughly 10-20 s of wall clock on this host."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ddsp_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -187,33 +189,43 @@ def measure_cpu_baseline(args, T, U):
     P = args.cpu_voices
     N = T * U
     L = int(args.ir_seconds * sr)
-    voices = [synth_controls(rng, 1, T, H, S=S, K=K) for _ in range(P)]
-    noises = [rng.uniform(-1, 1, [1, N]).astype(np.float32) for _ in range(P)]
-    ir = synth_ir(rng, 1, L)
     additive = O.MultiInharmonic(frame_rate=250, sample_rate=sr, inference=True)
     noise = O.FilteredNoise(frame_rate=250, sample_rate=sr)
     reverb = O.Reverb()
-    cores = os.cpu_count() or 1
+    threads = max(1, min(os.cpu_count() or 1, 32))
 
-    def voice(i):
-        c = voices[i]
+    def voice(task):
+        c, z = task
         a = additive(c['amplitudes'], c['harmonic_distribution'], c['inharm_coef'], c['f0_hz'])
-        z = noise.get_signal(**noise.get_controls(c['magnitudes']), noise=noises[i])
-        return a, z
+        n = noise.get_signal(**noise.get_controls(c['magnitudes']), noise=z)
+        return a, n
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        sigs = list(ex.map(voice, range(P)))
-    mix = None
-    for a, z in sigs:
-        mix = (z + a) if mix is None else ((mix + z) + a)
-    out = reverb.get_signal(mix, ir)
-    dt = time.perf_counter() - t0
-    assert out.shape == (1, N)
-    return {'value': N / dt, 'unit': 'audio samples/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 segment x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, {sr} Hz, full chain '
-                      f'(numpy oracle, {cores} threads over voices), {dt:.1f} s of CPU',
-            'rtf': N / dt / sr}
+    def make_segment():
+        return ([(synth_controls(rng, 1, T, H, S=S, K=K), rng.uniform(-1, 1, [1, N]).astype(np.float32))
+                 for _ in range(P)], synth_ir(rng, 1, L))
+
+    def run(segments):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            sigs = list(ex.map(voice, [t for seg, _ in segments for t in seg]))
+        outs = []
+        for si, (_, ir) in enumerate(segments):
+            mix = None
+            for a, z in sigs[si * P:(si + 1) * P]:
+                mix = (z + a) if mix is None else ((mix + z) + a)
+            outs.append(reverb.get_signal(mix, ir))
+        assert outs[0].shape == (1, N)
+        return time.perf_counter() - t0
+
+    t1 = run([make_segment()])                                   # also warms numpy / scipy up
+    n_seg = int(max(1, min(32, round(15.0 / max(t1, 1e-3)))))
+    segs = [make_segment() for _ in range(n_seg)]
+    dt = run(segs)
+    return {'value': n_seg * N / dt, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_seg} segment(s) x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, {sr} Hz, full '
+                      f'chain; numpy oracle, {threads} threads over voice tasks, {dt:.1f} s of wall clock '
+                      f'(host has {os.cpu_count()} logical cores)',
+            'rtf': n_seg * N / dt / sr}
 
 
 def main():

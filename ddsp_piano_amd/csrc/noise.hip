@@ -255,7 +255,7 @@ int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, const int
     const bool tiled = uniq && mirror && n_uniq > 0 && n_uniq <= 256 &&
                        (K == 32 || K == 64 || K == 96 || K == 128) && !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
-        const int fpb = 64;
+        const int fpb = env_int("DDSPP_FIR_FPB", 256);
         const dim3 grid((unsigned)((frames + fpb - 1) / fpb));
         const int nf = (int)frames;
 #define DDSPP_FIR_LAUNCH(KK)                                                                              \

@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ddspp.h declares, and rejects bad
+arguments with an error code + message (no kernel is launched, no GPU needed)."""
+import ctypes
+import os
+import re
+
+from ddsp_piano_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'ddspp.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ddspp_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/ddspp.h but not exported by libddspp.so'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_identity(lib):
+    assert lib.ddspp_version() >= 100
+    assert lib.ddspp_target_arch() == b'gfx950'
+
+
+def test_fft_size(lib):
+    assert lib.ddspp_fft_size(72000, 72000) == 262144       # BASELINE config 2: 3 s audio, 3 s IR
+    assert lib.ddspp_fft_size(72000, 48000) == 131072       # maestro-v2: L = 2 * sr
+    assert lib.ddspp_fft_size(144000, 480000) == 1048576    # config 5
+    assert lib.ddspp_fft_size(96, 190) == 512               # FilteredNoise frame (reference FFT size)
+    assert lib.ddspp_fft_size(1, 1) == 1
+
+
+def test_argument_errors_do_not_reach_the_gpu(lib):
+    null = ctypes.c_void_p(0)
+    rc = lib.ddspp_resample_linear(null, null, null, null, null, 1, 1, 1, 1, null)
+    assert rc == _lib.DDSPP_EINVAL and b'null' in lib.ddspp_last_error()
+    one = ctypes.c_void_p(16)
+    rc = lib.ddspp_cos_oscillator_bank(one, one, one, 1, 12, 4, 24000.0, 1, 1, 0, null, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'multiple of 8' in lib.ddspp_last_error()
+    rc = lib.ddspp_cos_oscillator_bank(one, one, one, 1, 16, 1000, 24000.0, 1, 1, 0, null, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'exceeds' in lib.ddspp_last_error()
+    rc = lib.ddspp_harmonic_synthesis(one, one, one, one, one, one, one, 1, 10, 1, 8, 100, 24000.0, 1, 0, null, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'upsampling' in lib.ddspp_last_error()
+    rc = lib.ddspp_time_varying_fir(one, one, one, 1, 100, 7, 10, -1, null)
+    assert rc == _lib.DDSPP_EINVAL
+    handle = ctypes.c_void_p()
+    rc = lib.ddspp_fftconv_plan_create(4, 3, 100, 10, ctypes.byref(handle))
+    assert rc == _lib.DDSPP_EINVAL and b'must be the same' in lib.ddspp_last_error()
+    assert lib.ddspp_osc_workspace_bytes(0, 10, 10) == 0
+    assert lib.ddspp_osc_workspace_bytes(1024, 72000, 128) > 0
+    try:
+        _lib.check(_lib.DDSPP_EINVAL)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError('EINVAL must map to ValueError')

@@ -1,0 +1,183 @@
+"""CPU: host side of the product (no kernels run): Processor protocol, DAG walking, DAG recognition,
+table builders against the oracle, error behaviour, sharding arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+import ddsp_piano_amd as dp
+from ddsp_piano_amd import core, parallel, polyphonic
+from util import O
+
+
+class Gain(dp.Processor):
+    def __init__(self, g, name):
+        super().__init__(name=name)
+        self.g = g
+
+    def get_controls(self, x):
+        return {'x': x}
+
+    def get_signal(self, x):
+        return x * self.g
+
+
+class Sum2(dp.Processor):
+    def get_controls(self, a, b):
+        return {'a': a, 'b': b}
+
+    def get_signal(self, a, b):
+        return a + b
+
+
+def test_processor_call_protocol():
+    p = Gain(2.0, 'g')
+    x = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    y = p(x)
+    assert y.dtype == torch.float32 and torch.equal(y, x.float() * 2)
+    d = p(x, return_outputs_dict=True)
+    assert set(d) == {'signal', 'controls'} and set(d['controls']) == {'x'}
+
+
+def test_processor_group_walks_dag_with_nested_keys():
+    a, b, s = Gain(2.0, 'a'), Gain(3.0, 'b'), Sum2('sum')
+    pg = dp.ProcessorGroup([(a, ['in']), (b, ['a/signal']), (a, ['b/signal']), (s, ['a/signal', 'b/controls/x'])])
+    x = torch.ones(1, 4)
+    out = pg({'in': x}, return_outputs_dict=True)
+    assert torch.equal(out['signal'], x * 12 + x * 2)        # a re-used: outputs['a'] overwritten
+    ctl = out['controls']
+    assert ctl['out'] is ctl['sum'] and torch.equal(ctl['in'], x) and 'inputs' in ctl
+    assert [p.name for p in pg.processors] == ['a', 'b', 'sum'] and pg.a is a
+    assert torch.equal(pg({'in': x}), out['signal'])
+    assert torch.equal(pg.get_signal(pg.get_controls({'in': x})), out['signal'])
+    with pytest.raises(KeyError):
+        pg({'nope': x})
+    with pytest.raises(TypeError):
+        dp.ProcessorGroup([('not a processor', ['in'])])
+
+
+def _dag(P, with_reverb=True, reverb=None):
+    add = dp.MultiInharmonic(name='additive', sample_rate=24000)
+    nz = dp.DynamicSizeFilteredNoise(name='noise', sample_rate=24000)
+    rv = reverb if reverb is not None else (dp.Reverb() if with_reverb else None)
+    return dp.polyphonic_dag(add, nz, rv, additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
+                             noise_controls=['magnitudes'], reverb_controls=['reverb_ir'] if rv else [], n_synths=P)
+
+
+def test_polyphonic_dag_matches_reference_node_list():
+    dag = _dag(3)
+    odag = O.polyphonic_dag(O.MultiInharmonic(name='additive'), O.FilteredNoise(name='noise'), O.Reverb(),
+                            additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
+                            noise_controls=['magnitudes'], reverb_controls=['reverb_ir'], n_synths=3)
+    assert [(n[0].name, list(n[1])) for n in dag] == [(n[0].name, list(n[1])) for n in odag]
+
+
+def test_fast_path_recognition():
+    plan = polyphonic.recognise(_dag(4))
+    assert plan is not None and plan.n_synths == 4 and plan.reverb_keys == ['reverb_ir']
+    assert polyphonic.recognise(_dag(2, with_reverb=False)).reverb is None
+    assert polyphonic.recognise(_dag(2, reverb=dp.FeedbackDelayNetworkApply())) is not None
+    dag = _dag(3)
+    dag[5] = (dag[5][0], ['noise/signal', 'additive/signal'])              # not the add chain
+    assert polyphonic.recognise(dag) is None
+    assert polyphonic.recognise([(Gain(1.0, 'g'), ['x'])] * 3) is None
+    a, b = Gain(1.0, 'a'), Gain(1.0, 'b')
+    assert dp.ProcessorGroup([(a, ['x']), (b, ['a/signal'])])({'x': torch.ones(2)}).shape == (2,)
+
+
+def test_stack_voices_zero_copy_on_cpu_falls_back_to_copy():
+    base = torch.randn(2, 3, 5, 4)
+    views = [base[:, i] for i in range(3)]
+    st = polyphonic._stack_voices(views)
+    assert st.shape == (2, 3, 5, 4) and torch.equal(st, base)
+
+
+def test_tables_match_the_oracle():
+    for T, U in [(750, 96), (50, 64), (40, 32), (20, 128), (33, 100)]:
+        lo, hi, w, aligned = core._linear_tables_np(T, T * U)
+        olo, ohi, ow = O.linear_resample_positions(T, T * U)
+        assert np.array_equal(lo, olo) and np.array_equal(hi, ohi) and np.array_equal(w, ow) and aligned
+    lo, hi, w, aligned = core._linear_tables_np(37, 1000)
+    assert not aligned and np.array_equal(w, O.linear_resample_positions(37, 1000)[2])
+    for n in (64, 128, 192, 257, 190, 7):
+        assert np.array_equal(core._hann_window_np(n), O.hann_window(n))
+    assert core.fused_synthesis_supported(750, 72000) and not core.fused_synthesis_supported(37, 1000)
+    assert not core.fused_synthesis_supported(20, 2000)            # U = 100 is not a multiple of 8
+
+
+@pytest.mark.parametrize('K,ws', [(96, 257), (64, 257), (32, 257), (128, 257), (200, 257), (65, 0), (129, 257)])
+def test_fir_matrix_is_frequency_impulse_response(K, ws):
+    rng = np.random.default_rng(K)
+    mags = rng.uniform(0, 2, [5, K]).astype(np.float32)
+    m = core._fir_matrix_np(K, ws)
+    ref = O.frequency_impulse_response(mags, ws)
+    assert m.shape == (K, ref.shape[-1])
+    np.testing.assert_allclose(mags.astype(np.float64) @ m.astype(np.float64), ref, atol=3e-7)
+    uniq, mirror = core._fir_symmetry_np(K, ws)
+    covered = set(uniq.tolist()) | set(int(x) for x in mirror if x >= 0)
+    assert covered == set(range(m.shape[1]))
+    for u, mi in zip(uniq, mirror):
+        if mi >= 0:
+            assert np.abs(m[:, u] - m[:, mi]).max() < 1e-6 * np.abs(m).max()
+
+
+def test_scale_fn_recognition():
+    import functools
+    assert core.scale_kind(None)[0] == 0
+    assert core.scale_kind(dp.exp_sigmoid)[0] == 1 and core.scale_kind(dp.exp_tanh)[0] == 2
+    k = core.scale_kind(functools.partial(dp.exp_sigmoid, max_value=3.0))
+    assert k[0] == 1 and k[1]['max_value'] == 3.0
+    assert core.scale_kind(lambda x: x) is None
+    assert core.scale_kind(functools.partial(dp.exp_sigmoid, bogus=1)) is None
+
+
+def test_shape_errors_are_raised_before_any_kernel():
+    x = torch.zeros(2, 10, 4)
+    with pytest.raises(ValueError):
+        core.upsample_with_windows(torch.zeros(10, 4), 100)
+    with pytest.raises(ValueError):
+        core.resample(x, 95, method='window')
+    with pytest.raises(ValueError):
+        core.resample(x, 100, method='bogus')
+    with pytest.raises(ValueError):
+        core.fft_convolve(torch.zeros(2, 100), torch.zeros(3, 10))
+    with pytest.raises(ValueError):
+        core.fft_convolve(torch.zeros(2, 100), torch.zeros(2, 60, 10))
+    with pytest.raises(ValueError):
+        core.fft_convolve(torch.zeros(2, 100), torch.zeros(2, 10), padding='full')
+    with pytest.raises(ValueError):
+        dp.Reverb().get_controls(torch.zeros(2, 100))
+    with pytest.raises(ValueError):
+        dp.InHarmonic().get_controls(torch.zeros(2, 5, 1), torch.zeros(2, 5, 8), torch.zeros(2, 5, 1),
+                                     torch.zeros(2, 5, 2))
+    with pytest.raises(ValueError):
+        dp.MultiInharmonic().get_controls(torch.zeros(2, 5, 2), torch.zeros(2, 5, 8), torch.zeros(2, 5, 1),
+                                          torch.zeros(2, 5, 2))
+    with pytest.raises(ValueError):
+        core.cos_oscillator_bank(torch.zeros(1, 8, 4), torch.zeros(1, 8, 5))
+
+
+def test_no_cpu_fallback():
+    """The product refuses CPU buffers instead of quietly computing somewhere else."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU box: tensors are moved to the device')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        core.resample(torch.zeros(1, 10, 4), 640)
+    with pytest.raises(RuntimeError):
+        dp.MultiInharmonic(sample_rate=16000).get_signal(torch.zeros(1, 10, 1), torch.zeros(1, 10, 8),
+                                                         torch.zeros(1, 10, 8), torch.zeros(1, 10, 1))
+
+
+def test_shard_ranges():
+    for B, W in [(512, 8), (64, 1), (10, 4), (3, 8), (0, 2)]:
+        rs = [parallel.shard_range(B, W, r) for r in range(W)]
+        assert rs[0][0] == 0 and rs[-1][1] == B
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+        sizes = [b - a for a, b in rs]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_range(8, 2, 2)
+    feats = {'a_0': torch.zeros(8, 5, 1), 'reverb_ir': torch.zeros(8, 100), 'flag': 3}
+    sh = parallel.shard_features(feats, 4, 1)
+    assert sh['a_0'].shape == (2, 5, 1) and sh['reverb_ir'].shape == (2, 100) and sh['flag'] == 3
+    with pytest.raises(ValueError):
+        parallel.shard_features({'a': torch.zeros(8, 1), 'b': torch.zeros(6, 1)}, 2, 0)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel-trace stats of bench.py, then HBM PMC passes (separate runs, as
+# MI355X_MICROARCH.md prescribes) for the oscillator-bank kernel.  Outputs land in gpurun_out/prof_$1.
+set -u
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --which osc --spans 1 --reps 2 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --which osc --spans 1 --reps 2 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --which osc,fused --spans 0 --reps 2 > $OUT/pmc_sq.log 2>&1
+cd $GRAFT_REPO_ROOT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+ls -R $OUT | head -40
