@@ -280,6 +280,58 @@ def _fir_symmetry_np(n_bands, window_size):
     return np.arange(lw, dtype=np.int32), np.full([lw], -1, np.int32)
 
 
+@functools.lru_cache(maxsize=16)
+def _fir_eo_tables_np(n_bands, window_size):
+    """Even/odd tables of the full-window FIR design, or None when the window is cropped / K unsupported.
+
+    z[j] = E[j] + O[j], z[half - j] = E[j] - O[j] (half = K - 1); out[i] = hann[i] * z[(i + half) % Lh].
+    """
+    k_all = int(n_bands)
+    ir_size = 2 * (k_all - 1)
+    if k_all not in (32, 64, 96, 128) or (0 < window_size < ir_size):
+        return None
+    half = k_all - 1
+    nj = half // 2 + 1
+    coef = np.full([k_all], 2.0)
+    coef[0] = coef[-1] = 1.0
+    j = np.arange(nj, dtype=np.float64)[None, :]
+    ke = np.arange(0, k_all, 2, dtype=np.float64)[:, None]
+    ko = np.arange(1, k_all, 2, dtype=np.float64)[:, None]
+    ce = coef[0::2, None] * np.cos(2.0 * np.pi * ke * j / ir_size) / ir_size
+    co = coef[1::2, None] * np.cos(2.0 * np.pi * ko * j / ir_size) / ir_size
+    win = _hann_window_np(ir_size).astype(np.float64)
+    idx = np.full([nj, 4], -1, np.int32)
+    we = np.zeros([nj, 4], np.float64)
+    wo = np.zeros([nj, 4], np.float64)
+    fill = np.zeros([nj], np.int64)
+    for i in range(ir_size):
+        jj = (i + half) % ir_size
+        if jj > half:
+            jj = ir_size - jj
+        if jj <= half // 2:
+            lane, sign = jj, 1.0
+        else:
+            lane, sign = half - jj, -1.0
+        s = fill[lane]
+        idx[lane, s] = i
+        we[lane, s] = win[i]
+        wo[lane, s] = sign * win[i]
+        fill[lane] += 1
+    assert fill.max() <= 4 and (idx >= 0).sum() == ir_size
+    return (np.ascontiguousarray(ce.astype(F32)), np.ascontiguousarray(co.astype(F32)), idx,
+            we.astype(F32), wo.astype(F32), nj, ir_size)
+
+
+def fir_eo_tables(n_bands, window_size, device):
+    def build():
+        t = _fir_eo_tables_np(int(n_bands), int(window_size))
+        if t is None:
+            return None
+        ce, co, idx, we, wo, nj, lw = t
+        return tuple(torch.from_numpy(a).to(device) for a in (ce, co, idx, we, wo)) + (nj, lw)
+    return _cached(('firEO', int(n_bands), int(window_size), str(device)), build)
+
+
 def fir_matrix(n_bands, window_size, device):
     def build():
         uniq, mirror = _fir_symmetry_np(int(n_bands), int(window_size))
@@ -452,6 +504,14 @@ def frequency_impulse_response(magnitudes, window_size=0):
     """ddsp.core.frequency_impulse_response: [..., K] magnitudes -> [..., Lw] causal linear-phase FIRs."""
     mags = tf_float32(magnitudes)
     k = int(mags.shape[-1])
+    eo = fir_eo_tables(k, int(window_size), mags.device) if mags.data_ptr() % 16 == 0 else None
+    if eo is not None:
+        ce, co, idx, we, wo, nj, lw = eo
+        frames = mags.numel() // k
+        ir = torch.empty(tuple(mags.shape[:-1]) + (lw,), dtype=torch.float32, device=mags.device)
+        _lib.check(_lib_().ddspp_fir_from_magnitudes_eo(_ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we),
+                                                        _ptr(wo), _ptr(ir), frames, k, lw, nj, _stream()))
+        return ir
     m, uniq, mirror = fir_matrix(k, int(window_size), mags.device)
     lw = int(m.shape[1])
     frames = mags.numel() // k

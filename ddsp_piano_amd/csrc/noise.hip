@@ -65,6 +65,68 @@ __global__ void __launch_bounds__(THREADS) fir_from_magnitudes_kernel(const floa
     }
 }
 
+// Even/odd split of the inverse real DFT (full-window case, Lh = 2 (K - 1), half = K - 1):
+//   cos(2 pi (half - j) k / Lh) = (-1)^k cos(2 pi j k / Lh)
+//   E[j] = sum_{k even} c_k m_k cos(.)/Lh,  O[j] = sum_{k odd} ...,   z[j] = E + O,  z[half - j] = E - O
+// so lane j (j <= half / 2) yields up to four taps of the symmetric FIR from K FMAs -- a quarter of the
+// dense product.  The frame's magnitudes are staged in LDS (coalesced) and read back as wave-uniform
+// 16-byte blocks; the lane's two table columns stay in K registers.
+template <int KH>   // KH = K / 2 (K even)
+__global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ mags,     // [frames, 2 KH]
+                                                   const float* __restrict__ CE,       // [KH, NJ]
+                                                   const float* __restrict__ CO,       // [KH, NJ]
+                                                   const int* __restrict__ tap_idx,    // [NJ, 4]
+                                                   const float* __restrict__ tap_we,   // [NJ, 4]
+                                                   const float* __restrict__ tap_wo,   // [NJ, 4]
+                                                   float* __restrict__ ir, int frames, int Lw, int NJ,
+                                                   int frames_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float mtile[];       // [frames_per_block][2 KH]
+    constexpr int K = 2 * KH;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int j = min(lane, NJ - 1);
+    const bool active = lane < NJ;
+    float ce[KH], co[KH];
+#pragma unroll
+    for (int q = 0; q < KH; ++q) {
+        ce[q] = CE[q * NJ + j];
+        co[q] = CO[q * NJ + j];
+    }
+    int tidx[4];
+    float twe[4], two[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        tidx[s] = active ? tap_idx[j * 4 + s] : -1;
+        twe[s] = tap_we[j * 4 + s];
+        two[s] = tap_wo[j * 4 + s];
+    }
+    const int f0 = blockIdx.x * frames_per_block;
+    const int nf = min(frames_per_block, frames - f0);
+    {   // coalesced copy of the tile
+        const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
+        float4* dst = reinterpret_cast<float4*>(mtile);
+        const int n4 = nf * (K / 4);
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int f = wib; f < nf; f += 4) {
+        const float4* mg = reinterpret_cast<const float4*>(mtile + f * K);   // wave-uniform address
+        float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < KH; q += 2) {
+            const float4 m = mg[q / 2];                  // magnitudes 2q, 2q+1, 2q+2, 2q+3
+            e0 = __builtin_fmaf(m.x, ce[q], e0);
+            o0 = __builtin_fmaf(m.y, co[q], o0);
+            e1 = __builtin_fmaf(m.z, ce[q + 1], e1);
+            o1 = __builtin_fmaf(m.w, co[q + 1], o1);
+        }
+        const float E = e0 + e1, O = o0 + o1;
+        float* dst = ir + (size_t)(f0 + f) * Lw;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (tidx[s] >= 0) dst[tidx[s]] = __builtin_fmaf(two[s], O, twe[s] * E);
+    }
+}
+
 __global__ void __launch_bounds__(256) fir_from_magnitudes_generic_kernel(const float* __restrict__ mags,
                                                                         const float* __restrict__ M,
                                                                         float* __restrict__ ir,
@@ -85,14 +147,15 @@ __global__ void __launch_bounds__(256) fir_from_magnitudes_generic_kernel(const 
 constexpr int FIR_W = 512;          // outputs per wavefront
 constexpr int FIR_PASS = 256;       // outputs per pass (64 lanes x 4)
 constexpr int FIR_MAX_FRAMES = 24;  // frames staged per wavefront
-constexpr int FIR_LDS_FLOATS = 2560;  // per wavefront
+constexpr int FIR_LDS_FLOATS = 2560;  // per wavefront: staged frame FIRs
+constexpr int FIR_X_FLOATS = 784;     // per wavefront: staged noise window (FIR_W + 254 + slack)
 
 __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x,   // [R, N]
                                                    const float* __restrict__ ir,  // [R, T, Lw]
                                                    float* __restrict__ out,       // [R, N]
                                                    int R, int N, int T, int U, int Lw, int delay,
                                                    int windows_per_row, int padl, int nb) {
-    __shared__ __attribute__((aligned(16))) float lds[4][FIR_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[4][FIR_LDS_FLOATS + FIR_X_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int task = wave_uniform(blockIdx.x * 4 + wib);
@@ -108,18 +171,51 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
     const int f_lo = j_first / U;
     const int f_hi = min(j_last / U, T - 1);
     const int nfr = f_hi - f_lo + 1;
-    for (int f = 0; f < nfr; ++f) {
-        const float* src = ir + ((size_t)row * T + f_lo + f) * Lw;
-        for (int q = lane; q < gstride; q += 64) {
-            const int tap = q - padl;
-            G[f * gstride + q] = (tap >= 0 && tap < Lw) ? src[tap] : 0.0f;
+    // Staging: every load is issued before the first LDS store (branch-free clamped addresses), so a
+    // wavefront pays the HBM/L2 latency once per batch of loads instead of once per load.
+    float* Xs = G + FIR_LDS_FLOATS;
+    const int jx0 = j_first & ~3;
+    {
+        constexpr int XL = (FIR_X_FLOATS + 63) / 64;
+        const float* xg = x + (size_t)row * N;
+        const int nx = j_last + 1 - jx0;
+        float xv[XL];
+#pragma unroll
+        for (int u = 0; u < XL; ++u) xv[u] = xg[jx0 + min(lane + 64 * u, nx - 1)];
+#pragma unroll
+        for (int u = 0; u < XL; ++u)
+            if (lane + 64 * u < nx) Xs[lane + 64 * u] = xv[u];
+    }
+    {
+        constexpr int FB = 4;                       // frames per batch
+        constexpr int QL = 5;                       // 64-lane strips per staged frame (gstride <= 320)
+        for (int f0 = 0; f0 < nfr; f0 += FB) {
+            float gv[FB][QL];
+#pragma unroll
+            for (int ff = 0; ff < FB; ++ff) {
+                const float* src = ir + ((size_t)row * T + f_lo + min(f0 + ff, nfr - 1)) * Lw;
+#pragma unroll
+                for (int u = 0; u < QL; ++u) {
+                    const int tap = lane + 64 * u - padl;
+                    gv[ff][u] = src[min(max(tap, 0), Lw - 1)];
+                }
+            }
+#pragma unroll
+            for (int ff = 0; ff < FB; ++ff) {
+#pragma unroll
+                for (int u = 0; u < QL; ++u) {
+                    const int q = lane + 64 * u, tap = q - padl;
+                    if (f0 + ff < nfr && q < gstride)
+                        G[(f0 + ff) * gstride + q] = (tap >= 0 && tap < Lw) ? gv[ff][u] : 0.0f;
+                }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const float* xr = x + (size_t)row * N;
+    const float* xr = Xs - jx0;                   // xr[j] = noise[row, j] for j in [jx0, j_last]
     const int bpf = U / 4;                        // input blocks per frame
     for (int ps = 0; ps < FIR_W / FIR_PASS; ++ps) {
         const int np0 = n0 + ps * FIR_PASS;
@@ -295,7 +391,8 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     const int frames_max = (FIR_W + Lw + U - 2) / U + 2;
     const bool tiled = (U % 4 == 0) && (N % 4 == 0) && ((uintptr_t)audio % 16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && frames_max <= FIR_MAX_FRAMES &&
-                       frames_max * nb * 4 <= FIR_LDS_FLOATS && !env_int("DDSPP_FIR_GENERIC", 0);
+                       frames_max * nb * 4 <= FIR_LDS_FLOATS && FIR_W + Lw + 8 <= FIR_X_FLOATS && nb * 4 <= 320 &&
+                       !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
         const int wpr = (N + FIR_W - 1) / FIR_W;
         const long long tasks = (long long)R * wpr;
@@ -306,6 +403,29 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
         hipLaunchKernelGGL(tv_fir_generic_kernel, dim3(stream_grid((size_t)R * N)), dim3(256), 0, stream,
                            audio, impulse_response, out, R, N, T, U, Lw, delay);
     }
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// Same operator through the even/odd tables (host: ddsp_piano_amd/core.py::_fir_eo_tables);
+// K must be even and a multiple of 4, NJ <= 64.
+int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
+                                 const float* tap_we, const float* tap_wo, float* ir, size_t frames, int K,
+                                 int Lw, int NJ, hipStream_t stream) {
+    DDSPP_REQUIRE(magnitudes && CE && CO && tap_idx && tap_we && tap_wo && ir, "fir_from_magnitudes_eo: null buffer");
+    DDSPP_REQUIRE(K > 0 && K % 4 == 0 && NJ > 0 && NJ <= 64 && Lw > 0, "fir_from_magnitudes_eo: bad dims");
+    DDSPP_REQUIRE(K == 32 || K == 64 || K == 96 || K == 128, "fir_from_magnitudes_eo: unsupported band count %d", K);
+    DDSPP_REQUIRE(frames < (1ull << 31), "fir_from_magnitudes_eo: too many frames");
+    DDSPP_REQUIRE((uintptr_t)magnitudes % 16 == 0, "fir_from_magnitudes_eo: magnitudes must be 16-byte aligned");
+    if (frames == 0) return DDSPP_OK;
+    const int fpb = 64;
+    const dim3 grid((unsigned)((frames + fpb - 1) / fpb)), block(256);
+    const size_t lds = (size_t)fpb * K * sizeof(float);
+    const int nf = (int)frames;
+    if (K == 32) hipLaunchKernelGGL(fir_eo_kernel<16>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
+    else if (K == 64) hipLaunchKernelGGL(fir_eo_kernel<32>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
+    else if (K == 96) hipLaunchKernelGGL(fir_eo_kernel<48>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
+    else hipLaunchKernelGGL(fir_eo_kernel<64>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -116,6 +116,13 @@ int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, 
 int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, const int* uniq, const int* mirror,
                               int n_uniq, float* ir, size_t frames, int K, int Lw, hipStream_t stream);
 
+/* The same operator for the full-window case (2 (K - 1) <= window_size), through the even/odd split of
+ * the inverse real DFT: CE/CO[K/2, NJ] cosine tables, tap_idx/tap_we/tap_wo[NJ, 4]: the up-to-four taps
+ * lane j produces and their weights, ir[tap] = we * E[j] + wo * O[j]. */
+int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
+                                 const float* tap_we, const float* tap_wo, float* ir, size_t frames, int K,
+                                 int Lw, int NJ, hipStream_t stream);
+
 /* ddsp.core.fft_convolve(audio[R,N], impulse_response[R,T,Lw], padding='same', delay_compensation)
  * in the framed case (frame = hop = N / T); reached from filtered_noise_synth.py:41-42 through
  * ddsp.core.frequency_filter.  delay_compensation < 0 -> (Lw - 1) // 2 - 1. */
