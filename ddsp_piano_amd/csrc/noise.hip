@@ -146,50 +146,60 @@ __global__ void __launch_bounds__(256) fir_from_magnitudes_generic_kernel(const 
 // ------------------------------------------------------------------------------------------------
 constexpr int FIR_W = 512;          // outputs per wavefront
 constexpr int FIR_PASS = 256;       // outputs per pass (64 lanes x 4)
-constexpr int FIR_MAX_FRAMES = 24;  // frames staged per wavefront
-constexpr int FIR_LDS_FLOATS = 2560;  // per wavefront: staged frame FIRs
-constexpr int FIR_X_FLOATS = 784;     // per wavefront: staged noise window (FIR_W + 254 + slack)
+constexpr int FIR_MAX_FRAMES = 80;  // frames staged per workgroup
+constexpr int FIR_BW = 4 * FIR_W;    // outputs per workgroup
+constexpr int FIR_G_FLOATS = 7168;   // per workgroup: staged frame FIRs
+constexpr int FIR_X_FLOATS = 2432;   // per workgroup: staged noise window incl. zero blocks around the signal
 
 __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x,   // [R, N]
                                                    const float* __restrict__ ir,  // [R, T, Lw]
                                                    float* __restrict__ out,       // [R, N]
                                                    int R, int N, int T, int U, int Lw, int delay,
-                                                   int windows_per_row, int padl, int nb) {
-    __shared__ __attribute__((aligned(16))) float lds[4][FIR_LDS_FLOATS + FIR_X_FLOATS];
+                                                   int windows_per_row, int padl, int nb, int seglen) {
+    // One workgroup = FIR_BW consecutive outputs of one row: the frame FIRs and the noise samples that
+    // reach them are staged ONCE for the four wavefronts (each then owns FIR_W outputs), which cuts
+    // the re-read of impulse responses shared by neighbouring windows from 1.9x to 1.2x.
+    __shared__ __attribute__((aligned(16))) float lds[FIR_G_FLOATS + FIR_X_FLOATS + 4 * 256];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int task = wave_uniform(blockIdx.x * 4 + wib);
-    if (task >= R * windows_per_row) return;
-    const int row = task / windows_per_row;
-    const int n0 = (task - row * windows_per_row) * FIR_W;
-    float* G = lds[wib];
+    const int row = blockIdx.x / windows_per_row;
+    const int nB0 = (blockIdx.x - row * windows_per_row) * FIR_BW;
+    const int n0 = nB0 + wib * FIR_W;             // this wavefront's outputs
+    float* G = lds;
+    float* Xs = G + FIR_G_FLOATS;
+    float* red = Xs + FIR_X_FLOATS + wib * 256;
     const int gstride = nb * 4;                   // floats per staged frame
 
-    // frames whose noise blocks can reach this window
-    const int j_first = max(n0 + delay - (Lw - 1), 0);
-    const int j_last = min(n0 + FIR_W - 1 + delay, N - 1);
+    // frames whose noise blocks can reach this workgroup's outputs
+    const int j_first = max(nB0 + delay - (Lw - 1), 0);
+    const int j_last = min(nB0 + FIR_BW - 1 + delay, N - 1);
     const int f_lo = j_first / U;
     const int f_hi = min(j_last / U, T - 1);
     const int nfr = f_hi - f_lo + 1;
+    // input blocks (of 4 samples) any lane may touch: zero outside the signal, so the inner loop
+    // needs no bounds logic at all
+    const int jb_min = (nB0 + delay + 3) / 4 - 4 * seglen;           // may be negative
+    const int jb_max = (nB0 + FIR_BW - 64 + delay + 3) / 4 + 15;
     // Staging: every load is issued before the first LDS store (branch-free clamped addresses), so a
     // wavefront pays the HBM/L2 latency once per batch of loads instead of once per load.
-    float* Xs = G + FIR_LDS_FLOATS;
-    const int jx0 = j_first & ~3;
     {
-        constexpr int XL = (FIR_X_FLOATS + 63) / 64;
+        constexpr int XL = (FIR_X_FLOATS + 255) / 256;
         const float* xg = x + (size_t)row * N;
-        const int nx = j_last + 1 - jx0;
+        const int nx = (jb_max - jb_min + 1) * 4;
+        const int j0 = 4 * jb_min;
         float xv[XL];
 #pragma unroll
-        for (int u = 0; u < XL; ++u) xv[u] = xg[jx0 + min(lane + 64 * u, nx - 1)];
+        for (int u = 0; u < XL; ++u) xv[u] = xg[min(max(j0 + (int)threadIdx.x + 256 * u, 0), N - 1)];
 #pragma unroll
-        for (int u = 0; u < XL; ++u)
-            if (lane + 64 * u < nx) Xs[lane + 64 * u] = xv[u];
+        for (int u = 0; u < XL; ++u) {
+            const int q = threadIdx.x + 256 * u, j = j0 + q;
+            if (q < nx) Xs[q] = (j >= 0 && j < N) ? xv[u] : 0.0f;
+        }
     }
     {
-        constexpr int FB = 4;                       // frames per batch
+        constexpr int FB = 4;                       // frames per batch (per wavefront)
         constexpr int QL = 5;                       // 64-lane strips per staged frame (gstride <= 320)
-        for (int f0 = 0; f0 < nfr; f0 += FB) {
+        for (int f0 = wib * FB; f0 < nfr; f0 += 4 * FB) {
             float gv[FB][QL];
 #pragma unroll
             for (int ff = 0; ff < FB; ++ff) {
@@ -211,62 +221,76 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
 
-    const float* xr = Xs - jx0;                   // xr[j] = noise[row, j] for j in [jx0, j_last]
-    const int bpf = U / 4;                        // input blocks per frame
-    for (int ps = 0; ps < FIR_W / FIR_PASS; ++ps) {
-        const int np0 = n0 + ps * FIR_PASS;
+    // ---- compute: 64 outputs per pass.  Lane = (output block a, input segment sg): the ~(Lw + 6) / 4
+    // input blocks that reach output block a are split over four lanes, so every FMA carries a tap
+    // inside (or one block around) the FIR's support.  The lane -> (sg, a) map follows the way the LDS
+    // services a ds_read_b128 (four fixed groups of 16 lanes): each group is one segment, so its 16
+    // noise blocks are consecutive (conflict free) and its tap block is one address (broadcast).
+    const int bpf = U / 4;                               // input blocks per frame
+    const int h = lane >> 5, w = lane & 31;
+    const bool g0 = (w < 4) || (w >= 12 && w < 16) || (w >= 20 && w < 28);
+    const int sg = 2 * h + (g0 ? 0 : 1);
+    const int a = g0 ? (w < 4 ? w : (w < 16 ? w - 8 : w - 12)) : (w < 12 ? w - 4 : (w < 20 ? w - 8 : w - 16));
+    for (int ps = 0; ps < FIR_W / 64; ++ps) {
+        const int np0 = n0 + ps * 64;
         if (np0 >= N) break;
-        const int m0 = np0 + delay;               // z index of lane 0, e = 0
-        int jb = max(m0 - (Lw - 1), 0) / 4;
-        const int jb_end = min(m0 + FIR_PASS - 1, N - 1) / 4 + 1;   // exclusive
+        const int m0 = np0 + delay;
+        const int c0 = (m0 - 3 + padl) / 4;              // exact: (delay - 3 + padl) % 4 == 0, np0 % 4 == 0
+        int jb = (m0 + 3) / 4 + a - sg * seglen;         // first (highest) input block of this lane
+        int bq = 4 * (c0 + a - jb);                      // float offset of the lower tap block; >= 0, same for all a
+        const int jbc = min(max(jb, 0), (N - 1) / 4);
+        int f = min(max((4 * jbc) / U, f_lo), f_hi);
+        int jr = jbc - f * bpf;                          // position of jb inside its frame
+        const float* Gf = G + (f - f_lo) * gstride;
+        const float* xp = Xs + 4 * (jb - jb_min);
+        float4 t0 = *reinterpret_cast<const float4*>(Gf + bq);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        // block index (before clamping) of the lower 16-byte block this lane reads for `jb`:
-        // positions pos = tap + padl, tap = (m0 - 4 jb) + 4 a + d, d in [-3, 4]
-        int b0 = (m0 - 4 * jb - 3 + padl) / 4 + lane;      // (..) is a multiple of 4 by choice of padl
-        while (jb < jb_end) {
-            const int f = (4 * jb) / U;                     // all blocks up to jb_stop share this FIR
-            const int jb_stop = min((f + 1) * bpf, jb_end);
-            const float* Gf = G + (f - f_lo) * gstride;
-            float4 hi = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 + 1, 0), nb - 1));
-            // four input blocks per trip: their noise samples (wave-uniform scalar loads) and their
-            // tap blocks are all requested before the first FMA needs them
-            for (; jb + 4 <= jb_stop; jb += 4, b0 -= 4) {
-                float4 xv[4], tb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    xv[u] = *reinterpret_cast<const float4*>(xr + 4 * (jb + u));
-                    tb[u] = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0 - u, 0), nb - 1));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 lo = tb[u];
-                    const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
-                    hi = lo;
-                }
+        auto step = [&](float4& lo, float4& hi) {
+            if (jr < 0 && f > f_lo) {                    // crossed into the previous frame: its own FIR
+                f -= 1;
+                jr += bpf;
+                Gf = G + (f - f_lo) * gstride;
+                lo = *reinterpret_cast<const float4*>(Gf + bq);
             }
-            for (; jb < jb_stop; ++jb, --b0) {
-                const float4 lo = *reinterpret_cast<const float4*>(Gf + 4 * min(max(b0, 0), nb - 1));
-                const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * jb);
-                const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            hi = *reinterpret_cast<const float4*>(Gf + bq + 4);
+            const float4 xv = *reinterpret_cast<const float4*>(xp);
+            const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
-                hi = lo;
-            }
+                for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+            bq += 4;
+            xp -= 4;
+            --jr;
+        };
+        float4 t1;
+        int i = 0;
+        for (; i + 2 <= seglen; i += 2) {                // two steps per trip: t0/t1 swap roles, no copies
+            step(t0, t1);
+            step(t1, t0);
         }
-        const int n = np0 + 4 * lane;
-        if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (i < seglen) step(t0, t1);
+        // meet the four segments of each output block
+        *reinterpret_cast<float4*>(red + (sg * 16 + a) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {
+            float4 s0 = *reinterpret_cast<const float4*>(red + lane * 4);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(red + (k * 16 + lane) * 4);
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            }
+            const int n = np0 + 4 * lane;
+            if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = s0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -386,19 +410,25 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     const int U = N / T;
     const int delay = delay_compensation < 0 ? (Lw - 1) / 2 - 1 : delay_compensation;
     DDSPP_REQUIRE(delay >= 0, "time_varying_fir: negative delay");
-    const int padl = 4 + ((3 - (delay % 4)) % 4 + 4) % 4;      // (delay - 3 + padl) % 4 == 0, padl >= 4
-    const int nb = (padl + Lw + 3) / 4 + 1;
-    const int frames_max = (FIR_W + Lw + U - 2) / U + 2;
+    // tap t of a frame sits at float padl + t of its staged image; padl makes (delay - 3 + padl) a
+    // multiple of 4 (aligned 16-byte tap blocks) and leaves >= 2 zero blocks in front, nb leaves zero
+    // blocks behind for every block index the inner loop can form (no clamping in the loop)
+    const int padl = 8 + ((3 - (delay % 4)) % 4 + 4) % 4;
+    const int seglen = (((Lw + 6) / 4 + 1) + 3) / 4;
+    const int nb_need = (padl + Lw + 3) / 4 + 1;
+    const int nb = (4 * seglen + 4 > nb_need ? 4 * seglen + 4 : nb_need) + 1;
+    const int frames_max = (FIR_BW + Lw + U - 2) / U + 2;
     const bool tiled = (U % 4 == 0) && (N % 4 == 0) && ((uintptr_t)audio % 16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && frames_max <= FIR_MAX_FRAMES &&
-                       frames_max * nb * 4 <= FIR_LDS_FLOATS && FIR_W + Lw + 8 <= FIR_X_FLOATS && nb * 4 <= 320 &&
+                       frames_max * nb * 4 <= FIR_G_FLOATS && (FIR_BW / 4 + 16 + 4 * seglen + 2) * 4 <= FIR_X_FLOATS &&
+                       nb * 4 <= 320 &&
                        !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
-        const int wpr = (N + FIR_W - 1) / FIR_W;
+        const int wpr = (N + FIR_BW - 1) / FIR_BW;
         const long long tasks = (long long)R * wpr;
         DDSPP_REQUIRE(tasks < (1ll << 31), "time_varying_fir: too many tasks");
-        hipLaunchKernelGGL(tv_fir_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, audio,
-                           impulse_response, out, R, N, T, U, Lw, delay, wpr, padl, nb);
+        hipLaunchKernelGGL(tv_fir_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, audio,
+                           impulse_response, out, R, N, T, U, Lw, delay, wpr, padl, nb, seglen);
     } else {
         hipLaunchKernelGGL(tv_fir_generic_kernel, dim3(stream_grid((size_t)R * N)), dim3(256), 0, stream,
                            audio, impulse_response, out, R, N, T, U, Lw, delay);

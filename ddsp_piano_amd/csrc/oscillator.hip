@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                     if (!CFREQ) fe[i][j] = x0[j] + dx * wl[i];        // legacy bilinear (core.resample)
                     // Hann overlap-add of frames t and t+1 (core.upsample_with_windows); the second
                     // product is fused: <= 1 ulp on an amplitude, never on a phase.
-                    if (MODE != MODE_PREPASS) ae[i][j] = __builtin_fmaf(a1[j], w1[i], a0[j] * w0[i]);
+                    if (MODE != MODE_PREPASS && act[j]) ae[i][j] = __builtin_fmaf(a1[j], w1[i], a0[j] * w0[i]);
                 }
             }
         } else {
@@ -472,6 +472,166 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     }
 }
 
+// Fused source, spans > 1: chunk end phases and span start offsets in ONE sequential walk per
+// (row, 64-oscillator group), with memoisation.  A chunk whose oscillators all keep one frequency
+// (every frame it touches has the same hf -- a held piano note) has an end phase that depends on that
+// frequency only (1000 sequential float32 adds of the same omega from 0), so it is scanned once and
+// re-used for every later chunk with the same frequencies; only chunks with moving frequencies are
+// scanned sample by sample.  Output: astart[row, span, v] = e[0] + ... + e[c0(span) - 1] accumulated
+// sequentially in float32 -- exactly what the pre-pass + offset-scan kernels produce.
+template <int VPL>
+__global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
+    const int lane = threadIdx.x & 63;
+    const int task = wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (task >= p.R * p.groups) return;
+    const int row = task / p.groups, grp = task - row * p.groups;
+    const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
+    const int vbase = grp * p.vgrp, vlast = min(vbase + p.vgrp, p.V) - 1;
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
+
+    int vk[VPL], vs[VPL], vidx[VPL];
+    bool valid[VPL];
+    float kmul[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int v = vbase + lane + 64 * j;
+        vidx[j] = v;
+        valid[j] = v <= vlast;
+        const int vc = min(v, vlast);
+        vs[j] = vc / H;
+        vk[j] = vc - vs[j] * H;
+        kmul[j] = (float)(vk[j] + 1);
+    }
+    // raw loads and arithmetic are kept apart (and free of branches) so that a batch of frames is
+    // fetched with all its loads in flight at once
+    const float* shp = p.shifts ? p.shifts : p.hd;          // no shifts: any finite [R, T, H] buffer ...
+    const float sh_on = p.shifts ? 1.0f : 0.0f;             // ... times 0
+    auto hf_raw = [&](int tt, float* rf, float* rs) {
+        const size_t fr = (size_t)row * T + tt;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            rf[j] = p.f0[fr * S + vs[j]];
+            rs[j] = shp[fr * H + vk[j]];
+        }
+    };
+    auto hf_calc = [&](const float* rf, const float* rs, float* xf) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            float f = rf[j] * kmul[j];
+            if (p.shifts) f = f * (1.0f + rs[j] * sh_on);
+            xf[j] = valid[j] ? f : 0.0f;
+        }
+    };
+    auto hf_of = [&](int tt, float* xf) {
+        float rf[VPL], rs[VPL];
+        hf_raw(tt, rf, rs);
+        hf_calc(rf, rs, xf);
+    };
+
+    // Streaming change detector over the frames: last_change = largest t <= t_checked with
+    // hf(t) != hf(t - 1) in some lane.  Frames are fetched 32 at a time with independent loads, so
+    // a wavefront pays one memory latency per 32 frames, not per frame.
+    constexpr int FB = VPL <= 2 ? 32 : (VPL <= 4 ? 16 : 8);
+    float x_prev[VPL];
+    hf_of(0, x_prev);
+    int t_checked = 0, last_change = 0;
+    auto check_upto = [&](int t_need) {
+        while (t_checked < t_need) {
+            float rf[FB][VPL], rs[FB][VPL];
+#pragma unroll
+            for (int u = 0; u < FB; ++u) hf_raw(min(t_checked + 1 + u, T - 1), rf[u], rs[u]);
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                float xb[1][VPL];
+                hf_calc(rf[u], rs[u], xb[0]);
+                bool ch = false;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    ch = ch || (xb[0][j] != x_prev[j]);
+                    x_prev[j] = xb[0][j];
+                }
+                if (__any(ch) && t_checked + 1 + u <= T - 1) last_change = t_checked + 1 + u;
+            }
+            t_checked = min(t_checked + FB, T - 1);
+            if (t_checked == T - 1) break;
+        }
+    };
+
+    float asum[VPL], e_memo[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        asum[j] = 0.0f;
+        e_memo[j] = 0.0f;
+    }
+    int memo_t = -1;                   // first frame of the chunk the memo was taken from (-1: none)
+    for (int c = 0; c <= p.npre; ++c) {
+        if (c % p.cps == 0) {
+            const int span = c / p.cps;
+            if (span < p.spans) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j)
+                    p.ework[((size_t)row * p.spans + span) * p.VP + vidx[j]] = asum[j];   // = astart
+            }
+        }
+        if (c == p.npre) break;
+        const int n_lo = c * DDSPP_CHUNK, n_hi = min(n_lo + DDSPP_CHUNK, N);
+        const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
+        check_upto(t_hi);
+        // no change in (t_lo, t_hi] <=> every frame the chunk touches carries the same frequencies
+        const bool chunk_const = (t_checked >= t_hi) && (last_change <= t_lo);
+        float e[VPL];
+        if (chunk_const && memo_t >= 0 && last_change <= memo_t) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) e[j] = e_memo[j];
+        } else if (chunk_const) {
+            float xa[VPL], om[VPL], ph[VPL];
+            hf_of(t_lo, xa);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                om[j] = omega_of<false>(xa[j], p.sr, p.rsr);
+                ph[j] = 0.0f;
+            }
+            for (int n = n_lo; n < n_hi; ++n) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) ph[j] = ph[j] + om[j];
+            }
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                e[j] = mod_2pi(ph[j]);
+                e_memo[j] = e[j];
+            }
+            memo_t = (n_hi - n_lo == DDSPP_CHUNK) ? t_lo : -1;     // a short last chunk is no memo
+        } else {
+            float ph[VPL], x0[VPL], x1[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) ph[j] = 0.0f;
+            int tt = t_lo, r = n_lo - t_lo * U;
+            hf_of(tt, x0);
+            hf_of(min(tt + 1, T - 1), x1);
+            for (int n = n_lo; n < n_hi; ++n) {
+                const float wl = wlin_c[n];
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const float fe = x0[j] + (x1[j] - x0[j]) * wl;
+                    ph[j] = ph[j] + omega_of<false>(fe, p.sr, p.rsr);
+                }
+                if (++r == U) {
+                    r = 0;
+                    ++tt;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) x0[j] = x1[j];
+                    hf_of(min(tt + 1, T - 1), x1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) e[j] = mod_2pi(ph[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + e[j];
+    }
+}
+
 // Sequential (float32) scan of the chunk end phases: astart[row, span, v] = e[0] + ... + e[c0-1]
 // in exactly the order of `tf.cumsum(offsets, axis=1)` in ddsp.core.angular_cumsum.
 __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __restrict__ ework,
@@ -566,7 +726,7 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
             // enough wavefronts to occupy 256 CUs; the fused source is ALU bound and likes more
             // waves, the materialised source pays one extra read of `fe` per pre-passed chunk and
             // is kept at one span whenever the rows alone give >= 4 waves per CU.
-            const int target = fused ? env_int("DDSPP_OSC_TARGET_WAVES_FUSED", 8192)
+            const int target = fused ? env_int("DDSPP_OSC_TARGET_WAVES_FUSED", 36864)
                                      : env_int("DDSPP_OSC_TARGET_WAVES", 1024);
             spans = (target + R - 1) / R;
         }
@@ -589,7 +749,12 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
     const dim3 blk(64 * p.groups);
     const size_t lds = ((size_t)p.groups * (TILE * TSTRIDE) + 2 * p.groups * 32) * sizeof(float);
     if (angular) {
-        if (p.spans > 1) {
+        if (p.spans > 1 && FUSED && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0)) {
+            OscParams q = p;
+            q.ework = const_cast<float*>(p.astart);      // the memo pre-pass writes astart directly
+            const int tasks = p.R * p.groups;
+            hipLaunchKernelGGL((osc_prepass_fused_kernel<VPL>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q);
+        } else if (p.spans > 1) {
             const int nblk_pre = p.R * p.npre;
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), blk, lds,
                                stream, p);
