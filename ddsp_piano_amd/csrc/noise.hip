@@ -238,41 +238,31 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
         if (np0 >= N) break;
         const int m0 = np0 + delay;
         const int c0 = (m0 - 3 + padl) / 4;              // exact: (delay - 3 + padl) % 4 == 0, np0 % 4 == 0
-        int jb = (m0 + 3) / 4 + a - sg * seglen;         // first (highest) input block of this lane
-        int bq = 4 * (c0 + a - jb);                      // float offset of the lower tap block; >= 0, same for all a
+        const int jb = (m0 + 3) / 4 + a - sg * seglen;   // first (highest) input block of this lane
+        const int bq0 = 4 * (c0 + a - jb);               // float offset of the lower tap block; >= 0, same for all a
+        // A lane's seglen (<= U / 4) input blocks lie in at most two frames: the first n1 steps use the
+        // frame of jb, the rest the frame before it.  Both tap pointers are per-lane constants, the
+        // loop body is branch free (one select per step) and carries no state between steps.
         const int jbc = min(max(jb, 0), (N - 1) / 4);
-        int f = min(max((4 * jbc) / U, f_lo), f_hi);
-        int jr = jbc - f * bpf;                          // position of jb inside its frame
-        const float* Gf = G + (f - f_lo) * gstride;
+        const int fA = min(max((4 * jbc) / U, f_lo), f_hi);
+        const int n1 = jb - fA * bpf + 1;                // blocks past the end of the signal count as its last frame
+        const float* GA = G + (fA - f_lo) * gstride + bq0;
+        const float* GB = G + (max(fA - 1, f_lo) - f_lo) * gstride + bq0;
         const float* xp = Xs + 4 * (jb - jb_min);
-        float4 t0 = *reinterpret_cast<const float4*>(Gf + bq);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        auto step = [&](float4& lo, float4& hi) {
-            if (jr < 0 && f > f_lo) {                    // crossed into the previous frame: its own FIR
-                f -= 1;
-                jr += bpf;
-                Gf = G + (f - f_lo) * gstride;
-                lo = *reinterpret_cast<const float4*>(Gf + bq);
-            }
-            hi = *reinterpret_cast<const float4*>(Gf + bq + 4);
-            const float4 xv = *reinterpret_cast<const float4*>(xp);
+#pragma unroll 2
+        for (int i = 0; i < seglen; ++i) {
+            const float* gp = (i < n1 ? GA : GB) + 4 * i;
+            const float4 lo = *reinterpret_cast<const float4*>(gp);
+            const float4 hi = *reinterpret_cast<const float4*>(gp + 4);
+            const float4 xv = *reinterpret_cast<const float4*>(xp - 4 * i);
             const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
-            bq += 4;
-            xp -= 4;
-            --jr;
-        };
-        float4 t1;
-        int i = 0;
-        for (; i + 2 <= seglen; i += 2) {                // two steps per trip: t0/t1 swap roles, no copies
-            step(t0, t1);
-            step(t1, t0);
         }
-        if (i < seglen) step(t0, t1);
         // meet the four segments of each output block
         *reinterpret_cast<float4*>(red + (sg * 16 + a) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -421,7 +411,7 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     const bool tiled = (U % 4 == 0) && (N % 4 == 0) && ((uintptr_t)audio % 16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && frames_max <= FIR_MAX_FRAMES &&
                        frames_max * nb * 4 <= FIR_G_FLOATS && (FIR_BW / 4 + 16 + 4 * seglen + 2) * 4 <= FIR_X_FLOATS &&
-                       nb * 4 <= 320 &&
+                       nb * 4 <= 320 && seglen <= U / 4 &&
                        !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
         const int wpr = (N + FIR_BW - 1) / FIR_BW;
