@@ -282,6 +282,15 @@ def main():
         d1 = time_steps(lambda: pg1(f1), 20, 3)
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
+    if rank == 0 and not args.no_single_stream:
+        # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
+        Tw = 34000
+        fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
+        pgw = build_group(dp, P, sr)
+        dw = time_steps(lambda: pgw(fw), 5, 2)
+        extra['whole_file'] = {'workload': f'B=1 x {Tw / 250:g} s in one segment, poly={P}, 2 s IR',
+                               'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
+        del fw, pgw
     roof = None
     if rank == 0 and not args.no_roofline:
         del feats

@@ -222,7 +222,10 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 
     // materialised source: ring of register buffers, NBUF - 1 blocks (8 KB each at H = 128) are in
     // flight per wavefront while one is being consumed.
-    constexpr int NBUF = FUSED ? 1 : (VPL <= 2 ? 4 : (VPL <= 4 ? 2 : 1));
+#ifndef DDSPP_NBUF
+#define DDSPP_NBUF 4
+#endif
+    constexpr int NBUF = FUSED ? 1 : (VPL <= 2 ? DDSPP_NBUF : (VPL <= 4 ? 2 : 1));
     float fbuf[NBUF][BLK][VPL], abuf[NBUF][BLK][VPL];
     auto load_block = [&](int n0, float (*fb)[VPL], float (*ab)[VPL]) {
 #pragma unroll

@@ -115,3 +115,26 @@ def test_standalone_processors_like_synthesize_from_csv():
     nz = noise.get_signal(**noise.get_controls(c['magnitudes']))
     assert sig.shape == nz.shape == (1, 30 * 96)
     assert pg.processors[0].sample_rate == 24000        # piano_model.py:70-72
+
+
+def test_long_segment_whole_file_mode():
+    """synthesize_midi_file.py feeds the WHOLE file as one segment: many chunks of the
+    angular cumsum (long float32 offset sums), many FIR frames, a multi-million point reverb FFT."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(77)
+    B, P, T, H, K, S, sr, L = 1, 2, 2600, 64, 32, 1, 16000, 16000
+    N = T * (sr // 250)                        # 166 400 samples = 167 chunks of 1000
+    feats = _features(rng, B, P, T, H, K, S, L)
+    for i in range(P):                         # a pitch change mid-file: frequencies move between frames
+        f0 = feats[f'f0_hz_{i}']
+        f0[:, T // 3:] *= np.float32(2 ** (3 / 12))
+        f0[:, 2 * T // 3:] *= np.float32(2 ** (-5 / 12))
+    noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
+    odag, _ = _build(O, P, sr)
+    ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': z} for z in noises]})
+    gdag, gnoise = _build(dp, P, sr)
+    gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
+    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}).cpu().numpy()
+    assert got.shape == ref.shape == (B, N)
+    err = rms_err(got, ref)
+    assert err < TOL * max(1.0, rms(ref)), f'{err:.3e} vs rms {rms(ref):.3e}'
