@@ -8,7 +8,8 @@ rebuilt here.
 """
 from . import core  # noqa: F401
 from .core import exp_sigmoid, exp_tanh  # noqa: F401
-from .effects import FeedbackDelayNetworkApply, Reverb  # noqa: F401
+from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  # noqa: F401
+                      fdn_impulse_response)
 from .polyphonic_dag import polyphonic_dag  # noqa: F401
 from .processors import Add, Processor, ProcessorGroup  # noqa: F401
 from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiAdd,  # noqa: F401
@@ -16,4 +17,4 @@ from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiA
 
 __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
            'MultiInharmonic', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
-           'FeedbackDelayNetworkApply', 'polyphonic_dag']
+           'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag']

@@ -17,7 +17,7 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip', 'reverb.hip']
+SOURCES = ['error.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip', 'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
 
 DDSPP_OK = 0
@@ -109,6 +109,12 @@ SIGNATURES = {
     'ddspp_fftconv_fft_size': (c_int, [c_void_p]),
     'ddspp_fftconv_execute': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_fdn_transfer': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'ddspp_fdn_add_early': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ddspp_irfft_plan_create': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'ddspp_irfft_plan_destroy': (c_int, [c_void_p]),
+    'ddspp_irfft_workspace_bytes': (c_size_t, [c_void_p]),
+    'ddspp_irfft_execute': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

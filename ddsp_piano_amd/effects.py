@@ -50,6 +50,118 @@ class Reverb(Processor):
         return core._fft_convolve_single(audio, ir, 'same', 0, mask_dry=True, add_dry=self._add_dry)
 
 
+FDN_DELAY_VALUES = (233., 311., 421., 461., 587., 613., 789., 891.)                      # fdn_reverb.py:96
+FDN_DELAYS_ALLPASS = ((131., 151., 337., 353.), (103., 173., 331., 373.), (89., 181., 307., 401.),
+                      (79., 197., 281., 419.), (61., 211., 257., 431.), (47., 229., 251., 443.),
+                      (81., 189., 287., 407.), (91., 203., 321., 377.))                  # fdn_reverb.py:102-113
+
+_irfft_plans = {}
+
+
+def _irfft(spectrum, n):
+    """tf.signal.irfft for [B, n/2+1] complex64 -> [B, n] float32 (rocFFT C2R; the spectrum buffer is consumed)."""
+    import atexit
+    import ctypes
+    from . import _lib
+    from .core import _lib_, _ptr, _stream
+    b = spectrum.shape[0]
+    key = (n, b, str(spectrum.device))
+    plan = _irfft_plans.get(key)
+    if plan is None:
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(spectrum.device):
+            _lib.check(_lib_().ddspp_irfft_plan_create(n, b, ctypes.byref(handle)))
+        plan = _irfft_plans[key] = handle
+        if len(_irfft_plans) == 1:
+            atexit.register(lambda: [_lib_().ddspp_irfft_plan_destroy(h) for h in _irfft_plans.values()])
+    nbytes = int(_lib_().ddspp_irfft_workspace_bytes(plan))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=spectrum.device)
+    out = torch.empty((b, n), dtype=torch.float32, device=spectrum.device)
+    _lib.check(_lib_().ddspp_irfft_execute(plan, _ptr(spectrum), _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def fdn_impulse_response(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone,
+                         early_ir=None, delay_values=FDN_DELAY_VALUES, sampling_rate=16000.0, mixing_matrix=None):
+    """FeedbackDelayNetwork.get_ir for B instruments at once (fdn_reverb.py:178-360; the
+    tf.vectorized_map of MultiInstrumentFeedbackDelayReverb.call, sub_modules.py:431-446).
+
+    input_gain / output_gain [B, D]; gain_allpass / delays_allpass [B, D, A]; time_rev_0_sec, alpha_tone
+    [B] (or [B, 1]); early_ir [B, E] or None  ->  ir [B, 2 * sampling_rate].
+    """
+    from . import _lib
+    from .core import _lib_, _ptr, _stream
+    input_gain, output_gain = core.tf_float32(input_gain), core.tf_float32(output_gain)
+    gain_allpass, delays_allpass = core.tf_float32(gain_allpass), core.tf_float32(delays_allpass)
+    if input_gain.dim() != 2 or gain_allpass.dim() != 3:
+        raise ValueError('input_gain must be [batch, delay_lines] and gain_allpass [batch, delay_lines, stages]')
+    b, d = input_gain.shape
+    a = gain_allpass.shape[-1]
+    dev = input_gain.device
+    t0 = core.tf_float32(time_rev_0_sec, device=dev).reshape(b).contiguous()
+    al = core.tf_float32(alpha_tone, device=dev).reshape(b).contiguous()
+    dv = core.tf_float32(torch.as_tensor(delay_values, dtype=torch.float32), device=dev).contiguous()
+    if dv.numel() != d:
+        raise ValueError(f'{dv.numel()} delay values for {d} delay lines')
+    if mixing_matrix is None:
+        mixing_matrix = -1.0 * torch.eye(d) + 0.5 * torch.ones(d, d)                    # fdn_reverb.py:118-120
+    mix = core.tf_float32(mixing_matrix, device=dev)
+    freq_points = int(2 * float(sampling_rate))                                       # fdn_reverb.py:81
+    nb = freq_points // 2 + 1
+    spec = torch.empty((b, nb, 2), dtype=torch.float32, device=dev)
+    _lib.check(_lib_().ddspp_fdn_transfer(_ptr(input_gain), _ptr(output_gain), _ptr(mix), _ptr(gain_allpass),
+                                          _ptr(delays_allpass), _ptr(t0), _ptr(al), _ptr(dv), _ptr(spec), b, d, a,
+                                          freq_points, float(sampling_rate), _stream()))
+    ir = _irfft(spec, freq_points)
+    if early_ir is not None:
+        early = core.tf_float32(early_ir, device=dev).reshape(b, -1).contiguous()
+        _lib.check(_lib_().ddspp_fdn_add_early(_ptr(ir), _ptr(early), b, freq_points, early.shape[1], _stream()))
+    return ir
+
+
+class FeedbackDelayNetwork(Processor):
+    """Frequency-sampled feedback delay network reverb, ddsp_piano/modules/fdn_reverb.py:20-410,
+    inference form (trainable=False: every parameter arrives through get_controls)."""
+
+    def __init__(self, trainable=False, name='DelayNetwork', sampling_rate=16000.0, delay_lines=8,
+                 delay_values=None, delays_allpass=None, early_ir_length=200, early_reflections=6,
+                 time_control_bands=6, delay_trainable=False):
+        if trainable:
+            raise NotImplementedError('trainable FeedbackDelayNetwork is out of scope (inference only)')
+        super().__init__(name=name, trainable=trainable)
+        self.sampling_rate = float(sampling_rate)
+        self.freq_points = int(2 * self.sampling_rate)
+        self.delay_values = tuple(delay_values) if delay_values is not None else FDN_DELAY_VALUES
+        self.delays_allpass = delays_allpass if delays_allpass is not None else FDN_DELAYS_ALLPASS
+        self.delay_lines = len(self.delay_values)
+        self.early_ir_length = early_ir_length
+
+    def __len__(self):
+        return self.delay_lines
+
+    def get_ir(self, input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir):
+        """fdn_reverb.py:336-360 (one instrument; returns [2 * sampling_rate])."""
+        def one(x, nd):
+            x = core.tf_float32(x)
+            return x.reshape((1,) + tuple(x.shape[-nd:])) if nd else x.reshape(1)
+        ir = fdn_impulse_response(one(input_gain, 1), one(output_gain, 1), one(gain_allpass, 2),
+                                  one(delays_allpass, 2), one(time_rev_0_sec, 0), one(alpha_tone, 0),
+                                  one(torch.as_tensor(early_ir).reshape(-1), 1), self.delay_values,
+                                  self.sampling_rate)
+        return ir[0]
+
+    def get_controls(self, audio_dry=None, input_gain=None, output_gain=None, gain_allpass=None,
+                     delays_allpass=None, time_rev_0_sec=None, alpha_tone=None, early_ir=None):
+        """fdn_reverb.py:362-405."""
+        ir = self.get_ir(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir)
+        return {'audio': audio_dry, 'ir': ir}
+
+    def get_signal(self, audio, ir):
+        """fdn_reverb.py:407-410."""
+        ir = core.tf_float32(ir)
+        return core.fft_convolve(audio, ir[None, :], delay_compensation=0)
+
+
 class FeedbackDelayNetworkApply(Processor):
     """The get_signal half of FeedbackDelayNetwork (fdn_reverb.py:407-410): the controls already
     carry a finished impulse response ``ir [L]``; no dry mask, no dry add."""

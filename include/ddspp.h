@@ -150,6 +150,27 @@ int ddspp_fftconv_execute(ddspp_fftconv_plan* plan, const float* audio, int audi
                           float* out, int out_len, int delay, int mask_dry, int add_dry, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
 
+/* ---- FDN reverb impulse-response generation ---------------------------------- */
+
+/* FeedbackDelayNetwork.get_late_ir up to the irfft -- fdn_reverb.py:178-334, B instruments at once
+ * (sub_modules.py:431-446).  gains [B,D], mixing_matrix [D,D], allpass gains/delays [B,D,A],
+ * time_rev_0_sec / alpha_tone [B], delay_values [D] -> H [B, freq_points/2+1] complex64. */
+int ddspp_fdn_transfer(const float* input_gain, const float* output_gain, const float* mixing_matrix,
+                       const float* gain_allpass, const float* delays_allpass, const float* time_rev_0_sec,
+                       const float* alpha_tone, const float* delay_values, void* H, int B, int D, int A,
+                       int freq_points, float sampling_rate, hipStream_t stream);
+
+/* FeedbackDelayNetwork.get_ir, fdn_reverb.py:354-360: ir[B,L] += zero-padded early_ir[B,E]. */
+int ddspp_fdn_add_early(float* ir, const float* early_ir, int B, int L, int E, hipStream_t stream);
+
+/* tf.signal.irfft of any even length n (rocFFT C2R, 1/n scale), batch rows; the spectrum is destroyed. */
+typedef struct C2rPlan ddspp_irfft_plan;
+int ddspp_irfft_plan_create(int n, int batch, ddspp_irfft_plan** out_plan);
+int ddspp_irfft_plan_destroy(ddspp_irfft_plan* plan);
+size_t ddspp_irfft_workspace_bytes(const ddspp_irfft_plan* plan);
+int ddspp_irfft_execute(ddspp_irfft_plan* plan, void* spectrum, float* signal, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -650,3 +650,88 @@ def polyphonic_dag(additive, noise, reverb=None,
 def midi_to_hz(notes):
     """ddsp.core.midi_to_hz."""
     return 440.0 * (2.0 ** ((np.asarray(notes, np.float64) - 69.0) / 12.0))
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY.md 8f-1 ("next" row): FDN impulse-response generation, fdn_reverb.py:178-360
+# (complex64 restatement; used by FeedbackDelayNetwork.get_controls and by
+# MultiInstrumentFeedbackDelayReverb.call, sub_modules.py:431-446)
+# ----------------------------------------------------------------------------------------------
+C64 = np.complex64
+FDN_DELAY_VALUES = np.asarray([233, 311, 421, 461, 587, 613, 789, 891], F32)            # fdn_reverb.py:96
+FDN_DELAYS_ALLPASS = np.asarray([[131, 151, 337, 353], [103, 173, 331, 373], [89, 181, 307, 401],
+                                 [79, 197, 281, 419], [61, 211, 257, 431], [47, 229, 251, 443],
+                                 [81, 189, 287, 407], [91, 203, 321, 377]], F32)         # fdn_reverb.py:102-113
+
+
+def fdn_mixing_matrix(delay_lines):
+    """fdn_reverb.py:118-120: Householder-style mixing matrix -I + 0.5 * ones."""
+    return (-1.0 * np.eye(delay_lines, dtype=F32) + F32(0.5) * np.ones([delay_lines, delay_lines], F32)).astype(F32)
+
+
+def fdn_get_late_ir(input_gain, output_gain, mixing_matrix, gain_allpass, delays_allpass, time_rev_0_sec,
+                    alpha_tone, delay_values=FDN_DELAY_VALUES, sampling_rate=16000.0, exact_solve=False):
+    """FeedbackDelayNetwork.get_late_ir, fdn_reverb.py:178-334, one instrument.
+
+    exact_solve=False follows the reference: the 8x8 systems are inverted in complex64, which is only
+    good to cond(I - F D) x 6e-8 near the network's resonances.  exact_solve=True keeps every float32 /
+    complex64 quantity the reference forms (frequencies, delays, filter and all-pass transfers) but
+    assembles, inverts and projects in complex128 -- the value both implementations approximate.
+    """
+    sr = F32(sampling_rate)
+    freq_points = int(2 * sr)                                            # :81
+    nb = freq_points // 2 + 1
+    delay_values = tf_float32(delay_values)
+    n_lines = delay_values.shape[0]
+    input_gain = tf_float32(input_gain).astype(C64)
+    output_gain = tf_float32(output_gain).astype(C64)
+    mixing = tf_float32(mixing_matrix).astype(C64)
+    wk = ((F32(2 * np.pi) * np.arange(nb, dtype=F32)).astype(F32) / F32(freq_points)).astype(F32).astype(C64)  # :234-239
+    mj = C64(-1j)
+    z_d = np.stack([np.exp((mj * wk).astype(C64) * C64(np.floor(delay_values[d]))).astype(C64)
+                    for d in range(n_lines)], axis=1)                     # :241-250
+    d_eta = (delay_values - np.floor(delay_values)).astype(F32).astype(C64)
+    eta = ((C64(1) - d_eta) / (C64(1) + d_eta)).astype(C64)               # :253-254
+    ez = np.exp((mj * wk).astype(C64)).astype(C64)
+    allpass_interp = np.stack([((eta[d] + ez) / (C64(1) + eta[d] * ez)).astype(C64) for d in range(n_lines)],
+                              axis=1)                                     # :255-261
+    dd = (z_d * allpass_interp).astype(C64)                               # diagonal of diag_delay_matrix :263
+    delays_allpass = tf_float32(delays_allpass)
+    gain_allpass = tf_float32(gain_allpass)
+    delay_sec = ((delay_values + np.sum(delays_allpass, axis=-1, dtype=F32)).astype(F32) / sr).astype(F32)   # :265-268
+    t0 = F32(time_rev_0_sec)
+    al = F32(alpha_tone)
+    k = np.power(F32(10.0), (F32(-3) * delay_sec / t0).astype(F32)).astype(F32)                 # :272
+    kpi = np.power(F32(10.0), (F32(-3) * delay_sec / (al * t0)).astype(F32)).astype(F32)        # :274-277
+    g = (F32(2) * k * kpi / (k + kpi)).astype(F32)
+    p = ((k - kpi) / (k + kpi)).astype(F32)
+    filt = (g.astype(C64)[None, :] / (C64(1) - p.astype(C64)[None, :] * ez[:, None] + C64(1e-8))).astype(C64)  # :289-291
+    z_delays = np.exp((C64(1j) * wk[:, None, None]).astype(C64) * delays_allpass.astype(C64)[None]).astype(C64)  # :302
+    ga = gain_allpass.astype(C64)[None]
+    allpass_transfer = np.prod(((C64(1) + ga * z_delays) / (ga + z_delays)).astype(C64), axis=-1).astype(C64)  # :305-308
+    feedback = (filt[:, :, None] * mixing[None, :, :] * allpass_transfer[:, None, :]).astype(C64)               # :314-316
+    if exact_solve:
+        c128 = np.complex128
+        fb = filt.astype(c128)[:, :, None] * mixing.astype(c128)[None] * allpass_transfer.astype(c128)[:, None, :]
+        a = np.eye(n_lines, dtype=c128)[None] - fb * dd.astype(c128)[:, None, :]
+        x = np.linalg.solve(a, np.broadcast_to(input_gain.astype(c128)[None, :, None], (nb, n_lines, 1)))[..., 0]
+        h = np.sum(output_gain.astype(c128)[None] * dd.astype(c128) * x, axis=1).astype(C64)
+        return np.fft.irfft(h.astype(np.complex128)).astype(F32)
+    eye = np.eye(n_lines, dtype=C64)[None]
+    a = (eye - feedback * dd[:, None, :]).astype(C64)                     # I - F @ diag(dd)
+    inv = np.linalg.inv(a).astype(C64)
+    m = (dd[:, :, None] * inv).astype(C64)                                # diag(dd) @ inv
+    h = np.einsum('i,nij,j->n', output_gain, m, input_gain).astype(C64)   # :323-333
+    return np.fft.irfft(h.astype(np.complex128)).astype(F32)
+
+
+def fdn_get_ir(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir,
+               delay_values=FDN_DELAY_VALUES, sampling_rate=16000.0, exact_solve=False):
+    """FeedbackDelayNetwork.get_ir, fdn_reverb.py:336-360."""
+    n_lines = tf_float32(delay_values).shape[0]
+    late = fdn_get_late_ir(input_gain, output_gain, fdn_mixing_matrix(n_lines), gain_allpass, delays_allpass,
+                           time_rev_0_sec, alpha_tone, delay_values, sampling_rate, exact_solve)
+    early = np.squeeze(tf_float32(early_ir))
+    if late.shape[0] > early.shape[0]:
+        early = np.pad(early, [[0, late.shape[0] - early.shape[0]]])
+    return (early[:late.shape[0]] + late).astype(F32)
