@@ -264,11 +264,10 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         float fe[BLK][VPL], ae[BLK][VPL];
         if (FUSED) {
             // per-sample scalar weights (wave-uniform -> scalar loads)
-            float wl[BLK], w0[BLK], w1[BLK];
+            float wl[BLK], w1[BLK];
 #pragma unroll
             for (int i = 0; i < BLK; ++i) {
                 if (!CFREQ) wl[i] = wlin_c[n0 + i];
-                w0[i] = whann_c[U + r + i];
                 w1[i] = whann_c[r + i];
             }
 #pragma unroll
@@ -277,9 +276,10 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) {
                     if (!CFREQ) fe[i][j] = x0[j] + dx * wl[i];        // legacy bilinear (core.resample)
-                    // Hann overlap-add of frames t and t+1 (core.upsample_with_windows); the second
-                    // product is fused: <= 1 ulp on an amplitude, never on a phase.
-                    if (MODE != MODE_PREPASS && act[j]) ae[i][j] = __builtin_fmaf(a1[j], w1[i], a0[j] * w0[i]);
+                    // Hann overlap-add of frames t and t+1 (core.upsample_with_windows):
+                    // a0 w[U + r] + a1 w[r] with w[U + r] + w[r] = 1 (to 1 ulp) is the cross-fade
+                    // a0 + (a1 - a0) w[r]; <= 2 ulp on an amplitude, never on a phase.
+                    if (MODE != MODE_PREPASS && act[j]) ae[i][j] = __builtin_fmaf(a1[j] - a0[j], w1[i], a0[j]);
                 }
             }
         } else {
