@@ -13,8 +13,8 @@ from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  
 from .polyphonic_dag import polyphonic_dag  # noqa: F401
 from .processors import Add, Processor, ProcessorGroup  # noqa: F401
 from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiAdd,  # noqa: F401
-                     MultiInharmonic)
+                     MultiInharmonic, SurrogateAdditive)
 
 __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
-           'MultiInharmonic', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
+           'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
            'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag']

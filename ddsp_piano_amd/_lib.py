@@ -82,6 +82,7 @@ SIGNATURES = {
     'ddspp_resample_linear': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     'ddspp_resample_window': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_decay_envelope': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_osc_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'ddspp_cos_oscillator_bank': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                           c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

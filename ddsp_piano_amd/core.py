@@ -497,6 +497,37 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_d
                                sum_sinusoids=sum_sinusoids, use_angular_cumsum=use_angular_cumsum)
 
 
+def surrogate_harmonic_synthesis(frequencies, amplitudes, decays=None, decay_time=None, harmonic_shifts=None,
+                                 harmonic_distribution=None, upsampling=64, sample_rate=16000,
+                                 amp_resample_method='window', use_angular_cumsum=False):
+    """ddsp_piano/modules/surrogate_synth.py:11-104: the oscillator bank with a
+    per-harmonic exponential decay on the amplitude envelopes."""
+    frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
+    b, t, _ = frequencies.shape
+    n_samples = int(upsampling) * t
+    if harmonic_distribution is not None:
+        harmonic_distribution = tf_float32(harmonic_distribution)
+        n_harmonics = int(harmonic_distribution.shape[-1])
+    elif harmonic_shifts is not None:
+        n_harmonics = int(tf_float32(harmonic_shifts).shape[-1])
+    else:
+        n_harmonics = 1
+    harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)
+    if harmonic_shifts is not None:
+        harmonic_frequencies = harmonic_frequencies * (1.0 + tf_float32(harmonic_shifts))
+    harmonic_amplitudes = amplitudes * harmonic_distribution if harmonic_distribution is not None else amplitudes
+    frequency_envelopes = resample(harmonic_frequencies, n_samples)
+    amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method)
+    if decays is not None and decay_time is not None:
+        decays = tf_float32(decays).expand(b, t, n_harmonics).contiguous()
+        decay_time = tf_float32(decay_time).reshape(b, t).contiguous()
+        amplitude_envelopes = amplitude_envelopes.expand(b, n_samples, n_harmonics).contiguous()
+        _lib.check(_lib_().ddspp_decay_envelope(_ptr(amplitude_envelopes), _ptr(decays), _ptr(decay_time), b, t,
+                                                n_harmonics, int(upsampling), _stream()))
+    return cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=sample_rate,
+                               use_angular_cumsum=use_angular_cumsum)
+
+
 # ----------------------------------------------------------------------------------------------------
 # FilteredNoise: impulse responses and the time-varying FIR
 # ----------------------------------------------------------------------------------------------------

@@ -79,6 +79,24 @@ __global__ void __launch_bounds__(256) resample_window_kernel(const float* __res
     }
 }
 
+// amplitude_envelopes[r, n, c] *= |decays[r, t, c]| ** (decay_time[r, t] * U + n % U),  t = n / U
+// (surrogate_synth.py:76-95: tf.repeat of the frame values, sample counter added, tf.math.pow)
+__global__ void __launch_bounds__(256) decay_envelope_kernel(float* __restrict__ env,
+                                                           const float* __restrict__ decays,
+                                                           const float* __restrict__ decay_time, int R, int T,
+                                                           int C, int U) {
+    const int N = T * U;
+    const size_t total = (size_t)R * N * C;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int c = (int)(g % C);
+        const size_t rn = g / C;
+        const int n = (int)(rn % N), r = (int)(rn / N);
+        const int t = n / U, j = n - t * U;
+        const float tt = decay_time[(size_t)r * T + t] * (float)U + (float)j;
+        env[g] = env[g] * powf(fabsf(decays[((size_t)r * T + t) * C + c]), tt);
+    }
+}
+
 static unsigned stream_grid(size_t total) {
     size_t blocks = (total + 255) / 256;
     const size_t cap = 256 * 16;     // 256 CUs x 16 blocks, grid-stride beyond that
@@ -124,6 +142,19 @@ int ddspp_resample_window(const float* x, const float* window, float* y, int R, 
     else
         hipLaunchKernelGGL(resample_window_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, stream, x,
                            window, y, R, T, C, U);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// surrogate_harmonic_synthesis' decay envelope (surrogate_synth.py:76-95), applied in place to the
+// sample-rate amplitude envelopes [R, T*U, C]; decays [R, T, C], decay_time [R, T].
+int ddspp_decay_envelope(float* amplitude_envelopes, const float* decays, const float* decay_time, int R, int T,
+                         int C, int U, hipStream_t stream) {
+    DDSPP_REQUIRE(amplitude_envelopes && decays && decay_time, "decay_envelope: null buffer");
+    DDSPP_REQUIRE(R > 0 && T > 0 && C > 0 && U > 0, "decay_envelope: bad dims");
+    const size_t total = (size_t)R * T * U * C;
+    hipLaunchKernelGGL(decay_envelope_kernel, dim3(stream_grid(total)), dim3(256), 0, stream, amplitude_envelopes,
+                       decays, decay_time, R, T, C, U);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -111,6 +111,50 @@ class MultiInharmonic(InHarmonic):
         return self._synthesize(amplitudes, harmonic_distribution, harmonic_shifts, f0_hz)  # :272-293
 
 
+class SurrogateAdditive(Processor):
+    """ddsp_piano/modules/surrogate_synth.py:107-214 (only configs/surrogate.gin uses it): the inharmonic
+    bank with per-harmonic decaying amplitudes.  get_controls is composed from the library's scale /
+    mask primitives, get_signal runs resample -> decay envelope -> cos_oscillator_bank kernels."""
+
+    def __init__(self, frame_rate=250, sample_rate=16000, min_frequency=20, normalize_harm_distribution=True,
+                 scale_fn=core.exp_sigmoid, normalize_below_nyquist=True, inference=False, name='inharmonic'):
+        super().__init__(name=name)
+        self.frame_rate, self.sample_rate, self.min_frequency = frame_rate, sample_rate, min_frequency
+        self.normalize_harm_distribution = normalize_harm_distribution
+        self.scale_fn = scale_fn
+        self.normalize_below_nyquist = normalize_below_nyquist
+        self.inference = inference
+
+    def get_controls(self, amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz):
+        amplitudes, harmonic_distribution = core.tf_float32(amplitudes), core.tf_float32(harmonic_distribution)
+        f0_hz = core.tf_float32(f0_hz)
+        if self.scale_fn is not None:                                                   # :152-154
+            amplitudes = core.tf_float32(self.scale_fn(amplitudes))
+            harmonic_distribution = core.tf_float32(self.scale_fn(harmonic_distribution))
+        inharm_coef = torch.clamp(core.tf_float32(inharm_coef), min=0.0)                 # :157
+        n_harmonics = int(harmonic_distribution.shape[-1])
+        inharmonic_freq, harmonic_shifts = core.get_inharmonic_freq(f0_hz, inharm_coef, n_harmonics)
+        if decays is not None:                                                          # :163-171
+            decays = torch.clamp(core.tf_float32(decays), min=1e-5, max=1.0)
+            decays = torch.where(inharmonic_freq >= self.sample_rate / 2.0, torch.ones_like(decays), decays)
+        if self.normalize_below_nyquist:                                                # :172-181
+            harmonic_distribution = core.remove_above_nyquist(inharmonic_freq, harmonic_distribution,
+                                                              self.sample_rate)
+            amplitudes = amplitudes * (f0_hz > self.min_frequency).to(torch.float32)
+        if self.normalize_harm_distribution:                                            # :183-187
+            harmonic_distribution = core.safe_divide(harmonic_distribution,
+                                                     harmonic_distribution.sum(dim=-1, keepdim=True))
+        return {'amplitudes': amplitudes, 'decays': decays, 'decay_time': decay_time,
+                'harmonic_distribution': harmonic_distribution, 'harmonic_shifts': harmonic_shifts, 'f0_hz': f0_hz}
+
+    def get_signal(self, amplitudes, decays, decay_time, harmonic_distribution, harmonic_shifts, f0_hz):
+        return core.surrogate_harmonic_synthesis(
+            frequencies=f0_hz, amplitudes=amplitudes, decays=decays, decay_time=decay_time,
+            harmonic_shifts=harmonic_shifts, harmonic_distribution=harmonic_distribution,
+            upsampling=int(self.sample_rate / self.frame_rate), sample_rate=self.sample_rate,
+            use_angular_cumsum=self.inference)
+
+
 class MultiAdd(Processor):
     """Sum arbitrary number of signals -- inharm_synth.py:296-309."""
 

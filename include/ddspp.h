@@ -56,6 +56,11 @@ int ddspp_resample_linear(const float* x, const int* lo, const int* hi, const fl
 int ddspp_resample_window(const float* x, const float* window, float* y, int R, int T, int C, int U,
                           hipStream_t stream);
 
+/* surrogate_harmonic_synthesis' decay envelope (ddsp_piano/modules/surrogate_synth.py:76-95), in place:
+ * amplitude_envelopes[R,T*U,C] *= |decays[R,T,C]| ** (decay_time[R,T] * U + n % U). */
+int ddspp_decay_envelope(float* amplitude_envelopes, const float* decays, const float* decay_time, int R, int T,
+                         int C, int U, hipStream_t stream);
+
 /* ---- oscillator bank ------------------------------------------------------------------------- */
 
 size_t ddspp_osc_workspace_bytes(int R, int N, int V);

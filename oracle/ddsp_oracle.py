@@ -735,3 +735,80 @@ def fdn_get_ir(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0
     if late.shape[0] > early.shape[0]:
         early = np.pad(early, [[0, late.shape[0] - early.shape[0]]])
     return (early[:late.shape[0]] + late).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY.md 8f-3 ("next" row): SurrogateAdditive, ddsp_piano/modules/surrogate_synth.py
+# ----------------------------------------------------------------------------------------------
+def surrogate_harmonic_synthesis(frequencies, amplitudes, decays=None, decay_time=None, harmonic_shifts=None,
+                                 harmonic_distribution=None, upsampling=64, sample_rate=16000,
+                                 amp_resample_method='window', use_angular_cumsum=False):
+    """surrogate_synth.py:11-104."""
+    frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
+    n_frames = int(frequencies.shape[1])
+    n_samples = upsampling * n_frames
+    if harmonic_distribution is not None:
+        harmonic_distribution = tf_float32(harmonic_distribution)
+        n_harmonics = int(harmonic_distribution.shape[-1])
+    elif harmonic_shifts is not None:
+        n_harmonics = int(tf_float32(harmonic_shifts).shape[-1])
+    else:
+        n_harmonics = 1
+    harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)            # :59-60
+    if harmonic_shifts is not None:
+        harmonic_frequencies = (harmonic_frequencies * (F32(1.0) + tf_float32(harmonic_shifts)).astype(F32)).astype(F32)
+    harmonic_amplitudes = (amplitudes * harmonic_distribution).astype(F32) if harmonic_distribution is not None \
+        else amplitudes                                                                  # :65-68
+    frequency_envelopes = resample(harmonic_frequencies, n_samples)                       # :71
+    amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method)   # :72-73
+    if decays is not None and decay_time is not None:
+        decays, decay_time = tf_float32(decays), tf_float32(decay_time)
+        decay_env = np.repeat(decays, upsampling, axis=1)                                 # :82
+        t_up = (np.repeat(decay_time, upsampling, axis=1) * F32(upsampling)).astype(F32)  # :83-84
+        rng = np.tile(np.arange(upsampling, dtype=F32), n_frames)[None, :, None]          # :86-89
+        t_up = (t_up + rng).astype(F32)
+        decay_env = np.power(np.abs(decay_env), t_up, dtype=F32)                          # :91-92
+        amplitude_envelopes = (amplitude_envelopes * decay_env).astype(F32)               # :95
+    return cos_oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=sample_rate,
+                               use_angular_cumsum=use_angular_cumsum)
+
+
+class SurrogateAdditive(Processor):
+    """surrogate_synth.py:107-214."""
+
+    def __init__(self, frame_rate=250, sample_rate=16000, min_frequency=20, normalize_harm_distribution=True,
+                 scale_fn=exp_sigmoid, normalize_below_nyquist=True, inference=False, name='inharmonic'):
+        super().__init__(name=name)
+        self.frame_rate, self.sample_rate, self.min_frequency = frame_rate, sample_rate, min_frequency
+        self.normalize_harm_distribution = normalize_harm_distribution
+        self.scale_fn = scale_fn
+        self.normalize_below_nyquist = normalize_below_nyquist
+        self.inference = inference
+
+    def get_controls(self, amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz):
+        amplitudes, harmonic_distribution = tf_float32(amplitudes), tf_float32(harmonic_distribution)
+        f0_hz = tf_float32(f0_hz)
+        if self.scale_fn is not None:
+            amplitudes = self.scale_fn(amplitudes)
+            harmonic_distribution = self.scale_fn(harmonic_distribution)
+        inharm_coef = np.maximum(tf_float32(inharm_coef), F32(0.0))
+        n_harmonics = int(harmonic_distribution.shape[-1])
+        inharmonic_freq, harmonic_shifts = get_inharmonic_freq(f0_hz, inharm_coef, n_harmonics)
+        if decays is not None:
+            decays = np.maximum(np.minimum(tf_float32(decays), F32(1.0)), F32(1e-5))      # :164-165
+            decays = np.where(inharmonic_freq >= F32(self.sample_rate / 2.0), F32(1.0), decays).astype(F32)
+        if self.normalize_below_nyquist:
+            harmonic_distribution = remove_above_nyquist(inharmonic_freq, harmonic_distribution, self.sample_rate)
+            amplitudes = (amplitudes * (f0_hz > F32(self.min_frequency)).astype(F32)).astype(F32)
+        if self.normalize_harm_distribution:
+            harmonic_distribution = safe_divide(harmonic_distribution,
+                                                np.sum(harmonic_distribution, axis=-1, keepdims=True, dtype=F32))
+        return {'amplitudes': amplitudes, 'decays': decays, 'decay_time': decay_time,
+                'harmonic_distribution': harmonic_distribution, 'harmonic_shifts': harmonic_shifts, 'f0_hz': f0_hz}
+
+    def get_signal(self, amplitudes, decays, decay_time, harmonic_distribution, harmonic_shifts, f0_hz):
+        return surrogate_harmonic_synthesis(frequencies=f0_hz, amplitudes=amplitudes, decays=decays,
+                                            decay_time=decay_time, harmonic_shifts=harmonic_shifts,
+                                            harmonic_distribution=harmonic_distribution,
+                                            upsampling=int(self.sample_rate / self.frame_rate),
+                                            sample_rate=self.sample_rate, use_angular_cumsum=self.inference)

@@ -200,3 +200,24 @@ def test_custom_python_scale_fn():
         **{k: _dev(v) for k, v in raw.items()})
     np.testing.assert_allclose(got['harmonic_distribution'].cpu().numpy(), ref['harmonic_distribution'],
                                rtol=2e-5, atol=1e-9)
+
+
+def test_surrogate_additive_matches_oracle():
+    """SurrogateAdditive (configs/surrogate.gin): decaying-amplitude oscillator bank."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(17)
+    B, T, H, sr = 2, 40, 96, 16000
+    raw = synth_controls(rng, B, T, H, silent_frac=0.0)
+    decays = rng.uniform(0.9990, 1.0002, [B, T, H]).astype(np.float32)
+    decay_time = np.tile((np.arange(T, dtype=np.float32) % 20)[None, :, None], [B, 1, 1])
+    o = O.SurrogateAdditive(sample_rate=sr, scale_fn=O.exp_tanh, normalize_harm_distribution=False, inference=True)
+    g = dp.SurrogateAdditive(sample_rate=sr, scale_fn=dp.exp_tanh, normalize_harm_distribution=False, inference=True)
+    octl = o.get_controls(raw['amplitudes'], decays, decay_time, raw['harmonic_distribution'], raw['inharm_coef'], raw['f0_hz'])
+    gctl = g.get_controls(_dev(raw['amplitudes']), _dev(decays), _dev(decay_time), _dev(raw['harmonic_distribution']),
+                          _dev(raw['inharm_coef']), _dev(raw['f0_hz']))
+    for k in ('amplitudes', 'decays', 'harmonic_distribution', 'harmonic_shifts'):
+        np.testing.assert_allclose(gctl[k].cpu().numpy(), octl[k], rtol=2e-5, atol=1e-9)
+    ref = o.get_signal(**octl)
+    got = g.get_signal(**{k: _dev(v) for k, v in octl.items()}).cpu().numpy()
+    assert got.shape == ref.shape == (B, T * 64)
+    assert rms_err(got, ref) < TOL * max(1.0, rms(ref))
