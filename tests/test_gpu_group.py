@@ -209,3 +209,22 @@ def test_config5_shape_48k_poly32_long_ir():
     orig = b.noise.get_signal
     b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
     assert (a(feats) - b(feats)).abs().max().item() < 5e-6
+
+
+def test_monophonic_group_and_config1_dry():
+    """BASELINE config 1 wiring: poly = 1, no reverb (dry) -- the smallest polyphonic DAG."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(2)
+    B, P, T, H, K, S, sr = 1, 1, 250, 64, 64, 1, 24000
+    feats = _features(rng, B, P, T, H, K, S, 100)
+    noise = rng.uniform(-1, 1, [B, T * 96]).astype(np.float32)
+    odag, _ = _build(O, P, sr, with_reverb=False)
+    ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': noise}]})
+    for fast in (True, False):
+        gdag, gnoise = _build(dp, P, sr, with_reverb=False)
+        gnoise.noise_override = [torch.as_tensor(noise, device='cuda')]
+        if not fast:
+            orig = gnoise.get_signal
+            gnoise.get_signal = lambda magnitudes, _o=orig, _n=gnoise: _o(magnitudes, noise=_n.noise_override.pop(0))
+        got = dp.ProcessorGroup(gdag, fast_path=fast)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()})
+        assert got.shape == (B, 24000) and rms_err(got.cpu().numpy(), ref) < TOL

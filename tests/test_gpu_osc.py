@@ -221,3 +221,33 @@ def test_surrogate_additive_matches_oracle():
     got = g.get_signal(**{k: _dev(v) for k, v in octl.items()}).cpu().numpy()
     assert got.shape == ref.shape == (B, T * 64)
     assert rms_err(got, ref) < TOL * max(1.0, rms(ref))
+
+
+@pytest.mark.parametrize('B,T,H,S,sr,fr', [
+    (2, 30, 64, 1, 16000, 160),     # U = 100: not a multiple of 8 -> resample + cos_oscillator_bank route
+    (1, 1, 32, 1, 16000, 250),      # a single control frame
+    (3, 7, 1, 1, 8000, 250),        # a single harmonic
+    (1, 25, 130, 1, 24000, 250),    # H not a multiple of 64 nor of a vector width (VPL = 3, strided lanes)
+    (2, 25, 200, 2, 24000, 250),    # S * H = 400 virtual oscillators (VPL = 8)
+])
+def test_get_signal_edge_shapes(B, T, H, S, sr, fr):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(B * 1000 + T + H)
+    raw = synth_controls(rng, B, T, H, S=S, silent_frac=0.0, midi_lo=40, midi_hi=70)
+    o = O.MultiInharmonic(frame_rate=fr, sample_rate=sr, inference=True)
+    g = dp.MultiInharmonic(frame_rate=fr, sample_rate=sr, inference=True)
+    ctl = o.get_controls(raw['amplitudes'], raw['harmonic_distribution'], raw['inharm_coef'], raw['f0_hz'])
+    ref = o.get_signal(**ctl)
+    got = g.get_signal(**{k: _dev(v) for k, v in ctl.items()}).cpu().numpy()
+    assert got.shape == ref.shape == (B, T * int(sr / fr))
+    assert rms_err(got, ref) < TOL * max(1.0, rms(ref)), rms_err(got, ref)
+
+
+def test_materialised_bank_with_many_sinusoids_and_groups():
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(123)
+    for H, spans in [(256, 1), (320, 2), (66, 1), (5, 3)]:
+        fe, ae = _envelopes(rng, 2, 3000, H, 48000)
+        ref = O.cos_oscillator_bank(fe, ae, 48000, use_angular_cumsum=True)
+        got = core.cos_oscillator_bank(_dev(fe), _dev(ae), 48000, use_angular_cumsum=True, spans=spans).cpu().numpy()
+        assert rms_err(got, ref) < TOL, (H, spans, rms_err(got, ref))
