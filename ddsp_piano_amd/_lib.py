@@ -89,6 +89,8 @@ SIGNATURES = {
     'ddspp_harmonic_synthesis': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
+    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                           c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
@@ -96,6 +98,7 @@ SIGNATURES = {
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                           c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes_eo': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -456,6 +456,31 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
     return out
 
 
+def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
+                        sample_rate, spans=0):
+    """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N].
+
+    The per-voice stems are never formed; lanes go only to oscillators that are audible somewhere in a
+    span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only."""
+    r, t, s = f0_hz.shape
+    h = harmonic_distribution.shape[-1]
+    b = int(n_segments)
+    p = r // b
+    u = n_samples // t
+    dev = f0_hz.device
+    _, _, wlin, _ = linear_tables(t, n_samples, dev)
+    whann = hann_window(2 * u, dev)
+    lib = _lib_()
+    nbytes = int(lib.ddspp_polyphonic_additive_workspace_bytes(b, p, t, s, h, u))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((b, n_samples), dtype=torch.float32, device=dev)
+    _lib.check(lib.ddspp_polyphonic_additive(
+        _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
+        _ptr(harmonic_shifts) if harmonic_shifts is not None else ctypes.c_void_p(0), _ptr(wlin), _ptr(whann),
+        _ptr(out), b, p, t, s, h, u, float(sample_rate), int(spans), _ptr(ws), nbytes, _stream()))
+    return out
+
+
 def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_distribution=None,
                        n_samples=64000, sample_rate=16000, amp_resample_method='window', sum_sinusoids=True,
                        use_angular_cumsum=False):

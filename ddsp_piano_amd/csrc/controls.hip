@@ -172,6 +172,28 @@ __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __rest
     }
 }
 
+// out[b, n] = sum_v a[b, v, n] (PA rows) + sum_v z[b, v, n] (PZ rows): the add chain when one operand is
+// already a per-segment mix
+__global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict__ a, int PA,
+                                                       const float* __restrict__ z, int PZ,
+                                                       float* __restrict__ out, int B, int N, int out_stride) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)B * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < PZ; ++v) {
+            const float4 t = reinterpret_cast<const float4*>(z)[((size_t)b * PZ + v) * n4 + i];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        for (int v = 0; v < PA; ++v) {
+            const float4 t = reinterpret_cast<const float4*>(a)[((size_t)b * PA + v) * n4 + i];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)b * out_stride)[i] = acc;
+    }
+}
+
 static unsigned stream_grid(size_t total) {
     size_t blocks = (total + 255) / 256;
     const size_t cap = 256 * 16;
@@ -256,6 +278,18 @@ int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, 
                   "polyphonic_mix: bad dims");
     hipLaunchKernelGGL(polyphonic_mix_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
                        additive, noise, out, B, P, N, out_stride);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// out[b] = sum of PA rows of a[b] + sum of PZ rows of z[b] (either may be NULL with its count 0).
+int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out, int B, int N, int out_stride,
+                     hipStream_t stream) {
+    DDSPP_REQUIRE(out && (a || PA == 0) && (z || PZ == 0) && PA >= 0 && PZ >= 0 && PA + PZ > 0,
+                  "mix_voices: bad arguments");
+    DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N, "mix_voices: bad dims");
+    hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
+                       out, B, N, out_stride);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -47,6 +47,11 @@ struct OscParams {
     int spans, cps, nchunks, npre;
     float sr, rsr, nyq;
     int fastdiv;                       // sample rate is in the exhaustively checked list
+    // compacted polyphonic mode (osc_kernel<1, true, MODE_MAIN, true, true>): R = segments, each with
+    // P voices; only oscillators with a non-zero amplitude somewhere in the span are given a lane
+    const int* __restrict__ nk;        // [B, spans, P] audible harmonics per voice and span
+    int* __restrict__ wcount;          // [B, spans]    wavefronts that actually produced a partial row
+    int P, wmax, nslots;               // voices per segment, partial rows per segment, workgroups per (segment, span)
 };
 
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
@@ -62,17 +67,28 @@ __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
     return om / sr;
 }
 
-template <int VPL, bool FUSED, int MODE, bool SUM>
+template <int VPL, bool FUSED, int MODE, bool SUM, bool COMPACT = false>
 __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
+    static_assert(!COMPACT || (VPL <= 2 && FUSED && MODE == MODE_MAIN && SUM), "compact mode: fused main kernel only");
     // one workgroup = the `groups` wavefronts of one (row, span): they walk the same samples, so
     // their per-tile partial sums can be combined through LDS behind a single barrier per tile
     extern __shared__ float lds_dyn[];
 
     const int lane = threadIdx.x & 63;
-    const int grp = wave_uniform(threadIdx.x >> 6);
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int grp = COMPACT ? 0 : wib;                     // compact mode: the 4 wavefronts are independent
     const int task = blockIdx.x;
     int row, c0, c1;
-    if (MODE == MODE_PREPASS) {
+    int cw = 0;                                            // compact mode: wavefront slot inside (segment, span)
+    if (COMPACT) {
+        const int nwg = p.nslots / 4;                      // workgroups (of 4 wavefront slots) per (segment, span)
+        const int bs = task / nwg;
+        cw = (task - bs * nwg) * 4 + wib;                  // then cw += nslots until the audible set is covered
+        row = bs / p.spans;                                // = segment b
+        const int span = bs - row * p.spans;
+        c0 = span * p.cps;
+        c1 = min(c0 + p.cps, p.nchunks);
+    } else if (MODE == MODE_PREPASS) {
         row = task / p.npre;
         c0 = task - row * p.npre;
         c1 = c0 + 1;
@@ -82,10 +98,11 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         c0 = span * p.cps;
         c1 = min(c0 + p.cps, p.nchunks);
     }
+    for (;;) {      // compact mode: one pass per 64 audible oscillators this workgroup is responsible for
     const int vbase = grp * p.vgrp;                       // first oscillator of this wavefront
     const int vlast = min(vbase + p.vgrp, p.V) - 1;       // last one (inclusive)
-    float* tile = lds_dyn + grp * (TILE * TSTRIDE);
-    float* comb = lds_dyn + p.groups * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
+    float* tile = lds_dyn + (COMPACT ? wib : grp) * (TILE * TSTRIDE);
+    float* comb = lds_dyn + (COMPACT ? 4 : p.groups) * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
     int comb_buf = 0;
 
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
@@ -109,8 +126,53 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     int vk[VPL], vs[VPL], vcol[VPL], vidx[VPL];
     bool valid[VPL];
     float kmul[VPL];
+    int lrow[VPL];                                         // row (= segment * P + voice) of this lane's j-th oscillator
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) {
+    for (int j = 0; j < VPL; ++j) lrow[j] = row;
+    if (COMPACT) {
+        // Pack the audible oscillators of the segment's P * S (voice, sub-string) rows back to back:
+        // sub-row q contributes its first nk harmonics; a wavefront slot covers 64 * VPL of them and
+        // lane l takes the (64 * VPL * cw + l + 64 j)-th, j < VPL.
+        const int Q = p.P * S;
+        const int span = c0 / p.cps;
+        const int len = lane < Q ? p.nk[((size_t)row * p.spans + span) * p.P + lane / S] : 0;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int total = __shfl(incl, 63);
+        if (cw == 0 && lane == 0) p.wcount[(size_t)row * p.spans + span] = (total + 64 * VPL - 1) / (64 * VPL);
+        if (64 * VPL * cw >= total) break;                 // nothing audible left for this slot
+        int* offs = reinterpret_cast<int*>(tile);          // exclusive offsets of the sub-rows, via LDS
+        offs[lane] = incl - len;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int g = 64 * VPL * cw + lane + 64 * j;
+            const int gc = min(g, total - 1);
+            int q = 0;                                     // last sub-row whose offset is <= gc
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (q + step < Q && offs[q + step] <= gc) q += step;
+            const int k = gc - offs[q];
+            lrow[j] = row * p.P + q / S;
+            vs[j] = q - (q / S) * S;
+            vk[j] = k;
+            vcol[j] = vs[j] * H + k;
+            vidx[j] = vcol[j];
+            valid[j] = g < total;
+            kmul[j] = (float)(k + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int j = 0; j < VPL && !COMPACT; ++j) {
         const int v = vbase + (CONTIG ? lane * VPL + j : lane + 64 * j);
         vidx[j] = v;
         valid[j] = v <= vlast;
@@ -133,7 +195,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         const int span = c0 / p.cps;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            asum[j] = p.astart[((size_t)row * p.spans + span) * p.VP + vidx[j]];
+            asum[j] = p.astart[((size_t)lrow[j] * p.spans + span) * p.VP + vidx[j]];
             off[j] = mod_2pi(asum[j]);
         }
     }
@@ -144,13 +206,13 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     // x0/a0 = frame t, x1/a1 = frame min(t + 1, T - 1); the raw values of the frame after that are
     // requested one whole frame early (q_*), so their HBM/L2 latency hides behind 96 samples of work.
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
-    float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp = 0.0f;
+    float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
     int t = 0, r = 0;
     auto frame_request = [&](int tt) {
-        const size_t fr = (size_t)row * T + tt;
-        q_amp = p.amp[fr];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
+            const size_t fr = (size_t)lrow[j] * T + tt;
+            q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
             q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : 0.0f;
             q_hd[j] = (MODE != MODE_PREPASS) ? p.hd[fr * H + vk[j]] : 0.0f;
@@ -161,7 +223,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         for (int j = 0; j < VPL; ++j) {
             float f = q_f0[j] * kmul[j];
             if (p.shifts) f = f * (1.0f + q_sh[j]);
-            const float a = q_amp * q_hd[j];
+            const float a = q_amp[j] * q_hd[j];
             xf[j] = valid[j] ? f : 0.0f;
             xa[j] = (valid[j] && MODE != MODE_PREPASS) ? a : 0.0f;
         }
@@ -214,7 +276,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         classify_frame();
     }
 
-    float* out_row = p.out + (size_t)row * N;
+    float* out_row = p.out + (COMPACT ? ((size_t)row * p.wmax + cw) * N : (size_t)row * N);
     int cpos = 0;                      // position inside the current 1000-sample chunk
     int chunk = c0;
     const float* fe_row = FUSED ? nullptr : p.fe + (size_t)row * N * H;
@@ -473,6 +535,9 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             }
         }
     }
+    if (!COMPACT) break;
+    cw += p.nslots;
+    }   // for (;;)
 }
 
 // Fused source, spans > 1: chunk end phases and span start offsets in ONE sequential walk per
@@ -651,6 +716,65 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
             ++span;
         }
         if (c < npre) a = a + ework[((size_t)row * npre + c) * VP + v];
+    }
+}
+
+// nk[b, span, p] = number of leading harmonics of voice p that have a non-zero amplitude
+// amp[t] * hd[t, k] in some frame the span touches (frames t_lo .. min(t_hi + 1, T - 1)).
+// get_controls zeroes harmonics above Nyquist and gates silent voices, so for a piano note this is
+// floor(Nyquist / f_k) -- typically a third of H.
+__global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict__ amp, const float* __restrict__ hd,
+                                                      int* __restrict__ nk, int R, int P, int T, int H, int U,
+                                                      int N, int spans, int cps) {
+    const int lane = threadIdx.x & 63;
+    const int task = wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (task >= R * spans) return;
+    const int row = task / spans, span = task - row * spans;
+    const int n_lo = span * cps * DDSPP_CHUNK, n_hi = min((span + 1) * cps * DDSPP_CHUNK, N);
+    const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
+    int best = 0;
+    constexpr int FB = 8;
+    for (int k0 = 0; k0 < H; k0 += 64) {
+        const int k = min(k0 + lane, H - 1);
+        bool any = false;
+        for (int t0 = t_lo; t0 <= t_hi; t0 += FB) {
+            float a[FB], h[FB];
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const size_t fr = (size_t)row * T + min(t0 + u, t_hi);
+                a[u] = amp[fr];
+                h[u] = hd[fr * H + k];
+            }
+#pragma unroll
+            for (int u = 0; u < FB; ++u) any = any || (a[u] * h[u] != 0.0f);
+        }
+        if (any && k0 + lane < H) best = k0 + lane + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (lane == 0) {
+        const int b = row / P, v = row - b * P;
+        nk[((size_t)b * spans + span) * P + v] = best;
+    }
+}
+
+// audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic)
+__global__ void __launch_bounds__(256) osc_partial_sum_kernel(const float* __restrict__ partial,
+                                                            const int* __restrict__ wcount,
+                                                            float* __restrict__ out, int B, int N, int wmax,
+                                                            int spans, int cps) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)B * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
+        const int span = min((4 * i) / (cps * DDSPP_CHUNK), spans - 1);
+        const int wc = wcount[(size_t)b * spans + span];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < wc; ++w) {
+            const float4 v = reinterpret_cast<const float4*>(partial + ((size_t)b * wmax + w) * N)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)b * N)[i] = acc;
     }
 }
 
@@ -892,6 +1016,99 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
     int rc = dispatch_vpl<true>(pl.vpl, p, use_angular_cumsum != 0, true, stream);
     DDSPP_REQUIRE(rc == DDSPP_OK, "harmonic_synthesis: dispatch failed");
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The additive branch of the whole polyphonic group in one call: sum over the P voices of a segment
+// of MultiInharmonic.get_signal (inharm_synth.py:272-293) = the `additive/signal` terms of the add
+// chain of polyphonic_dag.py:28-37, without the per-voice stems.  Rows are [B * P] (segment major);
+// only oscillators that are audible somewhere in a span get a lane (see osc_count_kernel), so the
+// work follows the number of partials below Nyquist instead of P * H.  audio: [B, T * U].
+size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U) {
+    if (B <= 0 || P <= 0 || T <= 0 || S <= 0 || H <= 0 || U <= 0) return 0;
+    const size_t N = (size_t)T * U;
+    const size_t nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
+    const size_t V = (size_t)S * H, VP = (V + 63) / 64 * 64 + 64;
+    const size_t wmax = (P * V + 63) / 64;
+    return ((size_t)B * P * nchunks * VP          /* astart (worst case: one span per chunk) */
+            + (size_t)B * nchunks * (P + 1)       /* nk + wcount */
+            + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
+}
+
+int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                              const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
+                              int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
+                  "polyphonic_additive: null buffer");
+    DDSPP_REQUIRE(B > 0 && P > 0 && T > 0 && S > 0 && H > 0 && U > 0, "polyphonic_additive: bad dims");
+    DDSPP_REQUIRE(U % BLK == 0, "polyphonic_additive: upsampling=%d must be a multiple of %d", U, BLK);
+    DDSPP_REQUIRE(P * S <= 64, "polyphonic_additive: n_synths * n_substrings = %d exceeds 64", P * S);
+    DDSPP_REQUIRE((long long)T * U < (1ll << 31) && (T * U) % 4 == 0, "polyphonic_additive: bad sample count");
+    const int V = S * H, R = B * P, N = T * U;
+    DDSPP_REQUIRE(pick_vpl(V) != 0, "polyphonic_additive: n_substrings*n_harmonics=%d exceeds 512", V);
+    DDSPP_REQUIRE(workspace_bytes >= ddspp_polyphonic_additive_workspace_bytes(B, P, T, S, H, U),
+                  "polyphonic_additive: workspace too small");
+    const int nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
+    // spans: enough (segment, span, slot) tasks to balance 256 CUs
+    int sp = spans > 0 ? spans : env_int("DDSPP_OSC_SPANS_COMPACT", 0);
+    if (sp <= 0) sp = (env_int("DDSPP_OSC_TARGET_WAVES_COMPACT", 18432) + B * 8 - 1) / (B * 8);
+    if (sp > nchunks) sp = nchunks;
+    if (sp < 1) sp = 1;
+    const int cps = (nchunks + sp - 1) / sp;
+    sp = (nchunks + cps - 1) / cps;
+    const int vpl_pre = pick_vpl(V);
+    const int VP = vpl_pre * 64;
+    const int wmax = (P * V + 127) / 128;              // partial rows per segment: 128 oscillators per wavefront slot
+
+    float* astart = (float*)workspace;
+    int* nk = (int*)(astart + (size_t)R * sp * VP);
+    int* wcount = nk + (size_t)B * sp * P;
+    float* partial = (float*)(wcount + (size_t)B * sp);
+    partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
+
+    OscParams p{};
+    p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
+    p.wlin = wlin; p.whann = whann;
+    p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
+    p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;
+    p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
+    p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.astart = astart;
+
+    // 1. span start offsets for every (row, oscillator): the memoised pre-pass over rows = B * P
+    if (sp > 1) {
+        OscParams q = p;
+        q.R = R; q.groups = 1; q.vgrp = V;
+        q.ework = astart;
+        const int tasks = R;
+        switch (vpl_pre) {
+            case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+        }
+    }
+    // 2. audible-harmonic counts per (segment, span, voice)
+    hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
+                       harmonic_distribution, nk, R, P, T, H, U, N, sp, cps);
+    // 3. the compacted oscillator bank: one wavefront per (segment, span, slot of 64 audible oscillators)
+    // workgroups per (segment, span): each loops over slots cw, cw + nslots, ...; a piano has about a
+    // third of its P * H partials below Nyquist, so wmax / 2 slots rarely need a second pass
+    int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", (3 * wmax + 3) / 4);
+    nslots = (nslots + 3) / 4 * 4;
+    if (nslots < 4) nslots = 4;
+    p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots;
+    p.nk = nk; p.wcount = wcount; p.out = partial;
+    const size_t lds = ((size_t)4 * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
+    hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256), lds,
+                       stream, p);
+    // 4. slots -> audio
+    hipLaunchKernelGGL(osc_partial_sum_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
+                       partial, wcount, audio, B, N, wmax, sp, cps);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -87,9 +87,13 @@ def _stack_voices(tensors):
     return torch.stack([core.tf_float32(x) for x in tensors], dim=1).contiguous()
 
 
-def run(plan, inputs, noise=None):
+def run(plan, inputs, noise=None, need_stems=True):
     """Execute the polyphonic DAG with voices batched.  Returns the ddsp-style outputs dict, or None
-    when the inputs do not fit the batched kernels (caller then walks the DAG node by node)."""
+    when the inputs do not fit the batched kernels (caller then walks the DAG node by node).
+
+    need_stems=False (a plain ``group(features)`` call that only wants the audio): the additive
+    branch runs through the compacted kernel, which forms the per-segment mix directly -- the
+    `additive` / `voices` entries are then absent from the outputs dict."""
     P = plan.n_synths
     add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
     amp = _stack_voices(add_ctl[0])           # [B, P, T, 1]
@@ -119,9 +123,16 @@ def run(plan, inputs, noise=None):
     # --- additive branch ------------------------------------------------------------------------
     ctl = additive._controls(amp.reshape(R, T, 1), hd.reshape(R, T, H), inh.reshape(R, T, 1),
                              f0.reshape(R, T, S))
-    additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
-                                                 ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
-                                                 additive.sample_rate, additive.inference)
+    compact = (not need_stems) and additive.inference and P * S <= 64 and N % 4 == 0
+    if compact:
+        additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
+                                                ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N,
+                                                additive.sample_rate)
+        additive_sig = None
+    else:
+        additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
+                                                     ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
+                                                     additive.sample_rate, additive.inference)
     # --- noise branch ---------------------------------------------------------------------------
     nctl = noise_p.get_controls(mags.reshape(R, T, K))
     if noise is None:
@@ -135,6 +146,18 @@ def run(plan, inputs, noise=None):
 
     # --- add chain ------------------------------------------------------------------------------
     dry = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if compact:
+        _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), P, _ptr(dry), B, N, N,
+                                            _stream()))
+        outputs = {'inputs': inputs}
+        outputs.update(inputs)
+        outputs[plan.add.name] = {'signal': dry, 'controls': {}}
+        module_outputs = outputs[plan.add.name]
+        if plan.reverb is not None:
+            module_outputs = plan.reverb(dry, *[inputs[k] for k in plan.reverb_keys], return_outputs_dict=True)
+            outputs[plan.reverb.name] = module_outputs
+        outputs['out'] = module_outputs
+        return outputs
     _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), B, P, N, N,
                                             _stream()))
 

@@ -95,6 +95,8 @@ class ProcessorGroup:
         return list(self._processors)
 
     def __call__(self, inputs, return_outputs_dict=False, **kwargs):
+        if not return_outputs_dict:
+            kwargs.setdefault('need_stems', False)     # audio only: the batched route may skip voice stems
         outputs = self.get_controls(inputs, **kwargs)
         signal = self.get_signal(outputs)
         if return_outputs_dict:
@@ -102,7 +104,8 @@ class ProcessorGroup:
         return signal
 
     def get_controls(self, inputs, **kwargs):
-        """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag)."""
+        """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag).  kwargs (noise=,
+        need_stems=) only concern the batched polyphonic route."""
         if self.fast_path:
             from . import polyphonic
             if self._plan is None:

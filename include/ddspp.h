@@ -84,6 +84,16 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
                              int H, int U, float sample_rate, int use_angular_cumsum, int spans,
                              void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* The additive branch of the whole polyphonic group: audio[B, T*U] = sum over the P voices of a segment
+ * of MultiInharmonic.get_signal (the `additive/signal` terms of polyphonic_dag.py:28-37); rows of the
+ * controls are [B * P], segment major.  Only oscillators with a non-zero amplitude somewhere in a span are
+ * given a lane, so the work follows the number of partials below Nyquist instead of P * H. */
+size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
+int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                              const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
+                              int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* ---- get_controls ---------------------------------------------------------------------------- */
 
 /* InHarmonic.get_controls / MultiInharmonic.get_controls -- inharm_synth.py:167-219, :254-270
@@ -112,6 +122,11 @@ int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, 
  * out_stride floats (noise may be NULL). */
 int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
                          int out_stride, hipStream_t stream);
+
+/* out[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] ([B,PA,N], [B,PZ,N] -> rows of out_stride floats):
+ * the add chain when the additive operand is already the per-segment mix of ddspp_polyphonic_additive. */
+int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out, int B, int N, int out_stride,
+                     hipStream_t stream);
 
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
