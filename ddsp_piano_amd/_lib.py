@@ -19,6 +19,9 @@ _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
 SOURCES = ['error.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip', 'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
+# packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
+# time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
+PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize']}
 
 DDSPP_OK = 0
 DDSPP_EINVAL = -22
@@ -55,7 +58,8 @@ def build(force=False, verbose=True):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
                 and os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, 'ddspp_common.h'))):
             return obj
-        cmd = [hipcc] + flags + ['-x', 'hip', '-c', srcp, '-o', obj]
+        extra = PER_FILE_FLAGS.get(src, [])
+        cmd = [hipcc] + flags + extra + ['-x', 'hip', '-c', srcp, '-o', obj]
         if verbose:
             print('[ddspp build]', ' '.join(cmd), file=sys.stderr, flush=True)
         subprocess.run(cmd, check=True)

@@ -62,69 +62,89 @@ struct InharmParams {
     ScaleFn scale;
 };
 
+// One wavefront conditions CTL_FPW consecutive frames of a row-major [R*T] frame list: all loads of the
+// batch are issued before the first use (short-lived one-frame wavefronts were latency bound at 2.9 TB/s).
+constexpr int CTL_FPW = 4;
+
 template <int HPL>
 __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmParams p) {
     const int lane = threadIdx.x & 63;
-    const size_t frame = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (frame >= (size_t)p.R * p.T) return;
+    const size_t nframes = (size_t)p.R * p.T;
+    const size_t frame0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * CTL_FPW;
+    if (frame0 >= nframes) return;
     const int H = p.H;
-    const float f0 = p.f0_hz[frame * p.S];                              // f0_hz[..., 0:1]  (:264)
-    const float inharm = fmaxf(p.inharm_coef[frame], 0.0f);             // :183
-    float amp = apply_scale(p.scale, p.amplitudes[frame]);              // :185
-    float hd[HPL], shift[HPL], freq[HPL];
-    float sum = 0.0f;
+    float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
 #pragma unroll
-    for (int j = 0; j < HPL; ++j) {
-        const int k = lane + 64 * j;
-        hd[j] = 0.0f;
-        shift[j] = 0.0f;
-        freq[j] = 0.0f;
-        if (k < H) {
-            hd[j] = apply_scale(p.scale, p.harmonic_distribution[frame * H + k]);   // :186
-            const float m = (float)(k + 1);
-            float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
-            g = g * inharm + 1.0f;                 //                                        :38
-            g = sqrtf(g);                          //                                        :39
-            freq[j] = (f0 * m) * g;                // f0_hz * int_multiplier * inharm_factor :42
-            shift[j] = g - 1.0f;                   //                                        :44
-            sum += hd[j];
-        }
+    for (int u = 0; u < CTL_FPW; ++u) {
+        const size_t fr = min(frame0 + u, nframes - 1);
+        raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
+        raw_in[u] = p.inharm_coef[fr];
+        raw_amp[u] = p.amplitudes[fr];
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) raw_hd[u][j] = p.harmonic_distribution[fr * H + min(lane + 64 * j, H - 1)];
     }
-    if (!p.normalize_after_nyquist_cut) {                                // :194-198
-        const float tot = wave_sum(sum);
-        const float den = tot == 0.0f ? 1e-7f : tot;                     // core.safe_divide
-        sum = 0.0f;
+#pragma unroll
+    for (int u = 0; u < CTL_FPW; ++u) {
+        const size_t frame = frame0 + u;
+        if (frame >= nframes) break;
+        const float f0 = raw_f0[u];
+        const float inharm = fmaxf(raw_in[u], 0.0f);                    // :183
+        float amp = apply_scale(p.scale, raw_amp[u]);                   // :185
+        float hd[HPL], shift[HPL], freq[HPL];
+        float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < HPL; ++j) {
-            hd[j] = hd[j] / den;
-            sum += hd[j];
+            const int k = lane + 64 * j;
+            hd[j] = 0.0f;
+            shift[j] = 0.0f;
+            freq[j] = 0.0f;
+            if (k < H) {
+                hd[j] = apply_scale(p.scale, raw_hd[u][j]);                                 // :186
+                const float m = (float)(k + 1);
+                float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
+                g = g * inharm + 1.0f;                 //                                        :38
+                g = sqrtf(g);                          //                                        :39
+                freq[j] = (f0 * m) * g;                // f0_hz * int_multiplier * inharm_factor :42
+                shift[j] = g - 1.0f;                   //                                        :44
+                sum += hd[j];
+            }
         }
-    }
-    if (p.normalize_below_nyquist) {                                     // :200-208
-        sum = 0.0f;
+        if (!p.normalize_after_nyquist_cut) {                                // :194-198
+            const float tot = wave_sum(sum);
+            const float den = tot == 0.0f ? 1e-7f : tot;                     // core.safe_divide
+            sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                hd[j] = hd[j] / den;
+                sum += hd[j];
+            }
+        }
+        if (p.normalize_below_nyquist) {                                     // :200-208
+            sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                if (freq[j] >= p.nyquist) hd[j] = 0.0f;                      // core.remove_above_nyquist
+                sum += hd[j];
+            }
+            amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
+        }
+        if (p.normalize_after_nyquist_cut) {                                 // :210-214
+            const float tot = wave_sum(sum);
+            const float den = tot == 0.0f ? 1e-7f : tot;
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) hd[j] = hd[j] / den;
+        }
+        amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
 #pragma unroll
         for (int j = 0; j < HPL; ++j) {
-            if (freq[j] >= p.nyquist) hd[j] = 0.0f;                      // core.remove_above_nyquist
-            sum += hd[j];
+            const int k = lane + 64 * j;
+            if (k < H) {
+                p.hd_out[frame * H + k] = hd[j];
+                p.shifts_out[frame * H + k] = shift[j];
+            }
         }
-        amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
+        if (lane == 0) p.amp_out[frame] = amp;
     }
-    if (p.normalize_after_nyquist_cut) {                                 // :210-214
-        const float tot = wave_sum(sum);
-        const float den = tot == 0.0f ? 1e-7f : tot;
-#pragma unroll
-        for (int j = 0; j < HPL; ++j) hd[j] = hd[j] / den;
-    }
-    amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
-#pragma unroll
-    for (int j = 0; j < HPL; ++j) {
-        const int k = lane + 64 * j;
-        if (k < H) {
-            p.hd_out[frame * H + k] = hd[j];
-            p.shifts_out[frame * H + k] = shift[j];
-        }
-    }
-    if (lane == 0) p.amp_out[frame] = amp;
 }
 
 __global__ void __launch_bounds__(256) scale_bias_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -234,7 +254,7 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
     p.normalize_below_nyquist = normalize_below_nyquist;
     p.scale = ScaleFn{scale_kind, logf(exponent), max_value, threshold, gain};
     const size_t frames = (size_t)R * T;
-    const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
+    const dim3 grid((unsigned)((frames + 4 * CTL_FPW - 1) / (4 * CTL_FPW))), block(256);
     const int hpl = (H + 63) / 64;
     if (hpl <= 1) hipLaunchKernelGGL(inharmonic_controls_kernel<1>, grid, block, 0, stream, p);
     else if (hpl <= 2) hipLaunchKernelGGL(inharmonic_controls_kernel<2>, grid, block, 0, stream, p);
