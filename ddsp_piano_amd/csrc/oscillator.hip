@@ -876,7 +876,12 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
     const dim3 blk(64 * p.groups);
     const size_t lds = ((size_t)p.groups * (TILE * TSTRIDE) + 2 * p.groups * 32) * sizeof(float);
     if (angular) {
-        if (p.spans > 1 && FUSED && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0)) {
+        // The memoised pre-pass walks the chunks of a row sequentially: right when there are enough
+        // rows to fill the chip, wrong for a single long file (few rows, thousands of chunks), where the
+        // chunk-parallel pre-pass + offset scan is used instead.
+        const bool memo = FUSED && p.R * p.groups >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) &&
+                          !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
+        if (p.spans > 1 && memo) {
             OscParams q = p;
             q.ework = const_cast<float*>(p.astart);      // the memo pre-pass writes astart directly
             const int tasks = p.R * p.groups;
@@ -1031,7 +1036,7 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
     const size_t nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     const size_t V = (size_t)S * H, VP = (V + 63) / 64 * 64 + 64;
     const size_t wmax = (P * V + 63) / 64;
-    return ((size_t)B * P * nchunks * VP          /* astart (worst case: one span per chunk) */
+    return (2 * (size_t)B * P * nchunks * VP      /* astart + chunk end phases (worst case: one span per chunk) */
             + (size_t)B * nchunks * (P + 1)       /* nk + wcount */
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
@@ -1063,7 +1068,8 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     const int wmax = (P * V + 127) / 128;              // partial rows per segment: 128 oscillators per wavefront slot
 
     float* astart = (float*)workspace;
-    int* nk = (int*)(astart + (size_t)R * sp * VP);
+    float* ework = astart + (size_t)R * sp * VP;           // chunk end phases (chunk-parallel pre-pass only)
+    int* nk = (int*)(ework + (size_t)R * nchunks * VP);
     int* wcount = nk + (size_t)B * sp * P;
     float* partial = (float*)(wcount + (size_t)B * sp);
     partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
@@ -1077,19 +1083,38 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
     p.astart = astart;
 
-    // 1. span start offsets for every (row, oscillator): the memoised pre-pass over rows = B * P
+    // 1. span start offsets for every (row, oscillator) over rows = B * P: memoised sequential walk when
+    //    the rows fill the chip, chunk-parallel pre-pass + scan for a few long rows (whole-file mode)
     if (sp > 1) {
         OscParams q = p;
         q.R = R; q.groups = 1; q.vgrp = V;
-        q.ework = astart;
-        const int tasks = R;
-        switch (vpl_pre) {
-            case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+        const bool memo = R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
+        if (memo) {
+            q.ework = astart;
+            const int tasks = R;
+            switch (vpl_pre) {
+                case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+                case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+                case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+                case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+                case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+                default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
+            }
+        } else {
+            q.ework = ework;
+            const dim3 grid((unsigned)(R * q.npre)), blk(64);
+            const size_t plds = ((size_t)(TILE * TSTRIDE) + 2 * 32) * sizeof(float);
+            switch (vpl_pre) {
+                case 1: hipLaunchKernelGGL((osc_kernel<1, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 2: hipLaunchKernelGGL((osc_kernel<2, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 3: hipLaunchKernelGGL((osc_kernel<3, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 4: hipLaunchKernelGGL((osc_kernel<4, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 6: hipLaunchKernelGGL((osc_kernel<6, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                default: hipLaunchKernelGGL((osc_kernel<8, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+            }
+            const size_t nthr = (size_t)R * VP;
+            hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                               ework, astart, R, q.npre, VP, sp, cps);
         }
     }
     // 2. audible-harmonic counts per (segment, span, voice)
