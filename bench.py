@@ -238,7 +238,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('DDSPP_BENCH_DIST') == '1'   # the latter: exercise RCCL with one rank
+    if use_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -259,16 +260,16 @@ def main():
     L = int(args.ir_seconds * sr)
     feats, base = make_features(B, P, T, H, K, S, L, device, seed=20240 + rank)
     pg = build_group(dp, P, sr)
-    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty((world * B, N), dtype=torch.float32, device=device) if use_dist else None
 
     def step():
         audio = pg(feats)
-        if world > 1:
+        if use_dist:
             parallel.gather_audio(audio, gathered)
         return audio
 
     dt = time_steps(step, args.steps, args.warmup, dist)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -318,9 +319,17 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         line.update(extra)
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe:
+        # push it out first so that the JSON line is the last line of the output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

@@ -3,13 +3,15 @@
 Drop-in for the processor group of lrenault/ddsp-piano (ddsp_piano/default_model.py:20-85,
 ddsp_piano/modules/polyphonic_dag.py, ddsp_piano/modules/piano_model.py:160): same Processor /
 ProcessorGroup call signatures, arithmetic in hand-written HIP kernels behind the C-ABI of
-include/ddspp.h.  Nothing else of the reference (control networks, MIDI / audio I/O, training) is
-rebuilt here.
+include/ddspp.h; plus the glue on its input edge (piano roll -> conditioning, Parallelizer un-merge).
+Nothing else of the reference (control networks, MIDI file / audio I/O, training) is rebuilt here.
 """
 from . import core  # noqa: F401
 from .core import exp_sigmoid, exp_tanh  # noqa: F401
 from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  # noqa: F401
                       fdn_impulse_response)
+from .midi_encoders import MIDIRoll2Conditioning, ensure_sequence_length, roll_to_conditioning  # noqa: F401
+from .parallelizer import Parallelizer  # noqa: F401
 from .polyphonic_dag import polyphonic_dag  # noqa: F401
 from .processors import Add, Processor, ProcessorGroup  # noqa: F401
 from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiAdd,  # noqa: F401
@@ -17,4 +19,5 @@ from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiA
 
 __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
            'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
-           'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag']
+           'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag',
+           'Parallelizer', 'MIDIRoll2Conditioning', 'ensure_sequence_length', 'roll_to_conditioning']

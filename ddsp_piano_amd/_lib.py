@@ -17,7 +17,8 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip', 'reverb.hip', 'fdn.hip']
+SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip',
+           'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
@@ -94,15 +95,15 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
-    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                           c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     'ddspp_scale_bias': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_float, c_float,
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                           c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes_eo': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -123,6 +124,12 @@ SIGNATURES = {
     'ddspp_irfft_plan_destroy': (c_int, [c_void_p]),
     'ddspp_irfft_workspace_bytes': (c_size_t, [c_void_p]),
     'ddspp_irfft_execute': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ddspp_midi_conditioning_create': (c_void_p, [c_int]),
+    'ddspp_midi_conditioning_destroy': (None, [c_void_p]),
+    'ddspp_midi_conditioning_reset': (c_int, [c_void_p]),
+    'ddspp_midi_conditioning_get_state': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ddspp_midi_conditioning_run_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'ddspp_midi_conditioning_run_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -457,8 +457,9 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
-                        sample_rate, spans=0):
-    """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N].
+                        sample_rate, spans=0, voice_major=False):
+    """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
+    (rows ordered [B, P], or [P, B] with voice_major=True).
 
     The per-voice stems are never formed; lanes go only to oscillators that are audible somewhere in a
     span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only."""
@@ -477,7 +478,8 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     _lib.check(lib.ddspp_polyphonic_additive(
         _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
         _ptr(harmonic_shifts) if harmonic_shifts is not None else ctypes.c_void_p(0), _ptr(wlin), _ptr(whann),
-        _ptr(out), b, p, t, s, h, u, float(sample_rate), int(spans), _ptr(ws), nbytes, _stream()))
+        _ptr(out), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
+        _stream()))
     return out
 
 

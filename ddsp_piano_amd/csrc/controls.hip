@@ -171,14 +171,14 @@ __global__ void __launch_bounds__(256) add_signals_kernel(const float* const* __
 __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __restrict__ additive,
                                                            const float* __restrict__ noise,
                                                            float* __restrict__ out, int B, int P,
-                                                           int N, int out_stride) {
+                                                           int N, int out_stride, int voice_major) {
     const int n4 = N / 4;
     const size_t total = (size_t)B * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int v = 0; v < P; ++v) {
-            const size_t off = ((size_t)b * P + v) * n4 + i;
+            const size_t off = (voice_major ? (size_t)v * B + b : (size_t)b * P + v) * n4 + i;
             if (noise) {
                 const float4 z = reinterpret_cast<const float4*>(noise)[off];
                 if (v == 0) acc = z;
@@ -196,18 +196,19 @@ __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __rest
 // already a per-segment mix
 __global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict__ a, int PA,
                                                        const float* __restrict__ z, int PZ,
-                                                       float* __restrict__ out, int B, int N, int out_stride) {
+                                                       float* __restrict__ out, int B, int N, int out_stride,
+                                                       int voice_major) {
     const int n4 = N / 4;
     const size_t total = (size_t)B * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int v = 0; v < PZ; ++v) {
-            const float4 t = reinterpret_cast<const float4*>(z)[((size_t)b * PZ + v) * n4 + i];
+            const float4 t = reinterpret_cast<const float4*>(z)[(voice_major ? (size_t)v * B + b : (size_t)b * PZ + v) * n4 + i];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
         for (int v = 0; v < PA; ++v) {
-            const float4 t = reinterpret_cast<const float4*>(a)[((size_t)b * PA + v) * n4 + i];
+            const float4 t = reinterpret_cast<const float4*>(a)[(voice_major ? (size_t)v * B + b : (size_t)b * PA + v) * n4 + i];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
         reinterpret_cast<float4*>(out + (size_t)b * out_stride)[i] = acc;
@@ -289,27 +290,28 @@ int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, 
 }
 
 // The `add` chain of polyphonic_dag.py:28-37 for all voices at once: additive/noise are
-// [B, P, N]; out rows are written with a stride (so the dry mix can land in a zero-padded FFT
-// buffer of the reverb).  noise may be null (dry additive only).
+// [B, P, N] (voice_major = 0) or [P, B, N] (voice_major = 1, the layout the reference's Parallelizer
+// leaves the merged controls in, sub_modules.py:573-592); out rows are written with a stride (so the
+// dry mix can land in a zero-padded FFT buffer of the reverb).  noise may be null (dry additive only).
 int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
-                         int out_stride, hipStream_t stream) {
+                         int out_stride, int voice_major, hipStream_t stream) {
     DDSPP_REQUIRE(additive && out, "polyphonic_mix: null buffer");
     DDSPP_REQUIRE(B > 0 && P > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N,
                   "polyphonic_mix: bad dims");
     hipLaunchKernelGGL(polyphonic_mix_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
-                       additive, noise, out, B, P, N, out_stride);
+                       additive, noise, out, B, P, N, out_stride, voice_major);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
 
 // out[b] = sum of PA rows of a[b] + sum of PZ rows of z[b] (either may be NULL with its count 0).
 int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out, int B, int N, int out_stride,
-                     hipStream_t stream) {
+                     int voice_major, hipStream_t stream) {
     DDSPP_REQUIRE(out && (a || PA == 0) && (z || PZ == 0) && PA >= 0 && PZ >= 0 && PA + PZ > 0,
                   "mix_voices: bad arguments");
     DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N, "mix_voices: bad dims");
     hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
-                       out, B, N, out_stride);
+                       out, B, N, out_stride, voice_major);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -52,6 +52,7 @@ struct OscParams {
     const int* __restrict__ nk;        // [B, spans, P] audible harmonics per voice and span
     int* __restrict__ wcount;          // [B, spans]    wavefronts that actually produced a partial row
     int P, wmax, nslots;               // voices per segment, partial rows per segment, workgroups per (segment, span)
+    int vmajor;                        // compact mode: rows are [P, B] (voice major) instead of [B, P]
 };
 
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             for (int step = 32; step > 0; step >>= 1)
                 if (q + step < Q && offs[q + step] <= gc) q += step;
             const int k = gc - offs[q];
-            lrow[j] = row * p.P + q / S;
+            lrow[j] = p.vmajor ? (q / S) * p.R + row : row * p.P + q / S;
             vs[j] = q - (q / S) * S;
             vk[j] = k;
             vcol[j] = vs[j] * H + k;
@@ -725,7 +726,7 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
 // floor(Nyquist / f_k) -- typically a third of H.
 __global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict__ amp, const float* __restrict__ hd,
                                                       int* __restrict__ nk, int R, int P, int T, int H, int U,
-                                                      int N, int spans, int cps) {
+                                                      int N, int spans, int cps, int vmajor) {
     const int lane = threadIdx.x & 63;
     const int task = wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (task >= R * spans) return;
@@ -753,7 +754,8 @@ __global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
     if (lane == 0) {
-        const int b = row / P, v = row - b * P;
+        const int B = R / P;
+        const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
         nk[((size_t)b * spans + span) * P + v] = best;
     }
 }
@@ -1027,7 +1029,8 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
 
 // The additive branch of the whole polyphonic group in one call: sum over the P voices of a segment
 // of MultiInharmonic.get_signal (inharm_synth.py:272-293) = the `additive/signal` terms of the add
-// chain of polyphonic_dag.py:28-37, without the per-voice stems.  Rows are [B * P] (segment major);
+// chain of polyphonic_dag.py:28-37, without the per-voice stems.  Rows are [B * P] (segment major) or,
+// with voice_major = 1, [P * B] (the reference Parallelizer's merged layout, sub_modules.py:573-592);
 // only oscillators that are audible somewhere in a span get a lane (see osc_count_kernel), so the
 // work follows the number of partials below Nyquist instead of P * H.  audio: [B, T * U].
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U) {
@@ -1044,7 +1047,7 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
-                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                              int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
                   "polyphonic_additive: null buffer");
     DDSPP_REQUIRE(B > 0 && P > 0 && T > 0 && S > 0 && H > 0 && U > 0, "polyphonic_additive: bad dims");
@@ -1119,14 +1122,14 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     }
     // 2. audible-harmonic counts per (segment, span, voice)
     hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
-                       harmonic_distribution, nk, R, P, T, H, U, N, sp, cps);
+                       harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
     // 3. the compacted oscillator bank: one wavefront per (segment, span, slot of 64 audible oscillators)
     // workgroups per (segment, span): each loops over slots cw, cw + nslots, ...; a piano has about a
     // third of its P * H partials below Nyquist, so wmax / 2 slots rarely need a second pass
     int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", (3 * wmax + 3) / 4);
     nslots = (nslots + 3) / 4 * 4;
     if (nslots < 4) nslots = 4;
-    p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots;
+    p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots; p.vmajor = voice_major ? 1 : 0;
     p.nk = nk; p.wcount = wcount; p.out = partial;
     const size_t lds = ((size_t)4 * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
     hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256), lds,

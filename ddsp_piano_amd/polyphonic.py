@@ -69,9 +69,24 @@ def recognise(dag):
     return Plan(additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, p)
 
 
-def _stack_voices(tensors):
-    """[B, T, C] x P -> [B, P, T, C] contiguous; zero-copy when the P tensors are the P slices of
-    one [B, P, T, C] buffer (what a batched control network naturally produces)."""
+def _same_buffer_slices(tensors, step_elems):
+    """True when tensors[i] starts i * step_elems elements after tensors[0] inside one storage."""
+    t0 = tensors[0]
+    es = t0.element_size()
+    base, ptr = t0.untyped_storage().data_ptr(), t0.data_ptr()
+    return all(x.untyped_storage().data_ptr() == base and x.data_ptr() == ptr + i * step_elems * es
+               for i, x in enumerate(tensors))
+
+
+def _stack_voices(tensors, voice_major=None):
+    """The P per-voice tensors [B, T, C] as ONE buffer of B * P rows, plus its row order.
+
+    Returns (rows [B * P, T, C] contiguous, voice_major).  Zero-copy when the P tensors are the P slices of
+    one buffer, in either of the two orders a batched control network produces:
+      * voice major [P, B, T, C]: what the reference's Parallelizer.unparallelize hands over
+        (`features[k + f'_{i}'] = features[k][i]`, sub_modules.py:586-592);
+      * segment major [B, P, T, C].
+    Otherwise the tensors are copied into the requested order (default: voice major, P block copies)."""
     t0 = tensors[0]
     p = len(tensors)
     if (t0.is_cuda and t0.dtype == torch.float32 and t0.dim() == 3 and
@@ -79,12 +94,15 @@ def _stack_voices(tensors):
                 x.device == t0.device for x in tensors)):
         b, t, c = t0.shape
         sb, st, sc = t0.stride()
-        es = t0.element_size()
-        if sc == 1 and st == c and sb == p * t * c and all(
-                x.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and
-                x.data_ptr() == t0.data_ptr() + i * t * c * es for i, x in enumerate(tensors)):
-            return torch.as_strided(t0, (b, p, t, c), (sb, t * c, c, 1))
-    return torch.stack([core.tf_float32(x) for x in tensors], dim=1).contiguous()
+        if sc == 1 and st == c:
+            if voice_major in (None, True) and sb == t * c and _same_buffer_slices(tensors, b * t * c):
+                return torch.as_strided(t0, (p * b, t, c), (t * c, c, 1)), True
+            if voice_major in (None, False) and sb == p * t * c and _same_buffer_slices(tensors, t * c):
+                return torch.as_strided(t0, (b * p, t, c), (t * c, c, 1)), False
+    vm = True if voice_major is None else voice_major
+    xs = [core.tf_float32(x) for x in tensors]
+    b, t, c = xs[0].shape
+    return torch.stack(xs, dim=0 if vm else 1).reshape(b * p, t, c), vm
 
 
 def run(plan, inputs, noise=None, need_stems=True):
@@ -96,15 +114,16 @@ def run(plan, inputs, noise=None, need_stems=True):
     `additive` / `voices` entries are then absent from the outputs dict."""
     P = plan.n_synths
     add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
-    amp = _stack_voices(add_ctl[0])           # [B, P, T, 1]
-    hd = _stack_voices(add_ctl[1])            # [B, P, T, H]
-    inh = _stack_voices(add_ctl[2])           # [B, P, T, 1]
-    f0 = _stack_voices(add_ctl[3])            # [B, P, T, S]
-    mags = _stack_voices([inputs[k] for k in plan.noise_keys])    # [B, P, T, K]
-    B, _, T, H = hd.shape
+    hd, vm = _stack_voices(add_ctl[1])               # [R, T, H]; the widest control decides the row order
+    amp, _ = _stack_voices(add_ctl[0], vm)           # [R, T, 1]
+    inh, _ = _stack_voices(add_ctl[2], vm)           # [R, T, 1]
+    f0, _ = _stack_voices(add_ctl[3], vm)            # [R, T, S]
+    mags, _ = _stack_voices([inputs[k] for k in plan.noise_keys], vm)    # [R, T, K]
+    R, T, H = hd.shape
+    B = R // P
     S = f0.shape[-1]
     K = mags.shape[-1]
-    if amp.shape[-1] != 1 or inh.shape[-1] != 1 or mags.shape[2] != T:
+    if amp.shape[-1] != 1 or inh.shape[-1] != 1 or mags.shape[1] != T:
         return None
     additive, noise_p = plan.additive, plan.noise
     if not isinstance(additive, InHarmonic):
@@ -113,32 +132,31 @@ def run(plan, inputs, noise=None, need_stems=True):
     N = U * T
     if not core.fused_synthesis_supported(T, N):
         return None
-    if noise_p._n_samples(mags.reshape(B * P, T, K)) != N:
+    if noise_p._n_samples(mags) != N:
         return None
     if S != 1 and type(additive) is InHarmonic:
         return None
-    R = B * P
     dev = hd.device
+    vmi = 1 if vm else 0
 
     # --- additive branch ------------------------------------------------------------------------
-    ctl = additive._controls(amp.reshape(R, T, 1), hd.reshape(R, T, H), inh.reshape(R, T, 1),
-                             f0.reshape(R, T, S))
+    ctl = additive._controls(amp, hd, inh, f0)
     compact = (not need_stems) and additive.inference and P * S <= 64 and N % 4 == 0
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                 ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N,
-                                                additive.sample_rate)
+                                                additive.sample_rate, voice_major=vm)
         additive_sig = None
     else:
         additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                      ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
                                                      additive.sample_rate, additive.inference)
     # --- noise branch ---------------------------------------------------------------------------
-    nctl = noise_p.get_controls(mags.reshape(R, T, K))
+    nctl = noise_p.get_controls(mags)
     if noise is None:
         override = getattr(noise_p, 'noise_override', None)
         if override:
-            noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=1)
+            noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=0 if vm else 1)
     if noise is None:
         noise = noise_p.draw_noise(R, N, dev)
     noise = core.tf_float32(noise).reshape(R, N)
@@ -148,7 +166,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     dry = torch.empty((B, N), dtype=torch.float32, device=dev)
     if compact:
         _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), P, _ptr(dry), B, N, N,
-                                            _stream()))
+                                            vmi, _stream()))
         outputs = {'inputs': inputs}
         outputs.update(inputs)
         outputs[plan.add.name] = {'signal': dry, 'controls': {}}
@@ -159,14 +177,17 @@ def run(plan, inputs, noise=None, need_stems=True):
         outputs['out'] = module_outputs
         return outputs
     _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), B, P, N, N,
-                                            _stream()))
+                                            vmi, _stream()))
 
-    additive_sig = additive_sig.reshape(B, P, N)
-    noise_sig = noise_sig.reshape(B, P, N)
+    def per_voice(x, shape):       # rows -> [B, P, ...] (a transposed view when the rows are voice major)
+        return x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape)
+
+    additive_sig = per_voice(additive_sig, (N,))
+    noise_sig = per_voice(noise_sig, (N,))
     last = P - 1
 
     def voice(x, shape):
-        return x.reshape((B, P) + shape)[:, last]
+        return per_voice(x, shape)[:, last]
 
     outputs = {'inputs': inputs}
     outputs.update(inputs)

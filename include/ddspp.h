@@ -86,13 +86,15 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
 
 /* The additive branch of the whole polyphonic group: audio[B, T*U] = sum over the P voices of a segment
  * of MultiInharmonic.get_signal (the `additive/signal` terms of polyphonic_dag.py:28-37); rows of the
- * controls are [B * P], segment major.  Only oscillators with a non-zero amplitude somewhere in a span are
- * given a lane, so the work follows the number of partials below Nyquist instead of P * H. */
+ * controls are [B * P] segment major (voice_major = 0), or [P * B] voice major (voice_major = 1): the layout the
+ * reference's Parallelizer.unparallelize leaves the merged controls in (sub_modules.py:573-592), so the per-voice
+ * keys `<name>_<i>` can be handed over without a copy.  Only oscillators with a non-zero amplitude somewhere in a
+ * span are given a lane, so the work follows the number of partials below Nyquist instead of P * H. */
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
-                              void* workspace, size_t workspace_bytes, hipStream_t stream);
+                              int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* ---- get_controls ---------------------------------------------------------------------------- */
 
@@ -118,15 +120,16 @@ int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_k
  * srcs = DEVICE array of nsrc device pointers. */
 int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, hipStream_t stream);
 
-/* the whole `add` chain of polyphonic_dag.py:28-37: additive/noise [B,P,N] -> out rows of
- * out_stride floats (noise may be NULL). */
+/* the whole `add` chain of polyphonic_dag.py:28-37: additive/noise [B,P,N] (voice_major = 0) or [P,B,N]
+ * (voice_major = 1) -> out rows of out_stride floats (noise may be NULL). */
 int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
-                         int out_stride, hipStream_t stream);
+                         int out_stride, int voice_major, hipStream_t stream);
 
-/* out[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] ([B,PA,N], [B,PZ,N] -> rows of out_stride floats):
- * the add chain when the additive operand is already the per-segment mix of ddspp_polyphonic_additive. */
+/* out[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] ([B,PA,N], [B,PZ,N], or [PA,B,N], [PZ,B,N] when
+ * voice_major = 1 -> rows of out_stride floats): the add chain when the additive operand is already the
+ * per-segment mix of ddspp_polyphonic_additive. */
 int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out, int B, int N, int out_stride,
-                     hipStream_t stream);
+                     int voice_major, hipStream_t stream);
 
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
@@ -190,6 +193,30 @@ int ddspp_irfft_plan_destroy(ddspp_irfft_plan* plan);
 size_t ddspp_irfft_workspace_bytes(const ddspp_irfft_plan* plan);
 int ddspp_irfft_execute(ddspp_irfft_plan* plan, void* spectrum, float* signal, void* workspace,
                         size_t workspace_bytes, hipStream_t stream);
+
+/* ---- input edge: MIDI piano roll -> polyphonic conditioning (HOST function, CPU buffers) ------- */
+
+/* MIDIRoll2Conditioning, ddsp_piano/utils/midi_encoders.py:4-104 (called from io_utils.py:118-120): a
+ * frame-sequential voice allocator.  roll[n_frames, 88, 2] = (note activity, onset velocity) per key (MIDI
+ * 21..108) -> conditioning[n_frames, n_synths, 2] = (activity * pitch, velocity) per channel, a note keeping its
+ * channel for as long as it sounds; polyphony[n_frames] = sum of the activities.  The allocator state
+ * (assigner, reorder, assigned_pitch -- the reference object's attributes) lives in the handle and carries
+ * over from one call to the next, like the reference object's.  All buffers are HOST memory; the roll is not
+ * modified (the reference multiplies the caller's activity roll by the pitch in place).
+ * Ties: the reference picks the n_synths largest values with an unstable np.argsort; among EQUAL values
+ * (in practice: the silent keys, activity 0) this implementation takes the higher keys -- identical output
+ * whenever equal-valued keys carry equal velocities, which holds for every roll note_seq produces (a silent
+ * key has no onset velocity). */
+typedef struct ddspp_midi_state ddspp_midi_state;
+ddspp_midi_state* ddspp_midi_conditioning_create(int n_synths);            /* NULL + last_error on bad n_synths */
+void ddspp_midi_conditioning_destroy(ddspp_midi_state* state);
+int ddspp_midi_conditioning_reset(ddspp_midi_state* state);                /* state of a fresh object, :16-22 */
+int ddspp_midi_conditioning_get_state(const ddspp_midi_state* state, int* assigner, int* reorder /* [n_synths] */,
+                                      double* assigned_pitch /* [n_synths] */);
+int ddspp_midi_conditioning_run_f64(ddspp_midi_state* state, const double* roll, int n_frames, int n_pitches,
+                                    double* conditioning, double* polyphony);
+int ddspp_midi_conditioning_run_f32(ddspp_midi_state* state, const float* roll, int n_frames, int n_pitches,
+                                    float* conditioning, float* polyphony);
 
 #ifdef __cplusplus
 }

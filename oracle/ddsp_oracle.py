@@ -812,3 +812,87 @@ class SurrogateAdditive(Processor):
                                             harmonic_distribution=harmonic_distribution,
                                             upsampling=int(self.sample_rate / self.frame_rate),
                                             sample_rate=self.sample_rate, use_angular_cumsum=self.inference)
+
+
+# ---------------------------------------------------------------------------------------------
+# Input edge: piano roll -> polyphonic conditioning.
+#
+# *** This part IS pinned ***: ddsp_piano/utils/midi_encoders.py is plain NumPy, so the reference
+# class itself was run in the build container and its inputs/outputs are committed as
+# tests/golden/midi_conditioning.npz (generator: tests/golden/make_golden_midi.py).
+# ---------------------------------------------------------------------------------------------
+
+class MIDIRoll2Conditioning:
+    """Frame-sequential voice allocator, restating ddsp_piano/utils/midi_encoders.py:4-104.
+
+    State (same names as the reference object's attributes): ``assigned_pitch[c]`` = pitch value a
+    channel holds (0 = free), ``assigner`` = next free channel (-1 = none), ``reorder`` = last
+    channel -> sorted-position permutation."""
+
+    def __init__(self, n_synths=16):
+        self.n_synths = int(n_synths)
+        self.pitch_mul = np.arange(21, 21 + 88)                    # :19
+        self.reorder = list(range(self.n_synths))                  # :20
+        self.assigner = 0                                          # :21
+        self.assigned_pitch = [0.0] * self.n_synths                # :22
+
+    def update_assigner(self):                                     # :24-32
+        n = self.n_synths
+        self.assigner = (self.assigner + 1) % n
+        if 0.0 not in self.assigned_pitch:
+            self.assigner = -1
+            return
+        while self.assigned_pitch[self.assigner] != 0.0:
+            self.assigner = (self.assigner + 1) % n
+
+    def __call__(self, roll):
+        roll = np.asarray(roll)
+        n = self.n_synths
+        activity = roll[..., 0]
+        polyphony = np.sum(activity, axis=-1)                      # :47
+        scaled = (activity * self.pitch_mul).astype(roll.dtype)    # :49 (in place in the reference)
+        # :52-55 -- the n largest values per frame, ascending.  Ties (equal values) are resolved by key
+        # number here; the reference leaves them to an unstable argsort (they only matter when equal-valued
+        # keys carry different velocities, which a real roll never has: silent keys have velocity 0).
+        keys = np.argsort(scaled, axis=-1, kind='stable')[:, 88 - n:]
+        top_pitch = np.take_along_axis(scaled, keys, axis=-1)
+        top_vel = np.take_along_axis(roll[..., 1], keys, axis=-1)
+        out = np.zeros((roll.shape[0], n, 2), dtype=roll.dtype)
+        for t in range(roll.shape[0]):
+            pitches = [float(v) for v in top_pitch[t]]
+            held = self.assigned_pitch
+            if t > 0 and set(pitches) == set(held):                # :61-69 nothing started or stopped
+                perm = self.reorder
+            else:
+                perm = [0] * n                                     # :72
+                for c in range(n):                                 # :74-79 channels whose note has ended
+                    if held[c] not in pitches:
+                        held[c] = 0.0
+                        if self.assigner == -1:
+                            self.update_assigner()
+                for c in range(n):                                 # :82-85 sounding notes keep their channel
+                    if pitches[c] != 0.0 and pitches[c] in held:
+                        perm[held.index(pitches[c])] = c
+                for c in range(n):                                 # :88-92 new notes take the next free channel
+                    if pitches[c] not in held:
+                        perm[self.assigner] = c                    # (-1 addresses the last channel, as in NumPy)
+                        held[self.assigner] = pitches[c]
+                        self.update_assigner()
+                for c in range(n):                                 # :95-98 silence fills the free channels
+                    if pitches[c] == 0.0:
+                        perm[self.assigner] = c
+                        self.update_assigner()
+                self.reorder = perm                                # :102
+            out[t, :, 0] = top_pitch[t][perm]                      # :66 / :100
+            out[t, :, 1] = top_vel[t][perm]                        # :67 / :101
+        return out, polyphony
+
+
+def ensure_sequence_length(sequence, length, right=True):
+    """ddsp_piano/utils/io_utils.py:204-224: crop or zero-pad along time, at the end or at the start."""
+    sequence = np.asarray(sequence)
+    n = sequence.shape[0]
+    if n >= length:
+        return sequence[:length] if right else sequence[n - length:]
+    extra = np.zeros((length - n,) + sequence.shape[1:], dtype=sequence.dtype)
+    return np.concatenate([sequence, extra] if right else [extra, sequence], axis=0)

@@ -76,30 +76,59 @@ def test_processor_group_matches_oracle(B, P, T, H, K, S, sr, L):
         assert [p.name for p in pg.processors] == ['additive', 'noise', 'add', 'reverb']
 
 
-def test_fast_path_zero_copy_views_and_no_reverb():
+@pytest.mark.parametrize('voice_major', [False, True])
+@pytest.mark.parametrize('stems', [False, True])
+def test_fast_path_zero_copy_views_and_no_reverb(voice_major, stems):
+    """Per-voice keys that are slices of one buffer are taken without a copy, in both orders: segment major
+    [B, P, T, C] and the reference Parallelizer's voice major [P, B, T, C] (sub_modules.py:573-592)."""
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import polyphonic
     rng = np.random.default_rng(5)
-    B, P, T, H, K, sr = 2, 4, 20, 64, 32, 16000
-    base = {k: torch.as_tensor(rng.normal(0, 1, [B, P, T, c]).astype(np.float32), device='cuda')
+    B, P, T, H, K, sr = 3, 4, 20, 64, 32, 16000
+    lead = (P, B) if voice_major else (B, P)
+    base = {k: torch.as_tensor(rng.normal(0, 1, [*lead, T, c]).astype(np.float32), device='cuda')
             for k, c in (('amplitudes', 1), ('harmonic_distribution', H), ('magnitudes', K))}
-    base['inharm_coef'] = torch.full((B, P, T, 1), 1e-4, device='cuda')
-    base['f0_hz'] = torch.as_tensor(rng.uniform(50, 2000, [B, P, 1, 1]).astype(np.float32), device='cuda').expand(B, P, T, 1).contiguous()
-    feats = {f'{k}_{i}': v[:, i] for k, v in base.items() for i in range(P)}
-    stacked = polyphonic._stack_voices([feats[f'harmonic_distribution_{i}'] for i in range(P)])
-    assert stacked.data_ptr() == base['harmonic_distribution'].data_ptr()      # no copy made
+    base['inharm_coef'] = torch.full((*lead, T, 1), 1e-4, device='cuda')
+    base['f0_hz'] = torch.as_tensor(rng.uniform(50, 2000, [*lead, 1, 1]).astype(np.float32), device='cuda').expand(*lead, T, 1).contiguous()
+    feats = {f'{k}_{i}': (v[i] if voice_major else v[:, i]) for k, v in base.items() for i in range(P)}
+    stacked, vm = polyphonic._stack_voices([feats[f'harmonic_distribution_{i}'] for i in range(P)])
+    assert stacked.data_ptr() == base['harmonic_distribution'].data_ptr() and vm == voice_major   # no copy made
+    assert stacked.shape == (B * P, T, H)
     dag, _ = _build(dp, P, sr, with_reverb=False)
     a = dp.ProcessorGroup(dag, fast_path=True)
     dagb, _ = _build(dp, P, sr, with_reverb=False)
     b = dp.ProcessorGroup(dagb, fast_path=False)
-    noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * 64]).astype(np.float32), device='cuda')
-    a.noise.noise_override = [noise[:, i] for i in range(P)]
-    b.noise.noise_override = [noise[:, i] for i in range(P)]
+    noise = torch.as_tensor(rng.uniform(-1, 1, [P, B, T * 64]).astype(np.float32), device='cuda')
+    a.noise.noise_override = [noise[i] for i in range(P)]
+    b.noise.noise_override = [noise[i] for i in range(P)]
     orig = b.noise.get_signal
     b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
-    ya, yb = a(feats), b(feats)
+    if stems:
+        oa, ob = a(feats, return_outputs_dict=True), b(feats, return_outputs_dict=True)
+        ya, yb = oa['signal'], ob['signal']
+        for name in ('additive', 'noise'):             # the last voice's stems, as the node-by-node walk leaves them
+            assert (oa['controls'][name]['signal'] - ob['controls'][name]['signal']).abs().max().item() < 2e-6
+        voices = oa['controls']['voices']['additive']
+        assert voices.shape == (B, P, T * 64)
+        assert torch.equal(voices[:, P - 1], oa['controls']['additive']['signal'])
+    else:
+        ya, yb = a(feats), b(feats)
     assert ya.shape == (B, T * 64)
     assert (ya - yb).abs().max().item() < 2e-6
+
+
+def test_stack_voices_copies_when_layouts_disagree():
+    from ddsp_piano_amd import polyphonic
+    B, P, T, C = 2, 3, 5, 4
+    x = torch.arange(B * P * T * C, dtype=torch.float32, device='cuda').reshape(B, P, T, C)
+    sep = [x[:, i].clone() for i in range(P)]
+    for vm in (True, False):
+        got, flag = polyphonic._stack_voices(sep, vm)
+        want = x.transpose(0, 1).reshape(P * B, T, C) if vm else x.reshape(B * P, T, C)
+        assert flag == vm and torch.equal(got, want)
+    # a segment-major view asked for in voice-major order has to be re-laid out
+    got, flag = polyphonic._stack_voices([x[:, i] for i in range(P)], True)
+    assert flag is True and torch.equal(got, x.transpose(0, 1).reshape(P * B, T, C))
 
 
 def test_standalone_processors_like_synthesize_from_csv():
@@ -252,8 +281,39 @@ def test_compacted_additive_equals_voice_stems():
                                            B, N, sr, spans=spans)
             assert mix.shape == (B, N)
             assert (mix - stems.sum(dim=1)).abs().max().item() < 3e-6, (B, P, H, S, spans)
+            # the same rows in voice-major order [P, B]: identical lanes, identical arithmetic
+            vm = [x.reshape((B, P) + x.shape[1:]).transpose(0, 1).reshape(x.shape).contiguous()
+                  for x in (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'])]
+            mix_vm = core.polyphonic_additive(*vm, B, N, sr, spans=spans, voice_major=True)
+            assert torch.equal(mix_vm, mix), (B, P, H, S, spans)
     # all voices silent: zeros
     z = torch.zeros(4, 20, 8, device='cuda')
     out = core.polyphonic_additive(torch.full((4, 20, 1), 100.0, device='cuda'), torch.zeros(4, 20, device='cuda'), z, z,
                                    2, 20 * 96, 24000)
     assert out.shape == (2, 1920) and (out == 0).all()
+
+
+def test_parallelizer_views_feed_the_group_without_copies():
+    """The reference hands the group `features[k + '_i'] = features[k][i]` of the merged [P * B, T, C] control
+    tensors (sub_modules.py:584-592): those views are consumed in place and give the same audio as separately
+    allocated per-voice tensors."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import polyphonic
+    rng = np.random.default_rng(21)
+    B, P, T, H, K, sr, L = 2, 5, 30, 128, 96, 24000, 2000
+    per_voice = [synth_controls(rng, B, T, H, S=1, K=K) for _ in range(P)]
+    merged = {k: torch.as_tensor(np.ascontiguousarray(np.concatenate([c[k] for c in per_voice], axis=0)), device='cuda')
+              for k in ('f0_hz', 'inharm_coef', 'amplitudes', 'harmonic_distribution', 'magnitudes')}
+    par = dp.Parallelizer(n_synths=P)
+    par.batch_size = B
+    feats = par(dict(merged), parallelize=False)
+    feats['reverb_ir'] = torch.as_tensor(synth_ir(rng, B, L), device='cuda')
+    rows, vm = polyphonic._stack_voices([feats[f'harmonic_distribution_{i}'] for i in range(P)])
+    assert vm is True and rows.data_ptr() == merged['harmonic_distribution'].data_ptr()
+    separate = {k: (v.clone() if k[-1].isdigit() else v) for k, v in feats.items() if k not in merged}
+    outs = []
+    for f in (feats, separate):
+        dag, noise = _build(dp, P, sr)
+        noise.seed = 11
+        outs.append(dp.ProcessorGroup(dag)({k: v for k, v in f.items() if k not in merged}))
+    assert outs[0].shape == (B, T * 96) and torch.equal(outs[0], outs[1])

@@ -33,7 +33,7 @@ def test_processor_call_protocol():
     p = Gain(2.0, 'g')
     x = torch.arange(6, dtype=torch.float64).reshape(2, 3)
     y = p(x)
-    assert y.dtype == torch.float32 and torch.equal(y, x.float() * 2)
+    assert y.dtype == torch.float32 and torch.equal(y.cpu(), x.float() * 2)     # (inputs move to the GPU if there is one)
     d = p(x, return_outputs_dict=True)
     assert set(d) == {'signal', 'controls'} and set(d['controls']) == {'x'}
 
@@ -43,9 +43,9 @@ def test_processor_group_walks_dag_with_nested_keys():
     pg = dp.ProcessorGroup([(a, ['in']), (b, ['a/signal']), (a, ['b/signal']), (s, ['a/signal', 'b/controls/x'])])
     x = torch.ones(1, 4)
     out = pg({'in': x}, return_outputs_dict=True)
-    assert torch.equal(out['signal'], x * 12 + x * 2)        # a re-used: outputs['a'] overwritten
+    assert torch.equal(out['signal'].cpu(), x * 12 + x * 2)        # a re-used: outputs['a'] overwritten
     ctl = out['controls']
-    assert ctl['out'] is ctl['sum'] and torch.equal(ctl['in'], x) and 'inputs' in ctl
+    assert ctl['out'] is ctl['sum'] and torch.equal(ctl['in'].cpu(), x) and 'inputs' in ctl
     assert [p.name for p in pg.processors] == ['a', 'b', 'sum'] and pg.a is a
     assert torch.equal(pg({'in': x}), out['signal'])
     assert torch.equal(pg.get_signal(pg.get_controls({'in': x})), out['signal'])
@@ -87,8 +87,10 @@ def test_fast_path_recognition():
 def test_stack_voices_zero_copy_on_cpu_falls_back_to_copy():
     base = torch.randn(2, 3, 5, 4)
     views = [base[:, i] for i in range(3)]
-    st = polyphonic._stack_voices(views)
-    assert st.shape == (2, 3, 5, 4) and torch.equal(st, base)
+    st, vm = polyphonic._stack_voices(views)            # CPU tensors: copied, voice major by default
+    assert vm is True and st.shape == (6, 5, 4) and torch.equal(st.cpu(), base.transpose(0, 1).reshape(6, 5, 4))
+    st, vm = polyphonic._stack_voices(views, False)
+    assert vm is False and torch.equal(st.cpu(), base.reshape(6, 5, 4))
 
 
 def test_tables_match_the_oracle():
@@ -181,3 +183,29 @@ def test_shard_ranges():
     assert sh['a_0'].shape == (2, 5, 1) and sh['reverb_ir'].shape == (2, 100) and sh['flag'] == 3
     with pytest.raises(ValueError):
         parallel.shard_features({'a': torch.zeros(8, 1), 'b': torch.zeros(6, 1)}, 2, 0)
+
+
+def test_parallelizer_merges_and_unmerges_like_the_reference():
+    """sub_modules.py:527-602: globals are repeated / transposed into [P * B, ...]; mono keys come back as
+    per-voice VIEWS of the merged buffer."""
+    P, B, T = 3, 2, 5
+    par = dp.Parallelizer(n_synths=P)
+    feats = {'conditioning': torch.arange(B * T * P * 2, dtype=torch.float32).reshape(B, T, P, 2),
+             'context': torch.randn(B, T, 7), 'global_inharm': torch.randn(B, T), 'global_detuning': torch.randn(B, T)}
+    cond0, ctx0 = feats['conditioning'].clone(), feats['context'].clone()
+    out = par(dict(feats), parallelize=True)
+    assert par.batch_size == B
+    assert out['conditioning'].shape == (P * B, T, 2) and out['context'].shape == (P * B, T, 7)
+    assert out['global_inharm'].shape == (P * B, T)
+    for i in range(P):                                  # voice-major rows: [i * B, (i + 1) * B) is voice i
+        assert torch.equal(out['conditioning'][i * B:(i + 1) * B], cond0[:, :, i])
+        assert torch.equal(out['context'][i * B:(i + 1) * B], ctx0)
+    merged = {k: torch.randn(P * B, T, c) for k, c in (('f0_hz', 1), ('inharm_coef', 1), ('amplitudes', 1),
+                                                       ('harmonic_distribution', 8), ('magnitudes', 4))}
+    keep = {k: v for k, v in merged.items()}
+    un = par(dict(merged), parallelize=False)
+    for k, v in keep.items():
+        assert un[k].shape == (P, B) + tuple(v.shape[1:])
+        for i in range(P):
+            assert torch.equal(un[f'{k}_{i}'], v[i * B:(i + 1) * B])
+            assert un[f'{k}_{i}'].data_ptr() == v[i * B:(i + 1) * B].data_ptr()       # a view, not a copy
