@@ -14,10 +14,10 @@
 //   fir_from_magnitudes_kernel : ir[r, t, :] = magnitudes[r, t, :] @ M, M = the (windowed,
 //       shifted) inverse real DFT matrix [K, Lw] built by the host in float64.  Lane = tap, the
 //       tap's column of M lives in registers, the frame's magnitudes arrive through scalar loads.
-//   tv_fir_kernel : gather form, one wavefront per 512 output samples.  Lane a owns 4 consecutive
-//       outputs; noise samples are wave-uniform scalars (s_load), the frame FIRs are staged in LDS
-//       and read as aligned 16-byte blocks that slide by one block per 4 input samples
-//       (16 FMAs per ds_read_b128).
+//   tv_fir_kernel : gather form, one workgroup per 2048 (or 1024) output samples of a row.  The frame FIRs
+//       and the noise window are staged in LDS once per workgroup; a lane owns 16 consecutive outputs and
+//       a quarter of the input blocks that reach them: 64 FMAs per six conflict-free ds_read_b128, the four
+//       partial sums meet in registers (two __shfl_xor rounds).
 //   tv_fir_generic_kernel : thread-per-output fallback for shapes the tiled kernel does not take.
 //   uniform_noise_kernel : Philox4x32-10 counter based U(-1, 1) noise (the reference draws an
 //       unseeded tf.random.uniform; parity is defined with the noise tensor supplied).
@@ -144,61 +144,67 @@ __global__ void __launch_bounds__(256) fir_from_magnitudes_generic_kernel(const 
 // ------------------------------------------------------------------------------------------------
 // time-varying FIR, tiled
 // ------------------------------------------------------------------------------------------------
-constexpr int FIR_W = 512;          // outputs per wavefront
-constexpr int FIR_PASS = 256;       // outputs per pass (64 lanes x 4)
-constexpr int FIR_MAX_FRAMES = 80;  // frames staged per workgroup
-constexpr int FIR_BW = 4 * FIR_W;    // outputs per workgroup
-constexpr int FIR_G_FLOATS = 7168;   // per workgroup: staged frame FIRs
-constexpr int FIR_X_FLOATS = 2432;   // per workgroup: staged noise window incl. zero blocks around the signal
+constexpr int FIR_OPL = 16;          // consecutive outputs per lane
+constexpr int FIR_PASS = 16 * FIR_OPL;  // outputs per wavefront pass: 16 output groups x 4 input segments = 64 lanes
+constexpr int FIR_G_FLOATS = 6400;   // per workgroup: staged frame FIRs (zero padded images)
+constexpr int FIR_X_FLOATS = 2880;   // per workgroup: staged noise window (one pad block after every four)
+// 37 KB of LDS per workgroup: four workgroups (16 wavefronts) per CU.
+
+// LDS float offset of noise block bb (blocks of 4 samples, counted from the first staged one).  A 16-lane
+// ds_read_b128 service group reads the blocks B, B + 4, ..., B + 60: with one pad block after every four
+// they land 5 blocks apart, i.e. on 16 different bank quads (5 is coprime with 16) -- conflict free.
+__device__ __forceinline__ int fir_xoff(int bb) { return 4 * (bb + (bb >> 2)); }
 
 __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x,   // [R, N]
                                                    const float* __restrict__ ir,  // [R, T, Lw]
                                                    float* __restrict__ out,       // [R, N]
                                                    int R, int N, int T, int U, int Lw, int delay,
-                                                   int windows_per_row, int padl, int nb, int seglen) {
-    // One workgroup = FIR_BW consecutive outputs of one row: the frame FIRs and the noise samples that
-    // reach them are staged ONCE for the four wavefronts (each then owns FIR_W outputs), which cuts
-    // the re-read of impulse responses shared by neighbouring windows from 1.9x to 1.2x.
-    __shared__ __attribute__((aligned(16))) float lds[FIR_G_FLOATS + FIR_X_FLOATS + 4 * 256];
+                                                   int windows_per_row, int bw, int padl, int nb, int seglen,
+                                                   int dc) {
+    // One workgroup = bw consecutive outputs of one row: the frame FIRs and the noise samples that reach
+    // them are staged ONCE for the four wavefronts (each then owns bw / 4 outputs).
+    __shared__ __attribute__((aligned(16))) float lds[FIR_G_FLOATS + FIR_X_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int row = blockIdx.x / windows_per_row;
-    const int nB0 = (blockIdx.x - row * windows_per_row) * FIR_BW;
-    const int n0 = nB0 + wib * FIR_W;             // this wavefront's outputs
+    const int nB0 = (blockIdx.x - row * windows_per_row) * bw;
+    const int wlen = bw / 4;                      // outputs per wavefront
+    const int n0 = nB0 + wib * wlen;
     float* G = lds;
     float* Xs = G + FIR_G_FLOATS;
-    float* red = Xs + FIR_X_FLOATS + wib * 256;
-    const int gstride = nb * 4;                   // floats per staged frame
+    const int gstride = nb * 4;                   // floats per staged frame (<= 256)
 
     // frames whose noise blocks can reach this workgroup's outputs
     const int j_first = max(nB0 + delay - (Lw - 1), 0);
-    const int j_last = min(nB0 + FIR_BW - 1 + delay, N - 1);
+    const int j_last = min(nB0 + bw - 1 + delay, N - 1);
     const int f_lo = j_first / U;
     const int f_hi = min(j_last / U, T - 1);
     const int nfr = f_hi - f_lo + 1;
-    // input blocks (of 4 samples) any lane may touch: zero outside the signal, so the inner loop
-    // needs no bounds logic at all
-    const int jb_min = (nB0 + delay + 3) / 4 - 4 * seglen;           // may be negative
-    const int jb_max = (nB0 + FIR_BW - 64 + delay + 3) / 4 + 15;
+    // input blocks (of 4 samples) any lane may touch: zero outside the signal, so the inner loop needs no
+    // bounds logic at all
+    const int jb_base = (nB0 + delay + 3) / 4;
+    const int jb_min = jb_base + 4 - 4 * seglen;                     // may be negative
+    const int nxb = bw / 4 + 4 * seglen - 4;                         // staged blocks: jb_min .. jb_base + bw / 4 - 1
     // Staging: every load is issued before the first LDS store (branch-free clamped addresses), so a
     // wavefront pays the HBM/L2 latency once per batch of loads instead of once per load.
     {
-        constexpr int XL = (FIR_X_FLOATS + 255) / 256;
-        const float* xg = x + (size_t)row * N;
-        const int nx = (jb_max - jb_min + 1) * 4;
-        const int j0 = 4 * jb_min;
-        float xv[XL];
+        constexpr int XL = 3;                                       // 16-byte blocks per thread (nxb <= 768)
+        const float4* xg = reinterpret_cast<const float4*>(x + (size_t)row * N);
+        const int nblk = N / 4;
+        float4 xv[XL];
 #pragma unroll
-        for (int u = 0; u < XL; ++u) xv[u] = xg[min(max(j0 + (int)threadIdx.x + 256 * u, 0), N - 1)];
+        for (int u = 0; u < XL; ++u) xv[u] = xg[min(max(jb_min + (int)threadIdx.x + 256 * u, 0), nblk - 1)];
 #pragma unroll
         for (int u = 0; u < XL; ++u) {
-            const int q = threadIdx.x + 256 * u, j = j0 + q;
-            if (q < nx) Xs[q] = (j >= 0 && j < N) ? xv[u] : 0.0f;
+            const int bb = threadIdx.x + 256 * u, jb = jb_min + bb;
+            if (bb < nxb)
+                *reinterpret_cast<float4*>(Xs + fir_xoff(bb)) =
+                    (jb >= 0 && jb < nblk) ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     {
         constexpr int FB = 4;                       // frames per batch (per wavefront)
-        constexpr int QL = 5;                       // 64-lane strips per staged frame (gstride <= 320)
+        constexpr int QL = 4;                       // 64-lane strips per staged frame (gstride <= 256)
         for (int f0 = wib * FB; f0 < nfr; f0 += 4 * FB) {
             float gv[FB][QL];
 #pragma unroll
@@ -223,23 +229,21 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
     }
     __syncthreads();
 
-    // ---- compute: 64 outputs per pass.  Lane = (output block a, input segment sg): the ~(Lw + 6) / 4
-    // input blocks that reach output block a are split over four lanes, so every FMA carries a tap
-    // inside (or one block around) the FIR's support.  The lane -> (sg, a) map follows the way the LDS
-    // services a ds_read_b128 (four fixed groups of 16 lanes): each group is one segment, so its 16
-    // noise blocks are consecutive (conflict free) and its tap block is one address (broadcast).
+    // ---- compute: 256 outputs per pass.  Lane = (output group a, input segment sg): lane (a, sg) owns the 16
+    // consecutive outputs of group a and the sg-th quarter of the ~(Lw + 18) / 4 input blocks that reach them.
+    // Per step it takes one input block (4 samples) and the 19 taps that connect it to its 16 outputs: 64 FMAs
+    // for six 16-byte LDS reads.  The lane -> (sg, a) map follows the way the LDS services a ds_read_b128 (four
+    // fixed groups of 16 lanes): a group is one segment, so its tap reads are one address (broadcast) and its 16
+    // noise blocks are 4 apart (conflict free through fir_xoff).
     const int bpf = U / 4;                               // input blocks per frame
     const int h = lane >> 5, w = lane & 31;
     const bool g0 = (w < 4) || (w >= 12 && w < 16) || (w >= 20 && w < 28);
     const int sg = 2 * h + (g0 ? 0 : 1);
     const int a = g0 ? (w < 4 ? w : (w < 16 ? w - 8 : w - 12)) : (w < 12 ? w - 4 : (w < 20 ? w - 8 : w - 16));
-    for (int ps = 0; ps < FIR_W / 64; ++ps) {
-        const int np0 = n0 + ps * 64;
-        if (np0 >= N) break;
+    const int bq0 = 4 * (dc - 3 + sg * seglen);          // float offset of the first tap block at step 0
+    for (int np0 = n0; np0 < min(n0 + wlen, N); np0 += FIR_PASS) {
         const int m0 = np0 + delay;
-        const int c0 = (m0 - 3 + padl) / 4;              // exact: (delay - 3 + padl) % 4 == 0, np0 % 4 == 0
-        const int jb = (m0 + 3) / 4 + a - sg * seglen;   // first (highest) input block of this lane
-        const int bq0 = 4 * (c0 + a - jb);               // float offset of the lower tap block; >= 0, same for all a
+        const int jb = (m0 + 3) / 4 + 4 * a + 3 - sg * seglen;   // first (highest) input block of this lane
         // A lane's seglen (<= U / 4) input blocks lie in at most two frames: the first n1 steps use the
         // frame of jb, the rest the frame before it.  Both tap pointers are per-lane constants, the
         // loop body is branch free (one select per step) and carries no state between steps.
@@ -248,39 +252,52 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
         const int n1 = jb - fA * bpf + 1;                // blocks past the end of the signal count as its last frame
         const float* GA = G + (fA - f_lo) * gstride + bq0;
         const float* GB = G + (max(fA - 1, f_lo) - f_lo) * gstride + bq0;
-        const float* xp = Xs + 4 * (jb - jb_min);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int i = 0; i < seglen; ++i) {
+        const int bb0 = jb - jb_min;
+        float acc[FIR_OPL];
+#pragma unroll
+        for (int e = 0; e < FIR_OPL; ++e) acc[e] = 0.f;
+        // software pipelined: the six LDS reads of step i + 1 are in flight while the 64 FMAs of step i issue
+        float4 tq[5], xq;
+        auto fetch = [&](int i) {
             const float* gp = (i < n1 ? GA : GB) + 4 * i;
-            const float4 lo = *reinterpret_cast<const float4*>(gp);
-            const float4 hi = *reinterpret_cast<const float4*>(gp + 4);
-            const float4 xv = *reinterpret_cast<const float4*>(xp - 4 * i);
-            const float tp[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int q = 0; q < 5; ++q) tq[q] = *reinterpret_cast<const float4*>(gp + 4 * q);
+            xq = *reinterpret_cast<const float4*>(Xs + fir_xoff(bb0 - i));
+        };
+        fetch(0);
+#pragma unroll 1
+        for (int i = 0; i < seglen; ++i) {
+            float tp[20];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
-        }
-        // meet the four segments of each output block
-        *reinterpret_cast<float4*>(red + (sg * 16 + a) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 16) {
-            float4 s0 = *reinterpret_cast<const float4*>(red + lane * 4);
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(red + (k * 16 + lane) * 4);
-                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            for (int q = 0; q < 5; ++q) {
+                tp[4 * q] = tq[q].x; tp[4 * q + 1] = tq[q].y; tp[4 * q + 2] = tq[q].z; tp[4 * q + 3] = tq[q].w;
             }
-            const int n = np0 + 4 * lane;
-            if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = s0;
+            asm volatile("" ::"v"(tp[19]));   // keep the fifth read 16 bytes wide: ds_read_b96 costs 8 LDS cycles, b128 4
+            const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
+            fetch(min(i + 1, seglen - 1));
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int e = 0; e < FIR_OPL; ++e) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // meet the four segments of each output group (reduce-scatter in registers): the lane pairs (l, l ^ 32)
+        // and (l, l ^ 4) hold the same group a; each lane ends up with the 4 outputs 4 sg .. 4 sg + 3 of the group
+        float half[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float keep = h ? acc[8 + k] : acc[k];
+            const float send = h ? acc[k] : acc[8 + k];
+            half[k] = keep + __shfl_xor(send, 32);
+        }
+        float quad[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float keep = g0 ? half[k] : half[4 + k];
+            const float send = g0 ? half[4 + k] : half[k];
+            quad[k] = keep + __shfl_xor(send, 4);
+        }
+        const int n = np0 + FIR_OPL * a + 4 * sg;
+        if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = make_float4(quad[0], quad[1], quad[2], quad[3]);
     }
 }
 
@@ -400,25 +417,35 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     const int U = N / T;
     const int delay = delay_compensation < 0 ? (Lw - 1) / 2 - 1 : delay_compensation;
     DDSPP_REQUIRE(delay >= 0, "time_varying_fir: negative delay");
-    // tap t of a frame sits at float padl + t of its staged image; padl makes (delay - 3 + padl) a
-    // multiple of 4 (aligned 16-byte tap blocks) and leaves >= 2 zero blocks in front, nb leaves zero
-    // blocks behind for every block index the inner loop can form (no clamping in the loop)
-    const int padl = 8 + ((3 - (delay % 4)) % 4 + 4) % 4;
-    const int seglen = (((Lw + 6) / 4 + 1) + 3) / 4;
+    // Tiled kernel geometry (see tv_fir_kernel).  Tap t of a frame sits at float padl + t of its staged image;
+    // padl makes (delay - 3 + padl) a multiple of 4 (aligned 16-byte tap blocks) and puts enough zero blocks in
+    // front that segment 0 starts at block dc - 3 >= 0; nb leaves zero blocks behind for every block index the
+    // inner loop can form (no clamping in the loop).
+    int padl = 18 - (delay + 3) % 4;
+    while ((delay - 3 + padl) % 4 != 0) ++padl;
+    const int dc = (padl - 6 + (delay + 3) % 4) / 4;
+    const int seglen = (((Lw + FIR_OPL - 1 + 3 + 3) / 4) + 3) / 4;       // steps per lane: a quarter of the input blocks
     const int nb_need = (padl + Lw + 3) / 4 + 1;
-    const int nb = (4 * seglen + 4 > nb_need ? 4 * seglen + 4 : nb_need) + 1;
-    const int frames_max = (FIR_BW + Lw + U - 2) / U + 2;
-    const bool tiled = (U % 4 == 0) && (N % 4 == 0) && ((uintptr_t)audio % 16 == 0) &&
-                       ((uintptr_t)out % 16 == 0) && frames_max <= FIR_MAX_FRAMES &&
-                       frames_max * nb * 4 <= FIR_G_FLOATS && (FIR_BW / 4 + 16 + 4 * seglen + 2) * 4 <= FIR_X_FLOATS &&
-                       nb * 4 <= 320 && seglen <= U / 4 &&
+    const int nb = (dc + 4 * seglen + 2 > nb_need ? dc + 4 * seglen + 2 : nb_need);
+    // outputs per workgroup: 2048, or 1024 when the frames are short (more of them per window)
+    int bw = 0;
+    for (int cand : {2048, 1024}) {
+        const int frames_max = (cand + Lw + U - 2) / U + 2;
+        const int nxb = cand / 4 + 4 * seglen - 4;
+        if (frames_max * nb * 4 <= FIR_G_FLOATS && (nxb + nxb / 4 + 2) * 4 <= FIR_X_FLOATS && nxb <= 768) {
+            bw = cand;
+            break;
+        }
+    }
+    const bool tiled = bw > 0 && (U % 4 == 0) && (N % 4 == 0) && ((uintptr_t)audio % 16 == 0) &&
+                       ((uintptr_t)out % 16 == 0) && dc >= 3 && nb * 4 <= 256 && seglen <= U / 4 &&
                        !env_int("DDSPP_FIR_GENERIC", 0);
     if (tiled) {
-        const int wpr = (N + FIR_BW - 1) / FIR_BW;
+        const int wpr = (N + bw - 1) / bw;
         const long long tasks = (long long)R * wpr;
         DDSPP_REQUIRE(tasks < (1ll << 31), "time_varying_fir: too many tasks");
         hipLaunchKernelGGL(tv_fir_kernel, dim3((unsigned)tasks), dim3(256), 0, stream, audio,
-                           impulse_response, out, R, N, T, U, Lw, delay, wpr, padl, nb, seglen);
+                           impulse_response, out, R, N, T, U, Lw, delay, wpr, bw, padl, nb, seglen, dc);
     } else {
         hipLaunchKernelGGL(tv_fir_generic_kernel, dim3(stream_grid((size_t)R * N)), dim3(256), 0, stream,
                            audio, impulse_response, out, R, N, T, U, Lw, delay);
