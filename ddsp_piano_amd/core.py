@@ -558,8 +558,11 @@ def surrogate_harmonic_synthesis(frequencies, amplitudes, decays=None, decay_tim
 # ----------------------------------------------------------------------------------------------------
 # FilteredNoise: impulse responses and the time-varying FIR
 # ----------------------------------------------------------------------------------------------------
-def frequency_impulse_response(magnitudes, window_size=0):
-    """ddsp.core.frequency_impulse_response: [..., K] magnitudes -> [..., Lw] causal linear-phase FIRs."""
+def frequency_impulse_response(magnitudes, window_size=0, raw_scale=None):
+    """ddsp.core.frequency_impulse_response: [..., K] magnitudes -> [..., Lw] causal linear-phase FIRs.
+
+    raw_scale = (kind, bias, params) of scale_kind(): ``magnitudes`` are raw network outputs and
+    scale_fn(magnitudes + bias) (FilteredNoise.get_controls) is applied inside the design kernel."""
     mags = tf_float32(magnitudes)
     k = int(mags.shape[-1])
     eo = fir_eo_tables(k, int(window_size), mags.device) if mags.data_ptr() % 16 == 0 else None
@@ -567,9 +570,17 @@ def frequency_impulse_response(magnitudes, window_size=0):
         ce, co, idx, we, wo, nj, lw = eo
         frames = mags.numel() // k
         ir = torch.empty(tuple(mags.shape[:-1]) + (lw,), dtype=torch.float32, device=mags.device)
+        if raw_scale is None:
+            code, bias, prm = -1, 0.0, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0)
+        else:
+            code, bias, prm = raw_scale
         _lib.check(_lib_().ddspp_fir_from_magnitudes_eo(_ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we),
-                                                        _ptr(wo), _ptr(ir), frames, k, lw, nj, _stream()))
+                                                        _ptr(wo), _ptr(ir), frames, k, lw, nj, int(code), float(bias),
+                                                        prm['exponent'], prm['max_value'], prm['threshold'],
+                                                        prm['gain'], _stream()))
         return ir
+    if raw_scale is not None:
+        mags = scale_bias(mags, *raw_scale)
     m, uniq, mirror = fir_matrix(k, int(window_size), mags.device)
     lw = int(m.shape[1])
     frames = mags.numel() // k
@@ -577,6 +588,15 @@ def frequency_impulse_response(magnitudes, window_size=0):
     _lib.check(_lib_().ddspp_fir_from_magnitudes(_ptr(mags), _ptr(m), _ptr(uniq), _ptr(mirror),
                                                  int(uniq.numel()), _ptr(ir), frames, k, lw, _stream()))
     return ir
+
+
+def scale_bias(x, code, bias, prm):
+    """scale_fn(x + bias) for the library's scale functions (ddspp_scale_bias)."""
+    x = tf_float32(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib_().ddspp_scale_bias(_ptr(x), _ptr(out), x.numel(), float(bias), int(code), prm['exponent'],
+                                        prm['max_value'], prm['threshold'], prm['gain'], _stream()))
+    return out
 
 
 def get_fft_size(frame_size, ir_size, power_of_2=True):
@@ -679,9 +699,9 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
     return out if padded == audio_size else out[:, :audio_size].contiguous()
 
 
-def frequency_filter(audio, magnitudes, window_size=0, padding='same'):
+def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale=None):
     """ddsp.core.frequency_filter -- call site filtered_noise_synth.py:41-42."""
-    impulse_response = frequency_impulse_response(magnitudes, window_size=window_size)
+    impulse_response = frequency_impulse_response(magnitudes, window_size=window_size, raw_scale=raw_scale)
     return fft_convolve(audio, impulse_response, padding=padding)
 
 

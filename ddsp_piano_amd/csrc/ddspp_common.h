@@ -56,6 +56,43 @@ extern "C" void ddspp_set_error(const char* fmt, ...);
 namespace ddspp {
 
 // ------------------------------------------------------------------------------------------
+// scale functions of the processors' get_controls (ddsp.core.exp_sigmoid, inharm_synth.py:13-17 exp_tanh)
+// ------------------------------------------------------------------------------------------
+enum { SCALE_NONE = 0, SCALE_EXP_SIGMOID = 1, SCALE_EXP_TANH = 2 };
+
+struct ScaleFn {
+    int kind;
+    float log_exponent;   // float32(log(exponent))
+    float max_value;
+    float threshold;
+    float gain;           // exp_tanh only
+};
+
+// exp / log through the hardware v_exp_f32 / v_log_f32 (base 2, ~1 ulp): the scale functions shape
+// amplitudes, never phases, and TF's own sigmoid / pow are a few ulp from correctly rounded anyway.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+__device__ __forceinline__ float fast_pow(float b, float e) {      // b >= 0
+    return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(b));
+}
+
+__device__ __forceinline__ float apply_scale(const ScaleFn& s, float x) {
+    if (s.kind == SCALE_EXP_SIGMOID) {
+        // max_value * sigmoid(x) ** log(exponent) + threshold          (ddsp.core.exp_sigmoid)
+        const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-x));
+        return s.max_value * fast_pow(sg, s.log_exponent) + s.threshold;
+    }
+    if (s.kind == SCALE_EXP_TANH) {
+        // max_value * (0.5 * (tanh(gain * x) + 1)) ** log(exponent) + threshold   (inharm_synth.py:13-17)
+        // 0.5 * (tanh(y) + 1) == sigmoid(2 y)
+        const float pt = __builtin_amdgcn_rcpf(1.0f + fast_exp(-2.0f * (s.gain * x)));
+        return s.max_value * fast_pow(pt, s.log_exponent) + s.threshold;
+    }
+    return x;
+}
+
+
+
+// ------------------------------------------------------------------------------------------
 // Correctly rounded x / d for a constant d, given rd = RN(1/d)  (Markstein's correction step).
 //   q  = RN(x * rd)           faithful quotient
 //   r  = x - q * d            exact in one FMA

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ m
                                                    const float* __restrict__ tap_we,   // [NJ, 4]
                                                    const float* __restrict__ tap_wo,   // [NJ, 4]
                                                    float* __restrict__ ir, int frames, int Lw, int NJ,
-                                                   int frames_per_block) {
+                                                   int frames_per_block, float bias, ScaleFn scale) {
     extern __shared__ __attribute__((aligned(16))) float mtile[];       // [frames_per_block][2 KH]
     constexpr int K = 2 * KH;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -105,7 +105,15 @@ __global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ m
         const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
         float4* dst = reinterpret_cast<float4*>(mtile);
         const int n4 = nf * (K / 4);
-        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+        if (scale.kind < 0) {
+            for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+        } else {      // raw network outputs: FilteredNoise.get_controls' scale_fn(magnitudes + initial_bias) on the way in
+            for (int i = threadIdx.x; i < n4; i += 256) {
+                const float4 m = src[i];
+                dst[i] = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
+                                     apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+            }
+        }
     }
     __syncthreads();
     for (int f = wib; f < nf; f += 4) {
@@ -455,11 +463,15 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
 }
 
 // Same operator through the even/odd tables (host: ddsp_piano_amd/core.py::_fir_eo_tables);
-// K must be even and a multiple of 4, NJ <= 64.
+// K must be even and a multiple of 4, NJ <= 64.  scale_kind >= 0: `magnitudes` are the raw network outputs and
+// FilteredNoise.get_controls' scale_fn(magnitudes + bias) is applied on the way in (saves one HBM round trip
+// of the [frames, K] tensor); scale_kind = -1: magnitudes are used as given.
 int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
                                  const float* tap_we, const float* tap_wo, float* ir, size_t frames, int K,
-                                 int Lw, int NJ, hipStream_t stream) {
+                                 int Lw, int NJ, int scale_kind, float bias, float exponent, float max_value,
+                                 float threshold, float gain, hipStream_t stream) {
     DDSPP_REQUIRE(magnitudes && CE && CO && tap_idx && tap_we && tap_wo && ir, "fir_from_magnitudes_eo: null buffer");
+    DDSPP_REQUIRE(scale_kind >= -1 && scale_kind <= 2, "fir_from_magnitudes_eo: unknown scale_fn %d", scale_kind);
     DDSPP_REQUIRE(K > 0 && K % 4 == 0 && NJ > 0 && NJ <= 64 && Lw > 0, "fir_from_magnitudes_eo: bad dims");
     DDSPP_REQUIRE(K == 32 || K == 64 || K == 96 || K == 128, "fir_from_magnitudes_eo: unsupported band count %d", K);
     DDSPP_REQUIRE(frames < (1ull << 31), "fir_from_magnitudes_eo: too many frames");
@@ -469,10 +481,11 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
     const dim3 grid((unsigned)((frames + fpb - 1) / fpb)), block(256);
     const size_t lds = (size_t)fpb * K * sizeof(float);
     const int nf = (int)frames;
-    if (K == 32) hipLaunchKernelGGL(fir_eo_kernel<16>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
-    else if (K == 64) hipLaunchKernelGGL(fir_eo_kernel<32>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
-    else if (K == 96) hipLaunchKernelGGL(fir_eo_kernel<48>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
-    else hipLaunchKernelGGL(fir_eo_kernel<64>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb);
+    const ScaleFn sfn{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
+    if (K == 32) hipLaunchKernelGGL(fir_eo_kernel<16>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
+    else if (K == 64) hipLaunchKernelGGL(fir_eo_kernel<32>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
+    else if (K == 96) hipLaunchKernelGGL(fir_eo_kernel<48>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
+    else hipLaunchKernelGGL(fir_eo_kernel<64>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

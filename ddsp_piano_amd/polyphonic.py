@@ -152,7 +152,8 @@ def run(plan, inputs, noise=None, need_stems=True):
                                                      ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
                                                      additive.sample_rate, additive.inference)
     # --- noise branch ---------------------------------------------------------------------------
-    nctl = noise_p.get_controls(mags)
+    fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
+    nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
     if noise is None:
         override = getattr(noise_p, 'noise_override', None)
         if override:
@@ -160,7 +161,10 @@ def run(plan, inputs, noise=None, need_stems=True):
     if noise is None:
         noise = noise_p.draw_noise(R, N, dev)
     noise = core.tf_float32(noise).reshape(R, N)
-    noise_sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
+    if fuse_scale:
+        noise_sig = core.frequency_filter(noise, mags, window_size=noise_p.window_size, raw_scale=noise_p.raw_scale())
+    else:
+        noise_sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
 
     # --- add chain ------------------------------------------------------------------------------
     dry = torch.empty((B, N), dtype=torch.float32, device=dev)

@@ -186,20 +186,22 @@ class FilteredNoise(Processor):
         self.seed = seed
         self._calls = itertools.count()
 
+    def raw_scale(self):
+        """(kind, bias, params) when scale_fn is one of the library's (so get_controls can be fused into the FIR
+        design kernel), else None."""
+        if self.scale_fn is None:
+            return None
+        kind = core.scale_kind(self.scale_fn)
+        return None if kind is None else (kind[0], float(self.initial_bias), kind[1])
+
     def get_controls(self, magnitudes):
         magnitudes = core.tf_float32(magnitudes)
         if self.scale_fn is not None:
-            kind = core.scale_kind(self.scale_fn)
-            if kind is None:
+            rs = self.raw_scale()
+            if rs is None:
                 magnitudes = core.tf_float32(self.scale_fn(magnitudes + self.initial_bias))
             else:
-                code, prm = kind
-                out = torch.empty_like(magnitudes)
-                _lib.check(_lib_().ddspp_scale_bias(_ptr(magnitudes), _ptr(out), magnitudes.numel(),
-                                                    float(self.initial_bias), code, prm['exponent'],
-                                                    prm['max_value'], prm['threshold'], prm['gain'],
-                                                    _stream()))
-                magnitudes = out
+                magnitudes = core.scale_bias(magnitudes, *rs)
         return {'magnitudes': magnitudes}
 
     def _n_samples(self, magnitudes):

@@ -141,10 +141,14 @@ int ddspp_fir_from_magnitudes(const float* magnitudes, const float* M, const int
 
 /* The same operator for the full-window case (2 (K - 1) <= window_size), through the even/odd split of
  * the inverse real DFT: CE/CO[K/2, NJ] cosine tables, tap_idx/tap_we/tap_wo[NJ, 4]: the up-to-four taps
- * lane j produces and their weights, ir[tap] = we * E[j] + wo * O[j]. */
+ * lane j produces and their weights, ir[tap] = we * E[j] + wo * O[j].
+ * scale_kind 0 / 1 / 2 (none / exp_sigmoid / exp_tanh, as ddspp_scale_bias): `magnitudes` are the raw network
+ * outputs and FilteredNoise.get_controls' scale_fn(magnitudes + bias) is applied on the way in;
+ * scale_kind -1: magnitudes are used as given (bias and the scale parameters are ignored). */
 int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
                                  const float* tap_we, const float* tap_wo, float* ir, size_t frames, int K,
-                                 int Lw, int NJ, hipStream_t stream);
+                                 int Lw, int NJ, int scale_kind, float bias, float exponent, float max_value,
+                                 float threshold, float gain, hipStream_t stream);
 
 /* ddsp.core.fft_convolve(audio[R,N], impulse_response[R,T,Lw], padding='same', delay_compensation)
  * in the framed case (frame = hop = N / T); reached from filtered_noise_synth.py:41-42 through

@@ -145,3 +145,29 @@ def test_fdn_apply_and_fft_convolve_valid():
         core.fft_convolve(_dev(audio), _dev(np.zeros([3, 10], np.float32)))
     with pytest.raises(ValueError):
         core.fft_convolve(_dev(audio), _dev(np.zeros([2, 1999, 10], np.float32)))   # frame-count mismatch
+
+
+@pytest.mark.parametrize('K,scale', [(96, 'exp_sigmoid'), (64, 'exp_tanh'), (32, 'none')])
+def test_scale_fn_fused_into_the_fir_design_is_bit_identical(K, scale):
+    """Audio-only route: FilteredNoise.get_controls' scale_fn(magnitudes + bias) runs inside the FIR design
+    kernel instead of as its own pass over the [R, T, K] tensor."""
+    import functools
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(3)
+    raw = torch.as_tensor(rng.normal(0, 3, [5, 37, K]).astype(np.float32), device='cuda')
+    fn = {'exp_sigmoid': dp.exp_sigmoid, 'exp_tanh': functools.partial(dp.exp_tanh, gain=0.7), 'none': None}[scale]
+    synth = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=24000, scale_fn=fn, initial_bias=-2.5)
+    rs = synth.raw_scale()
+    if fn is None:
+        assert rs is None
+        return
+    scaled = synth.get_controls(raw)['magnitudes']
+    want = core.frequency_impulse_response(scaled, window_size=synth.window_size)
+    got = core.frequency_impulse_response(raw, window_size=synth.window_size, raw_scale=rs)
+    assert torch.equal(got, want)
+    noise = torch.as_tensor(rng.uniform(-1, 1, [5, 37 * 96]).astype(np.float32), device='cuda')
+    assert torch.equal(core.frequency_filter(noise, raw, window_size=synth.window_size, raw_scale=rs),
+                       core.frequency_filter(noise, scaled, window_size=synth.window_size))
+    # python callables that the library does not know stay outside the kernel
+    assert dp.DynamicSizeFilteredNoise(scale_fn=lambda x: torch.sigmoid(x)).raw_scale() is None
