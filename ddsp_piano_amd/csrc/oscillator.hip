@@ -69,7 +69,8 @@ __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
 }
 
 template <int VPL, bool FUSED, int MODE, bool SUM, bool COMPACT = false>
-__global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? 4 : 1, COMPACT ? 4 : 8)))
+osc_kernel(const OscParams p) {
     static_assert(!COMPACT || (VPL <= 2 && FUSED && MODE == MODE_MAIN && SUM), "compact mode: fused main kernel only");
     // one workgroup = the `groups` wavefronts of one (row, span): they walk the same samples, so
     // their per-tile partial sums can be combined through LDS behind a single barrier per tile
@@ -82,9 +83,14 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     int row, c0, c1;
     int cw = 0;                                            // compact mode: wavefront slot inside (segment, span)
     if (COMPACT) {
-        const int nwg = p.nslots / 4;                      // workgroups (of 4 wavefront slots) per (segment, span)
-        const int bs = task / nwg;
-        cw = (task - bs * nwg) * 4 + wib;                  // then cw += nslots until the audible set is covered
+        // workgroups (of 4 wavefront slots) per (segment, span): nslots / 4.  Workgroup index = slot group major,
+        // (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so every XCD gets the same
+        // mix of busy (low slots) and idle (slots past the audible set, exit at once) workgroups, and the busy
+        // ones are dispatched first.  (Slot-group minor with 4 groups parks all the work on half of the XCDs.)
+        const int nbs = p.R * p.spans;
+        const int g = task / nbs;
+        const int bs = task - g * nbs;
+        cw = g * 4 + wib;                                  // then cw += nslots until the audible set is covered
         row = bs / p.spans;                                // = segment b
         const int span = bs - row * p.spans;
         c0 = span * p.cps;
@@ -1061,7 +1067,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     const int nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     // spans: enough (segment, span, slot) tasks to balance 256 CUs
     int sp = spans > 0 ? spans : env_int("DDSPP_OSC_SPANS_COMPACT", 0);
-    if (sp <= 0) sp = (env_int("DDSPP_OSC_TARGET_WAVES_COMPACT", 18432) + B * 8 - 1) / (B * 8);
+    if (sp <= 0) sp = (env_int("DDSPP_OSC_TARGET_WAVES_COMPACT", 36864) + B * 8 - 1) / (B * 8);
     if (sp > nchunks) sp = nchunks;
     if (sp < 1) sp = 1;
     const int cps = (nchunks + sp - 1) / sp;
@@ -1124,9 +1130,10 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
                        harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
     // 3. the compacted oscillator bank: one wavefront per (segment, span, slot of 64 audible oscillators)
-    // workgroups per (segment, span): each loops over slots cw, cw + nslots, ...; a piano has about a
-    // third of its P * H partials below Nyquist, so wmax / 2 slots rarely need a second pass
-    int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", (3 * wmax + 3) / 4);
+    // wavefront slots launched per (segment, span): slot cw takes the cw-th block of 128 audible oscillators (and
+    // cw + nslots, ... when fewer slots than wmax are launched); a piano has about a third of its P * H partials
+    // below Nyquist, the slots past the audible set exit at once (cheap: slot-group-major workgroup order)
+    int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", wmax);
     nslots = (nslots + 3) / 4 * 4;
     if (nslots < 4) nslots = 4;
     p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots; p.vmajor = voice_major ? 1 : 0;

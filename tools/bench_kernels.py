@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel timing harness (HIP events) for the kernels of the synthesis path at bench sizes.
-usage: python tools/bench_kernels.py [--which fused,osc,fir,controls] [--batch 64] [--reps 5]"""
+usage: python tools/bench_kernels.py [--which fused,compact,osc,fir,controls] [--batch 64] [--reps 5]"""
 import argparse
 import os
 import sys
@@ -71,6 +71,13 @@ def main():
             mn, av = timeit(fn, args.reps)
             print(f'harmonic_synthesis fused spans={sp:3d} min {mn:8.3f} ms avg {av:8.3f} ms  '
                   f'{osc_total / mn / 1e6:8.1f} G osc-samples/s')
+    if 'compact' in which:
+        for sp in [int(s) for s in args.spans.split(',')]:
+            fn = lambda: core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),  # noqa: E731
+                                                  ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr,
+                                                  spans=sp)
+            mn, av = timeit(fn, args.reps)
+            print(f'polyphonic_additive spans={sp:3d} min {mn:8.3f} ms avg {av:8.3f} ms')
     if 'fir' in which:
         nctl = noise.get_controls(mags)['magnitudes']
         mn, av = timeit(lambda: core.frequency_impulse_response(nctl, 257), args.reps)
