@@ -3,7 +3,8 @@
 // Replaces ddsp.core.fft_convolve for the single-frame case (one impulse response per batch row)
 // as called by ddsp.effects.Reverb.get_signal (dry-masked IR, delay_compensation=0, + dry) and by
 // FeedbackDelayNetwork.get_signal (ddsp_piano/modules/fdn_reverb.py:407-410).
-//   fft_size = 2 ** ceil(log2(N + L - 1))            ddsp.core.get_fft_size(power_of_2=True)
+//   fft_size = 2 ** ceil(log2(N + L - 1))            ddsp.core.get_fft_size(power_of_2=True); here the cheapest
+//                                                     of 2^k, 3 * 2^k, 5 * 2^k, ... >= N + L - 1 (fast_fft_size)
 //   out[n]   = irfft(rfft(audio, fft_size) * rfft(ir, fft_size))[n + delay]  (+ audio[n])
 // rocFFT owns the butterflies; the hand-written kernels around it fuse the dry-sample mask into the
 // zero padding of the IR, and the crop + add-dry into one epilogue pass.  The library owns only the
@@ -112,13 +113,43 @@ int ddspp_fft_size(int N, int L) {
     return n > 0x40000000ll ? -1 : (int)n;
 }
 
+// Transform length the plan really uses.  The reference pads to the next power of two (ddspp_fft_size); the
+// linear convolution does not depend on the padding, so any length >= N + L - 1 that rocFFT handles well will do.
+// Measured on MI355X (64 rows, N = L = 72000, whole fft_convolve): 262144 = 2^18 0.389 ms, 163840 = 5 * 2^15
+// 0.280 ms, 196608 = 3 * 2^16 0.348 ms, 147456 = 9 * 2^14 0.346 ms, 144000 = 2^7 3^2 5^3 0.346 ms: per point the
+// power of two is cheapest, {3, 5} * 2^k cost ~1.18x, other 5-smooth lengths ~1.6x.  The smallest such cost wins.
+// DDSPP_FFT_POW2=1 keeps the reference's size, DDSPP_FFT_SIZE=n forces a length (tuning).
+static int fast_fft_size(int N, int L) {
+    const long long need = (long long)N + L - 1;
+    const char* e = getenv("DDSPP_FFT_POW2");
+    if (e && *e == '1') return ddspp_fft_size(N, L);
+    const char* f = getenv("DDSPP_FFT_SIZE");
+    if (f && atoll(f) >= need && atoll(f) % 8 == 0) return (int)atoll(f);
+    long long best = -1;
+    double best_cost = 0.0;
+    for (int p5 = 0; p5 <= 3; ++p5)
+        for (int p3 = 0; p3 <= 2; ++p3) {
+            long long v = 1;
+            for (int i = 0; i < p5; ++i) v *= 5;
+            for (int i = 0; i < p3; ++i) v *= 3;
+            while (v < need || v % 8 != 0) v *= 2;
+            const double weight = (p3 + p5 == 0) ? 1.0 : (p3 + p5 == 1 ? 1.18 : 1.6);
+            const double cost = weight * (double)v;
+            if (best < 0 || cost < best_cost) {
+                best = v;
+                best_cost = cost;
+            }
+        }
+    return (best < 8 || best > 0x40000000ll) ? -1 : (int)best;
+}
+
 int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan** out_plan) {
     DDSPP_REQUIRE(out_plan, "fftconv_plan_create: null out_plan");
     DDSPP_REQUIRE(B > 0 && N > 0 && L > 0, "fftconv_plan_create: bad dims");
     DDSPP_REQUIRE(B_ir == B || B_ir == 1,
                   "Batch size of audio (%d) and impulse response (%d) must be the same.", B, B_ir);
-    const int nfft = ddspp_fft_size(N, L);
-    DDSPP_REQUIRE(nfft >= 4, "fftconv_plan_create: fft size out of range");
+    const int nfft = fast_fft_size(N, L);
+    DDSPP_REQUIRE(nfft >= 8, "fftconv_plan_create: fft size out of range");
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     FftConvPlan* pl = new FftConvPlan();
     pl->B = B; pl->B_ir = B_ir; pl->N = N; pl->L = L; pl->nfft = nfft;
