@@ -457,12 +457,13 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
-                        sample_rate, spans=0, voice_major=False):
+                        sample_rate, spans=0, voice_major=False, audible=None):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
     The per-voice stems are never formed; lanes go only to oscillators that are audible somewhere in a
-    span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only."""
+    span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only.  audible: the int32 [R, T]
+    per-frame counts of InHarmonic._controls(want_counts=True) (saves a scan of the [R, T, H] controls)."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
@@ -475,9 +476,13 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     nbytes = int(lib.ddspp_polyphonic_additive_workspace_bytes(b, p, t, s, h, u))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     out = torch.empty((b, n_samples), dtype=torch.float32, device=dev)
+    null = ctypes.c_void_p(0)
+    if audible is not None and (audible.dtype != torch.int32 or audible.numel() != r * t or not audible.is_contiguous()):
+        raise ValueError('audible must be a contiguous int32 tensor of R * T frame counts')
     _lib.check(lib.ddspp_polyphonic_additive(
         _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
-        _ptr(harmonic_shifts) if harmonic_shifts is not None else ctypes.c_void_p(0), _ptr(wlin), _ptr(whann),
+        _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
+        ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(wlin), _ptr(whann),
         _ptr(out), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
         _stream()))
     return out

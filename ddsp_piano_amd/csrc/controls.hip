@@ -24,6 +24,7 @@ struct InharmParams {
     float* __restrict__ amp_out;                      // [R, T]
     float* __restrict__ hd_out;                       // [R, T, H]
     float* __restrict__ shifts_out;                   // [R, T, H]
+    int* __restrict__ count_out;                      // [R, T] audible leading harmonics per frame, or null
     int R, T, H, S;
     float nyquist, min_frequency, n_substrings;
     int normalize_after_nyquist_cut, normalize_below_nyquist;
@@ -112,6 +113,19 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             }
         }
         if (lane == 0) p.amp_out[frame] = amp;
+        if (p.count_out) {
+            // 1 + index of the last harmonic whose sample-rate amplitude amp * hd is not zero in this frame
+            // (what ddspp_polyphonic_additive needs to know to skip the silent top of the harmonic range)
+            int last = 0;
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                const int k = lane + 64 * j;
+                if (k < H && amp * hd[j] != 0.0f) last = k + 1;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+            if (lane == 0) p.count_out[frame] = last;
+        }
     }
 }
 
@@ -202,8 +216,8 @@ extern "C" {
 // keyword defaults of those functions unless the caller overrides them.
 int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
                               const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
-                              float* harmonic_distribution_out, float* harmonic_shifts_out, int R, int T,
-                              int H, int S, float sample_rate, float min_frequency, int scale_kind,
+                              float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
+                              int R, int T, int H, int S, float sample_rate, float min_frequency, int scale_kind,
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
                               hipStream_t stream) {
@@ -217,6 +231,7 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
     p.amplitudes = amplitudes; p.harmonic_distribution = harmonic_distribution;
     p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
     p.amp_out = amplitudes_out; p.hd_out = harmonic_distribution_out; p.shifts_out = harmonic_shifts_out;
+    p.count_out = audible_out;
     p.R = R; p.T = T; p.H = H; p.S = S;
     p.nyquist = sample_rate / 2.0f; p.min_frequency = min_frequency; p.n_substrings = (float)S;
     p.normalize_after_nyquist_cut = normalize_after_nyquist_cut;

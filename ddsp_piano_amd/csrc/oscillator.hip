@@ -766,6 +766,23 @@ __global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict_
     }
 }
 
+// The same from the per-frame counts ddspp_inharmonic_controls leaves behind (audible[R, T]): one thread per
+// (row, span), a dozen ints instead of a [frames, H] scan.
+__global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __restrict__ audible, int* __restrict__ nk,
+                                                             int R, int P, int T, int U, int N, int spans, int cps,
+                                                             int vmajor) {
+    const int task = blockIdx.x * 256 + threadIdx.x;
+    if (task >= R * spans) return;
+    const int row = task / spans, span = task - row * spans;
+    const int n_lo = span * cps * DDSPP_CHUNK, n_hi = min((span + 1) * cps * DDSPP_CHUNK, N);
+    const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
+    int best = 0;
+    for (int t = t_lo; t <= t_hi; ++t) best = max(best, audible[(size_t)row * T + t]);
+    const int B = R / P;
+    const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
+    nk[((size_t)b * spans + span) * P + v] = best;
+}
+
 // audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic)
 __global__ void __launch_bounds__(256) osc_partial_sum_kernel(const float* __restrict__ partial,
                                                             const int* __restrict__ wcount,
@@ -1051,7 +1068,8 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
 }
 
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
-                              const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
+                              const float* harmonic_shifts, const int* audible, const float* wlin,
+                              const float* whann, float* audio,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
@@ -1127,8 +1145,12 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
         }
     }
     // 2. audible-harmonic counts per (segment, span, voice)
-    hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
-                       harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
+    if (audible)
+        hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
+                           P, T, U, N, sp, cps, voice_major);
+    else
+        hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
+                           harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
     // 3. the compacted oscillator bank: one wavefront per (segment, span, slot of 64 audible oscillators)
     // wavefront slots launched per (segment, span): slot cw takes the cw-th block of 128 audible oscillators (and
     // cw + nslots, ... when fewer slots than wmax are launched); a piano has about a third of its P * H partials

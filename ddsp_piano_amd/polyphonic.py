@@ -140,12 +140,12 @@ def run(plan, inputs, noise=None, need_stems=True):
     vmi = 1 if vm else 0
 
     # --- additive branch ------------------------------------------------------------------------
-    ctl = additive._controls(amp, hd, inh, f0)
     compact = (not need_stems) and additive.inference and P * S <= 64 and N % 4 == 0
+    ctl = additive._controls(amp, hd, inh, f0, want_counts=compact)
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                 ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N,
-                                                additive.sample_rate, voice_major=vm)
+                                                additive.sample_rate, voice_major=vm, audible=ctl['_audible'])
         additive_sig = None
     else:
         additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),

@@ -34,7 +34,7 @@ class InHarmonic(Processor):
     def upsampling(self):
         return int(self.sample_rate / self.frame_rate)               # :163-165
 
-    def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
+    def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz, want_counts=False):
         """One fused kernel for :183-214 (+ :269); f0_hz may carry several sub-strings."""
         amplitudes = core.tf_float32(amplitudes)
         harmonic_distribution = core.tf_float32(harmonic_distribution)
@@ -58,13 +58,17 @@ class InHarmonic(Processor):
         amp_out = torch.empty_like(amplitudes)
         hd_out = torch.empty_like(harmonic_distribution)
         shifts_out = torch.empty_like(harmonic_distribution)
+        counts = torch.empty((b, t), dtype=torch.int32, device=amplitudes.device) if want_counts else None
         _lib.check(_lib_().ddspp_inharmonic_controls(
             _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
-            _ptr(hd_out), _ptr(shifts_out), b, t, h, s, float(self.sample_rate), float(self.min_frequency),
+            _ptr(hd_out), _ptr(shifts_out), counts.data_ptr() if counts is not None else None, b, t, h, s, float(self.sample_rate), float(self.min_frequency),
             code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
             int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
-        return {'amplitudes': amp_out, 'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out,
-                'f0_hz': f0_hz}
+        ctl = {'amplitudes': amp_out, 'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out,
+               'f0_hz': f0_hz}
+        if want_counts:
+            ctl['_audible'] = counts       # per-frame count of leading non-silent harmonics (batched route only)
+        return ctl
 
     def get_controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz):
         """inharm_synth.py:167-219."""

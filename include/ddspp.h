@@ -89,10 +89,12 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
  * controls are [B * P] segment major (voice_major = 0), or [P * B] voice major (voice_major = 1): the layout the
  * reference's Parallelizer.unparallelize leaves the merged controls in (sub_modules.py:573-592), so the per-voice
  * keys `<name>_<i>` can be handed over without a copy.  Only oscillators with a non-zero amplitude somewhere in a
- * span are given a lane, so the work follows the number of partials below Nyquist instead of P * H. */
+ * span are given a lane, so the work follows the number of partials below Nyquist instead of P * H.
+ * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics. */
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
-                              const float* harmonic_shifts, const float* wlin, const float* whann, float* audio,
+                              const float* harmonic_shifts, const int* audible, const float* wlin,
+                              const float* whann, float* audio,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
@@ -101,11 +103,13 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
 /* InHarmonic.get_controls / MultiInharmonic.get_controls -- inharm_synth.py:167-219, :254-270
  * (+ get_inharmonic_freq :20-46).  amplitudes[R,T], harmonic_distribution[R,T,H], inharm_coef[R,T],
  * f0_hz[R,T,S] -> amplitudes_out[R,T] (already divided by S), harmonic_distribution_out[R,T,H],
- * harmonic_shifts_out[R,T,H]. */
+ * harmonic_shifts_out[R,T,H]; audible_out[R,T] (int32, may be NULL): 1 + index of the last harmonic with
+ * amplitudes_out * harmonic_distribution_out != 0 in the frame, which ddspp_polyphonic_additive accepts as
+ * `audible` so that it need not scan the [R,T,H] tensor again. */
 int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
                               const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
-                              float* harmonic_distribution_out, float* harmonic_shifts_out, int R, int T,
-                              int H, int S, float sample_rate, float min_frequency, int scale_kind,
+                              float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
+                              int R, int T, int H, int S, float sample_rate, float min_frequency, int scale_kind,
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
                               hipStream_t stream);

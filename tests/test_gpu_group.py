@@ -286,6 +286,16 @@ def test_compacted_additive_equals_voice_stems():
                   for x in (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'])]
             mix_vm = core.polyphonic_additive(*vm, B, N, sr, spans=spans, voice_major=True)
             assert torch.equal(mix_vm, mix), (B, P, H, S, spans)
+            # the per-frame audible-harmonic counts of get_controls replace the scan of [R, T, H]: same lanes, same bits
+            raw_t = [torch.as_tensor(raw[k], device='cuda') for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]
+            cnt = syn._controls(*raw_t, want_counts=True)['_audible']
+            assert cnt.dtype == torch.int32 and cnt.shape == (R, T)
+            prod = (ctl['amplitudes'] * ctl['harmonic_distribution']) != 0
+            want = torch.where(prod.any(-1), H - prod.flip(-1).to(torch.int32).argmax(-1), torch.zeros_like(cnt))
+            assert torch.equal(cnt, want.to(torch.int32))
+            mix_cnt = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'],
+                                               B, N, sr, spans=spans, audible=cnt)
+            assert torch.equal(mix_cnt, mix), (B, P, H, S, spans)
     # all voices silent: zeros
     z = torch.zeros(4, 20, 8, device='cuda')
     out = core.polyphonic_additive(torch.full((4, 20, 1), 100.0, device='cuda'), torch.zeros(4, 20, device='cuda'), z, z,
