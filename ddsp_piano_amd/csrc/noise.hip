@@ -11,6 +11,8 @@
 // round trips, and it equals the FFT result to float32 round-off.
 //
 // Kernels
+//   fir_eo_mfma_kernel : the FIR design as two GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32)
+//       through the even/odd split of the inverse real DFT; fir_eo_kernel is its VALU form (K = 128).
 //   fir_from_magnitudes_kernel : ir[r, t, :] = magnitudes[r, t, :] @ M, M = the (windowed,
 //       shifted) inverse real DFT matrix [K, Lw] built by the host in float64.  Lane = tap, the
 //       tap's column of M lives in registers, the frame's magnitudes arrive through scalar loads.
@@ -80,8 +82,9 @@ __global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ m
                                                    const float* __restrict__ tap_wo,   // [NJ, 4]
                                                    float* __restrict__ ir, int frames, int Lw, int NJ,
                                                    int frames_per_block, float bias, ScaleFn scale) {
-    extern __shared__ __attribute__((aligned(16))) float mtile[];       // [frames_per_block][2 KH]
+    extern __shared__ __attribute__((aligned(16))) float mtile[];       // [frames_per_block][2 KH], then the output rows
     constexpr int K = 2 * KH;
+    float* otile = mtile + frames_per_block * K;                        // [frames_per_block][Lw]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int j = min(lane, NJ - 1);
     const bool active = lane < NJ;
@@ -99,39 +102,177 @@ __global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ m
         twe[s] = tap_we[j * 4 + s];
         two[s] = tap_wo[j * 4 + s];
     }
-    const int f0 = blockIdx.x * frames_per_block;
-    const int nf = min(frames_per_block, frames - f0);
-    {   // coalesced copy of the tile
-        const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
-        float4* dst = reinterpret_cast<float4*>(mtile);
-        const int n4 = nf * (K / 4);
-        if (scale.kind < 0) {
-            for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-        } else {      // raw network outputs: FilteredNoise.get_controls' scale_fn(magnitudes + initial_bias) on the way in
-            for (int i = threadIdx.x; i < n4; i += 256) {
-                const float4 m = src[i];
-                dst[i] = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
-                                     apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+    // A workgroup walks several tiles of frames_per_block frames: the 2 KH table registers loaded above (as many
+    // bytes as a tile itself) are paid once per workgroup, not once per tile.
+    const int ntiles = (frames + frames_per_block - 1) / frames_per_block;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int f0 = tile * frames_per_block;
+        const int nf = min(frames_per_block, frames - f0);
+        {   // coalesced copy of the tile
+            const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
+            float4* dst = reinterpret_cast<float4*>(mtile);
+            const int n4 = nf * (K / 4);
+            if (scale.kind < 0) {
+                for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+            } else {  // raw network outputs: FilteredNoise.get_controls' scale_fn(magnitudes + initial_bias) on the way in
+                for (int i = threadIdx.x; i < n4; i += 256) {
+                    const float4 m = src[i];
+                    dst[i] = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
+                                         apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+                }
             }
         }
+        __syncthreads();
+        for (int f = wib; f < nf; f += 4) {
+            const float4* mg = reinterpret_cast<const float4*>(mtile + f * K);   // wave-uniform address
+            float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < KH; q += 2) {
+                const float4 m = mg[q / 2];                  // magnitudes 2q, 2q+1, 2q+2, 2q+3
+                e0 = __builtin_fmaf(m.x, ce[q], e0);
+                o0 = __builtin_fmaf(m.y, co[q], o0);
+                e1 = __builtin_fmaf(m.z, ce[q + 1], e1);
+                o1 = __builtin_fmaf(m.w, co[q + 1], o1);
+            }
+            const float E = e0 + e1, O = o0 + o1;
+            float* dst = otile + f * Lw;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (tidx[s] >= 0) dst[tidx[s]] = __builtin_fmaf(two[s], O, twe[s] * E);
+        }
+        __syncthreads();                 // rows complete; the magnitude tile may be overwritten by the next one
+        {   // the tile's impulse responses are one contiguous block of ir: full 16-byte stores instead of four
+            // 4-byte scatters per lane and frame (partial-line writes held the kernel at 2.9 TB/s)
+            float* dst = ir + (size_t)f0 * Lw;                       // 16-byte aligned: frames_per_block * Lw % 4 == 0
+            const int nfl = nf * Lw, n4 = nfl / 4;
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            const float4* src4 = reinterpret_cast<const float4*>(otile);
+            for (int i = threadIdx.x; i < n4; i += 256) dst4[i] = src4[i];
+            for (int i = 4 * n4 + threadIdx.x; i < nfl; i += 256) dst[i] = otile[i];
+        }
+    }
+}
+
+// The same even/odd product on the matrix cores.  E = M_even @ CE and O = M_odd @ CO are [frames, K/2] x [K/2, NJ]
+// GEMMs: a wavefront owns 16 frames, v_mfma_f32_16x16x4_f32 accumulates the 16 x 16 blocks of E and O over K/8
+// steps (exact f32, a k-ordered fma chain).  The table fragments (B operands) live in registers for the whole
+// kernel; the A operands are one ds_read_b64 per step (magnitudes 2k, 2k + 1 of the lane's frame) shared by all
+// the 16-column blocks -- 2 * JT matrix instructions (2048 * JT MACs) per LDS read instead of 4 FMAs.  The rows
+// of the tile are assembled in LDS (tap weights applied on the way) and leave as full 16-byte stores.
+// Wavefronts are independent (private LDS region, no workgroup barrier) and walk tiles of 16 frames.
+template <int KH, int JT>   // KH = K / 2, JT = ceil(NJ / 16)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) fir_eo_mfma_kernel(const float* __restrict__ mags,     // [frames, 2 KH]
+                                                        const float* __restrict__ CE,       // [KH, NJ]
+                                                        const float* __restrict__ CO,       // [KH, NJ]
+                                                        const int* __restrict__ tap_idx,    // [NJ, 4]
+                                                        const float* __restrict__ tap_we,   // [NJ, 4]
+                                                        const float* __restrict__ tap_wo,   // [NJ, 4]
+                                                        float* __restrict__ ir, int frames, int Lw, int NJ,
+                                                        int region_floats, float bias, ScaleFn scale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    constexpr int K = 2 * KH, KS = KH / 4, FT = 16;      // FT frames per tile
+    constexpr int ASTR = K + 4;                            // padded row stride of the magnitude tile (16-byte aligned)
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    float* reg = lds_dyn + (size_t)wib * region_floats;    // this wavefront's LDS: magnitudes, then the output rows
+    const int col = lane & 15, kq = lane >> 4;
+
+    // B fragments: lane holds CE/CO[4 s + kq][16 jt + col]
+    float bE[JT][KS], bO[JT][KS];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int j = min(16 * jt + col, NJ - 1);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            bE[jt][st] = CE[(4 * st + kq) * NJ + j];
+            bO[jt][st] = CO[(4 * st + kq) * NJ + j];
+        }
+    }
+    // tap tables (index, even weight, odd weight per lane column and slot): shared by the workgroup, in LDS
+    int* tix = reinterpret_cast<int*>(lds_dyn + (size_t)4 * region_floats);     // [16 JT][4]
+    float* twe = reinterpret_cast<float*>(tix + 64 * JT);
+    float* two = twe + 64 * JT;
+    for (int i = threadIdx.x; i < 64 * JT; i += 256) {
+        const int j = i >> 2;
+        tix[i] = j < NJ ? tap_idx[i] : -1;
+        twe[i] = j < NJ ? tap_we[i] : 0.0f;
+        two[i] = j < NJ ? tap_wo[i] : 0.0f;
     }
     __syncthreads();
-    for (int f = wib; f < nf; f += 4) {
-        const float4* mg = reinterpret_cast<const float4*>(mtile + f * K);   // wave-uniform address
-        float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+    const int ntiles = (frames + FT - 1) / FT;
+    for (int tile = blockIdx.x * 4 + wib; tile < ntiles; tile += gridDim.x * 4) {
+        const int f0 = tile * FT;
+        const int nf = min(FT, frames - f0);
+        // ---- magnitudes of the 16 frames -> LDS (scale_fn on the way when they are raw network outputs)
+        {
+            constexpr int PER_ROW = K / 4;                          // float4 per frame
+            constexpr int N4 = FT * PER_ROW;
+            const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
+            const int lim = nf * PER_ROW - 1;
 #pragma unroll
-        for (int q = 0; q < KH; q += 2) {
-            const float4 m = mg[q / 2];                  // magnitudes 2q, 2q+1, 2q+2, 2q+3
-            e0 = __builtin_fmaf(m.x, ce[q], e0);
-            o0 = __builtin_fmaf(m.y, co[q], o0);
-            e1 = __builtin_fmaf(m.z, ce[q + 1], e1);
-            o1 = __builtin_fmaf(m.w, co[q + 1], o1);
+            for (int u = 0; u < (N4 + 63) / 64; ++u) {
+                const int i = lane + 64 * u;
+                if (i < N4) {
+                    float4 m = src[min(i, lim)];
+                    if (scale.kind >= 0)
+                        m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
+                                        apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+                    const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
+                    *reinterpret_cast<float4*>(reg + fr * ASTR + 4 * c4) = m;
+                }
+            }
         }
-        const float E = e0 + e1, O = o0 + o1;
-        float* dst = ir + (size_t)(f0 + f) * Lw;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- E, O accumulation: A fragment = magnitudes (2 kk, 2 kk + 1), kk = 4 s + kq, of frame `col`
+        f32x4 accE[JT], accO[JT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (tidx[s] >= 0) dst[tidx[s]] = __builtin_fmaf(two[s], O, twe[s] * E);
+        for (int jt = 0; jt < JT; ++jt) {
+            accE[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accO[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* arow = reg + col * ASTR + 2 * kq;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const float2 a = *reinterpret_cast<const float2*>(arow + 8 * st);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                accE[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bE[jt][st], accE[jt], 0, 0, 0);
+                accO[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bO[jt][st], accO[jt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // every lane is done with the magnitude tile: reuse the region
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- D[row = 4 kq + r][col]: frame 4 kq + r, lane column j = 16 jt + col -> its (up to) four taps
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float E = accE[jt][r], O = accO[jt][r];
+                float* dst = reg + (4 * kq + r) * Lw;
+                const int4 ti = *reinterpret_cast<const int4*>(tix + 4 * (16 * jt + col));
+                const float4 we = *reinterpret_cast<const float4*>(twe + 4 * (16 * jt + col));
+                const float4 wo = *reinterpret_cast<const float4*>(two + 4 * (16 * jt + col));
+                if (ti.x >= 0) dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
+                if (ti.y >= 0) dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
+                if (ti.z >= 0) dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
+                if (ti.w >= 0) dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // the tile's impulse responses are contiguous in ir (16 * Lw floats, 16-byte aligned start)
+            float* dst = ir + (size_t)f0 * Lw;
+            const int nfl = nf * Lw, n4 = nfl / 4;
+            for (int i = lane; i < n4; i += 64)
+                reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(reg)[i];
+            for (int i = 4 * n4 + lane; i < nfl; i += 64) dst[i] = reg[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // rows copied out before the next tile's magnitudes land
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -477,9 +618,29 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
     DDSPP_REQUIRE(frames < (1ull << 31), "fir_from_magnitudes_eo: too many frames");
     DDSPP_REQUIRE((uintptr_t)magnitudes % 16 == 0, "fir_from_magnitudes_eo: magnitudes must be 16-byte aligned");
     if (frames == 0) return DDSPP_OK;
-    const int fpb = 64;
-    const dim3 grid((unsigned)((frames + fpb - 1) / fpb)), block(256);
-    const size_t lds = (size_t)fpb * K * sizeof(float);
+    if (K <= 96 && NJ <= 16 * ((K / 2 + 15) / 16) && !env_int("DDSPP_FIR_NO_MFMA", 0)) {
+        DDSPP_REQUIRE((uintptr_t)ir % 16 == 0, "fir_from_magnitudes_eo: ir must be 16-byte aligned");
+        const int region = ((16 * (K + 4) > 16 * Lw ? 16 * (K + 4) : 16 * Lw) + 3) / 4 * 4;
+        const size_t lds_m = ((size_t)4 * region + 3 * 64 * 4) * sizeof(float);       // + tap tables
+        const long long ntiles16 = ((long long)frames + 15) / 16;
+        long long wgs = (ntiles16 + 3) / 4;
+        const long long cap = (long long)256 * env_int("DDSPP_FIR_WGS_PER_CU", 3);    // wavefronts walk tiles beyond that
+        if (wgs > cap) wgs = cap;
+        const dim3 grid_m((unsigned)wgs), block_m(256);
+        const ScaleFn sf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
+        const int nfr = (int)frames;
+        if (K == 32) hipLaunchKernelGGL((fir_eo_mfma_kernel<16, 1>), grid_m, block_m, lds_m, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nfr, Lw, NJ, region, bias, sf);
+        else if (K == 64) hipLaunchKernelGGL((fir_eo_mfma_kernel<32, 2>), grid_m, block_m, lds_m, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nfr, Lw, NJ, region, bias, sf);
+        else hipLaunchKernelGGL((fir_eo_mfma_kernel<48, 3>), grid_m, block_m, lds_m, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nfr, Lw, NJ, region, bias, sf);
+        DDSPP_LAUNCH_CHECK();
+        return DDSPP_OK;
+    }
+    const int fpb = 32;               // frames per tile: (K + Lw) * 4 * 32 bytes of LDS, four workgroups per CU
+    DDSPP_REQUIRE(((size_t)fpb * Lw) % 4 == 0 && (uintptr_t)ir % 16 == 0, "fir_from_magnitudes_eo: ir must be 16-byte aligned");
+    const long long ntiles = ((long long)frames + fpb - 1) / fpb;
+    const int tpw = env_int("DDSPP_FIR_TILES_PER_WG", 4);       // tiles a workgroup walks
+    const dim3 grid((unsigned)((ntiles + tpw - 1) / (tpw > 0 ? tpw : 1))), block(256);
+    const size_t lds = (size_t)fpb * (K + Lw) * sizeof(float);
     const int nf = (int)frames;
     const ScaleFn sfn{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
     if (K == 32) hipLaunchKernelGGL(fir_eo_kernel<16>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
