@@ -34,19 +34,22 @@ def shard_features(features, world_size, rank, batch_axis=0):
     return out
 
 
-def gather_audio(local_audio, out=None, group=None):
-    """All-gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order)."""
+def gather_audio(local_audio, out=None, group=None, async_op=False):
+    """All-gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order).
+
+    async_op=True returns (out, work): the collective runs on RCCL's own stream, so the next segment's kernels
+    overlap with it; call work.wait() (a stream-level wait) before reading ``out``."""
     world = dist.get_world_size(group)
     local_audio = local_audio.contiguous()
     if out is None:
         out = torch.empty((world * local_audio.shape[0],) + tuple(local_audio.shape[1:]),
                           dtype=local_audio.dtype, device=local_audio.device)
     try:
-        dist.all_gather_into_tensor(out, local_audio, group=group)
+        work = dist.all_gather_into_tensor(out, local_audio, group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):
         chunks = list(out.chunk(world, dim=0))
-        dist.all_gather(chunks, local_audio, group=group)
-    return out
+        work = dist.all_gather(chunks, local_audio, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def gather_audio_uneven(local_audio, global_batch, group=None):

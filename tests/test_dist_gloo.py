@@ -38,6 +38,10 @@ def _worker(rank, world, port, global_batch, q):
         buf = torch.empty(global_batch, 8)
         parallel.gather_audio(local, buf)
         ok = ok and torch.allclose(buf, full_ref) and (hi - lo) == global_batch // world
+        buf2 = torch.zeros(global_batch, 8)                    # the overlapped form bench.py uses
+        out2, work = parallel.gather_audio(local, buf2, async_op=True)
+        work.wait()
+        ok = ok and out2 is buf2 and torch.allclose(buf2, full_ref)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))
