@@ -706,8 +706,45 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
 
 def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale=None):
     """ddsp.core.frequency_filter -- call site filtered_noise_synth.py:41-42."""
+    fused = _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale)
+    if fused is not None:
+        return fused
     impulse_response = frequency_impulse_response(magnitudes, window_size=window_size, raw_scale=raw_scale)
     return fft_convolve(audio, impulse_response, padding=padding)
+
+
+def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale):
+    """FIR design + time-varying FIR in one kernel (ddspp_frequency_filter_eo) when the shape fits, else None.
+    Bit-identical to the two-kernel form; the [B, T, Lw] impulse responses are never materialised."""
+    if padding != 'same' or not (torch.is_tensor(audio) and torch.is_tensor(magnitudes)):
+        return None
+    x, mags = tf_float32(audio), tf_float32(magnitudes)
+    if x.dim() != 2 or mags.dim() != 3 or x.shape[0] != mags.shape[0]:
+        return None
+    b, n = x.shape
+    t, k = int(mags.shape[1]), int(mags.shape[2])
+    if t < 2 or n % t != 0:
+        return None
+    eo = fir_eo_tables(k, int(window_size), mags.device)
+    if eo is None:
+        return None
+    ce, co, idx, we, wo, nj, lw = eo
+    lib = _lib_()
+    if not lib.ddspp_frequency_filter_eo_supported(n, t, k, lw, -1):
+        return None
+    x, mags = x.contiguous(), mags.contiguous()
+    if x.data_ptr() % 16 or mags.data_ptr() % 16:
+        return None
+    if raw_scale is None:
+        code, bias, prm = -1, 0.0, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0)
+    else:
+        code, bias, prm = raw_scale
+    out = torch.empty((b, n), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ddspp_frequency_filter_eo(_ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo),
+                                             _ptr(out), b, n, t, k, lw, nj, -1, int(code), float(bias),
+                                             prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+                                             _stream()))
+    return out
 
 
 def uniform_noise(shape, seed=0, offset=0, device=None):

@@ -450,6 +450,218 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FilteredNoise in one kernel: FIR design (matrix cores) + time-varying FIR, impulse responses never leave the CU
+// ------------------------------------------------------------------------------------------------
+// Persistent workgroups walk (row, window of 1024 outputs) tasks.  Per window:
+//   1. the noise blocks and the magnitudes of the (<= 16) frames that reach the window, prefetched into registers
+//      during the previous window's arithmetic, go to LDS (scale_fn applied to raw magnitudes on the way);
+//   2. E = M_even CE, O = M_odd CO on v_mfma_f32_16x16x4_f32: the 2 JT (E/O, 16-column block) units are dealt
+//      to the four wavefronts, whose table fragments stay in registers for the life of the workgroup;
+//   3. tap weights: every (frame, column) pair yields four taps of the frame's zero-padded FIR image in LDS
+//      (the zero pads are written once per workgroup);
+//   4. the time-varying FIR of tv_fir_kernel: each wavefront 256 outputs, 64 FMAs per six ds_read_b128.
+// HBM sees the noise, 1.4 x the magnitudes and the output: the [R, T, Lw] impulse responses (0.58 GB written
+// and 0.8 GB read at batch 64) do not exist.
+constexpr int FUS_BW = 1024;            // outputs per window
+constexpr int FUS_FRAMES = 16;          // frames staged per window = one MFMA row tile
+
+template <int KH, int JT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
+                       const float* __restrict__ mags,       // [R, T, 2 KH]
+                       const float* __restrict__ CE, const float* __restrict__ CO,     // [KH, NJ]
+                       const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
+                       const float* __restrict__ tap_wo,     // [NJ, 4]
+                       float* __restrict__ out,              // [R, N]
+                       int R, int N, int T, int U, int Lw, int NJ, int delay, int windows_per_row, int padl,
+                       int nb, int seglen, int dc, float bias, ScaleFn scale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int K = 2 * KH, KS = KH / 4, ASTR = K + 4, NJP = 16 * JT;
+    constexpr int UNITS = 2 * JT, UPW = (UNITS + 3) / 4;      // (E/O, column block) units, units per wavefront
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int gstride = nb * 4;                               // floats per staged frame image (<= 256)
+    float* G = lds_dyn;                                       // [16][gstride]
+    float* Xs = G + FUS_FRAMES * 256;                         // padded noise window
+    float* M = Xs + 1536;                                     // [16][ASTR] magnitudes
+    float* S = M + FUS_FRAMES * ASTR;                         // [2][16][NJP] E and O
+    int* tix = reinterpret_cast<int*>(S + 2 * FUS_FRAMES * NJP);   // [NJP][4]
+    float* twe = reinterpret_cast<float*>(tix + 4 * NJP);
+    float* two = twe + 4 * NJP;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+
+    // ---- once per workgroup: tap tables, zero pads of the FIR images, this wavefront's table fragments
+    for (int i = threadIdx.x; i < 4 * NJP; i += 256) {
+        const int j = i >> 2;
+        tix[i] = j < NJ ? tap_idx[i] : -1;
+        twe[i] = j < NJ ? tap_we[i] : 0.0f;
+        two[i] = j < NJ ? tap_wo[i] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < FUS_FRAMES * 256; i += 256) G[i] = 0.0f;
+    float bfrag[UPW][KS];
+#pragma unroll
+    for (int v = 0; v < UPW; ++v) {
+        const int unit = min(wib + 4 * v, UNITS - 1);
+        const int eo = unit / JT, jt = unit - eo * JT;
+        const float* C = eo ? CO : CE;
+        const int j = min(16 * jt + col, NJ - 1);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) bfrag[v][st] = C[(4 * st + kq) * NJ + j];
+    }
+
+    const int bpf = U / 4;                                    // input blocks per frame
+    const int nblk = N / 4;
+    const int nxb = FUS_BW / 4 + 4 * seglen - 4;              // staged noise blocks per window (<= 512)
+    const int h = lane >> 5, w = lane & 31;
+    const bool g0 = (w < 4) || (w >= 12 && w < 16) || (w >= 20 && w < 28);
+    const int sg = 2 * h + (g0 ? 0 : 1);
+    const int a = g0 ? (w < 4 ? w : (w < 16 ? w - 8 : w - 12)) : (w < 12 ? w - 4 : (w < 20 ? w - 8 : w - 16));
+    const int bq0 = 4 * (dc - 3 + sg * seglen);
+    const int ntasks = R * windows_per_row;
+
+    // registers holding the NEXT window's inputs
+    float4 xv[2], mv[2];
+    auto window_geometry = [&](int task, int& row, int& nB0, int& f_lo, int& jb_min) {
+        row = task / windows_per_row;
+        nB0 = (task - row * windows_per_row) * FUS_BW;
+        f_lo = max(nB0 + delay - (Lw - 1), 0) / U;
+        jb_min = (nB0 + delay + 3) / 4 + 4 - 4 * seglen;
+    };
+    auto prefetch = [&](int task) {
+        int row, nB0, f_lo, jb_min;
+        window_geometry(task, row, nB0, f_lo, jb_min);
+        const float4* xg = reinterpret_cast<const float4*>(x + (size_t)row * N);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xv[u] = xg[min(max(jb_min + (int)threadIdx.x + 256 * u, 0), nblk - 1)];
+        constexpr int PER_ROW = K / 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = min((int)threadIdx.x + 256 * u, FUS_FRAMES * PER_ROW - 1);
+            const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
+            const int f = min(f_lo + fr, T - 1);
+            mv[u] = reinterpret_cast<const float4*>(mags + ((size_t)row * T + f) * K)[c4];
+        }
+    };
+    if ((int)blockIdx.x < ntasks) prefetch(blockIdx.x);
+    __syncthreads();
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int row, nB0, f_lo, jb_min;
+        window_geometry(task, row, nB0, f_lo, jb_min);
+        const int f_hi = min(min(nB0 + FUS_BW - 1 + delay, N - 1) / U, T - 1);
+        // ---- 1. registers -> LDS
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bb = threadIdx.x + 256 * u, jb = jb_min + bb;
+            if (bb < nxb)
+                *reinterpret_cast<float4*>(Xs + fir_xoff(bb)) =
+                    (jb >= 0 && jb < nblk) ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        {
+            constexpr int PER_ROW = K / 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < FUS_FRAMES * PER_ROW) {
+                    float4 m = mv[u];
+                    if (scale.kind >= 0)
+                        m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
+                                        apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+                    const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
+                    *reinterpret_cast<float4*>(M + fr * ASTR + 4 * c4) = m;
+                }
+            }
+        }
+        __syncthreads();
+        if (task + (int)gridDim.x < ntasks) prefetch(task + gridDim.x);      // in flight during steps 2-4
+        // ---- 2. E / O blocks on the matrix cores
+#pragma unroll
+        for (int v = 0; v < UPW; ++v) {
+            const int unit = wib + 4 * v;
+            if (unit < UNITS) {
+                const int eo = unit / JT, jt = unit - eo * JT;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* arow = M + col * ASTR + 2 * kq + eo;
+#pragma unroll
+                for (int st = 0; st < KS; ++st)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8 * st], bfrag[v][st], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(eo * FUS_FRAMES + 4 * kq + r) * NJP + 16 * jt + col] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- 3. tap weights -> zero-padded FIR images
+        for (int pidx = threadIdx.x; pidx < FUS_FRAMES * NJP; pidx += 256) {
+            const int fr = pidx / NJP, j = pidx - fr * NJP;
+            const float E = S[fr * NJP + j], O = S[(FUS_FRAMES + fr) * NJP + j];
+            const int4 ti = *reinterpret_cast<const int4*>(tix + 4 * j);
+            const float4 we = *reinterpret_cast<const float4*>(twe + 4 * j);
+            const float4 wo = *reinterpret_cast<const float4*>(two + 4 * j);
+            float* dst = G + fr * gstride + padl;
+            if (ti.x >= 0) dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
+            if (ti.y >= 0) dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
+            if (ti.z >= 0) dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
+            if (ti.w >= 0) dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+        }
+        __syncthreads();
+        // ---- 4. time-varying FIR: this wavefront's 256 outputs (see tv_fir_kernel)
+        const int np0 = nB0 + wib * FIR_PASS;
+        if (np0 < N) {
+            const int m0 = np0 + delay;
+            const int jb = (m0 + 3) / 4 + 4 * a + 3 - sg * seglen;
+            const int jbc = min(max(jb, 0), (N - 1) / 4);
+            const int fA = min(max((4 * jbc) / U, f_lo), f_hi);
+            const int n1 = jb - fA * bpf + 1;
+            const float* GA = G + (fA - f_lo) * gstride + bq0;
+            const float* GB = G + (max(fA - 1, f_lo) - f_lo) * gstride + bq0;
+            const int bb0 = jb - jb_min;
+            float acc[FIR_OPL];
+#pragma unroll
+            for (int e = 0; e < FIR_OPL; ++e) acc[e] = 0.f;
+            float4 tq[5], xq;
+            auto fetch = [&](int i) {
+                const float* gp = (i < n1 ? GA : GB) + 4 * i;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) tq[q] = *reinterpret_cast<const float4*>(gp + 4 * q);
+                xq = *reinterpret_cast<const float4*>(Xs + fir_xoff(bb0 - i));
+            };
+            fetch(0);
+#pragma unroll 1
+            for (int i = 0; i < seglen; ++i) {
+                float tp[20];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    tp[4 * q] = tq[q].x; tp[4 * q + 1] = tq[q].y; tp[4 * q + 2] = tq[q].z; tp[4 * q + 3] = tq[q].w;
+                }
+                asm volatile("" ::"v"(tp[19]));
+                const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
+                fetch(min(i + 1, seglen - 1));
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int e = 0; e < FIR_OPL; ++e) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+            }
+            float half[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float keep = h ? acc[8 + k] : acc[k];
+                const float send = h ? acc[k] : acc[8 + k];
+                half[k] = keep + __shfl_xor(send, 32);
+            }
+            float quad[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float keep = g0 ? half[k] : half[4 + k];
+                const float send = g0 ? half[4 + k] : half[k];
+                quad[k] = keep + __shfl_xor(send, 4);
+            }
+            const int n = np0 + FIR_OPL * a + 4 * sg;
+            if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = make_float4(quad[0], quad[1], quad[2], quad[3]);
+        }
+        __syncthreads();                 // LDS is rewritten by the next window
+    }
+}
+
 __global__ void __launch_bounds__(256) tv_fir_generic_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ ir,
                                                            float* __restrict__ out, int R, int N, int T,
@@ -647,6 +859,73 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
     else if (K == 64) hipLaunchKernelGGL(fir_eo_kernel<32>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
     else if (K == 96) hipLaunchKernelGGL(fir_eo_kernel<48>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
     else hipLaunchKernelGGL(fir_eo_kernel<64>, grid, block, lds, stream, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, ir, nf, Lw, NJ, fpb, bias, sfn);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// Geometry of the fused FilteredNoise kernel for a shape, or false when it does not apply (the caller then
+// runs ddspp_fir_from_magnitudes_eo + ddspp_time_varying_fir).
+struct FusedGeom {
+    int U, delay, padl, dc, seglen, nb, wpr;
+};
+static bool fused_geometry(int N, int T, int K, int Lw, int delay_compensation, FusedGeom* g) {
+    if (N <= 0 || T <= 0 || N % T != 0 || (K != 32 && K != 64 && K != 96) || Lw != 2 * (K - 1)) return false;
+    const int U = N / T;
+    const int delay = delay_compensation < 0 ? (Lw - 1) / 2 - 1 : delay_compensation;
+    if (delay < 0 || U % 4 != 0 || N % 4 != 0) return false;
+    int padl = 18 - (delay + 3) % 4;
+    while ((delay - 3 + padl) % 4 != 0) ++padl;
+    const int dc = (padl - 6 + (delay + 3) % 4) / 4;
+    const int seglen = (((Lw + FIR_OPL - 1 + 3 + 3) / 4) + 3) / 4;
+    const int nb_need = (padl + Lw + 3) / 4 + 1;
+    const int nb = (dc + 4 * seglen + 2 > nb_need ? dc + 4 * seglen + 2 : nb_need);
+    const int frames_max = (FUS_BW + Lw + U - 2) / U + 2;
+    const int nxb = FUS_BW / 4 + 4 * seglen - 4;
+    if (frames_max > FUS_FRAMES || nb * 4 > 256 || nxb > 512 || 4 * (nxb + nxb / 4) + 4 > 1536 || dc < 3 ||
+        seglen > U / 4 || env_int("DDSPP_FIR_NO_FUSED", 0))
+        return false;
+    *g = FusedGeom{U, delay, padl, dc, seglen, nb, (N + FUS_BW - 1) / FUS_BW};
+    return true;
+}
+
+int ddspp_frequency_filter_eo_supported(int N, int T, int K, int Lw, int delay_compensation) {
+    FusedGeom g;
+    return fused_geometry(N, T, K, Lw, delay_compensation, &g) ? 1 : 0;
+}
+
+// ddsp.core.frequency_filter (frequency_impulse_response + framed fft_convolve) in one kernel; call only for
+// shapes ddspp_frequency_filter_eo_supported accepts.  Tables and scale arguments as ddspp_fir_from_magnitudes_eo.
+int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R,
+                              int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
+                              float bias, float exponent, float max_value, float threshold, float gain,
+                              hipStream_t stream) {
+    DDSPP_REQUIRE(audio && magnitudes && CE && CO && tap_idx && tap_we && tap_wo && out,
+                  "frequency_filter_eo: null buffer");
+    DDSPP_REQUIRE(R > 0, "frequency_filter_eo: bad dims");
+    DDSPP_REQUIRE(scale_kind >= -1 && scale_kind <= 2, "frequency_filter_eo: unknown scale_fn %d", scale_kind);
+    FusedGeom g;
+    DDSPP_REQUIRE(fused_geometry(N, T, K, Lw, delay_compensation, &g) && NJ == K / 2,
+                  "frequency_filter_eo: shape not supported (N=%d T=%d K=%d Lw=%d)", N, T, K, Lw);
+    DDSPP_REQUIRE((uintptr_t)audio % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)magnitudes % 16 == 0,
+                  "frequency_filter_eo: buffers must be 16-byte aligned");
+    const long long tasks = (long long)R * g.wpr;
+    DDSPP_REQUIRE(tasks < (1ll << 31), "frequency_filter_eo: too many tasks");
+    const int njp = 16 * ((NJ + 15) / 16);
+    const size_t lds = ((size_t)FUS_FRAMES * 256 + 1536 + (size_t)FUS_FRAMES * (K + 4) + 2 * FUS_FRAMES * njp +
+                        3 * 4 * njp) * sizeof(float);
+    long long wgs = (long long)256 * env_int("DDSPP_FUSED_WGS_PER_CU", 8);
+    if (wgs > tasks) wgs = tasks;
+    const dim3 grid((unsigned)wgs), block(256);
+    const ScaleFn sf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
+#define DDSPP_FUSED_LAUNCH(KH, JT)                                                                              \
+    hipLaunchKernelGGL((noise_fir_fused_kernel<KH, JT>), grid, block, lds, stream, audio, magnitudes, CE, CO,    \
+                       tap_idx, tap_we, tap_wo, out, R, N, T, g.U, Lw, NJ, g.delay, g.wpr, g.padl, g.nb,         \
+                       g.seglen, g.dc, bias, sf)
+    if (K == 32) DDSPP_FUSED_LAUNCH(16, 1);
+    else if (K == 64) DDSPP_FUSED_LAUNCH(32, 2);
+    else DDSPP_FUSED_LAUNCH(48, 3);
+#undef DDSPP_FUSED_LAUNCH
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -160,6 +160,19 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
 int ddspp_time_varying_fir(const float* audio, const float* impulse_response, float* out, int R, int N,
                            int T, int Lw, int delay_compensation, hipStream_t stream);
 
+/* ddsp.core.frequency_filter(audio, magnitudes, window_size) of DynamicSizeFilteredNoise.get_signal
+ * (filtered_noise_synth.py:27-42) in ONE kernel: the FIR design of ddspp_fir_from_magnitudes_eo (matrix cores) and
+ * the time-varying FIR of ddspp_time_varying_fir, with the impulse responses kept in LDS -- the [R,T,Lw] tensor
+ * is never written.  Same tables and scale arguments as ddspp_fir_from_magnitudes_eo; results equal the two-call
+ * form bit for bit.  ddspp_frequency_filter_eo_supported tells whether a shape fits (at most 16 frames reach a
+ * window of 1024 outputs, K in {32, 64, 96}, full window); otherwise use the two calls. */
+int ddspp_frequency_filter_eo_supported(int N, int T, int K, int Lw, int delay_compensation);
+int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R,
+                              int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
+                              float bias, float exponent, float max_value, float threshold, float gain,
+                              hipStream_t stream);
+
 /* stand-in for the reference's unseeded tf.random.uniform([B, N], -1, 1)
  * (filtered_noise_synth.py:39-40): Philox4x32-10, counter = offset + i / 4, key = seed. */
 int ddspp_uniform_noise(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t stream);

@@ -171,3 +171,27 @@ def test_scale_fn_fused_into_the_fir_design_is_bit_identical(K, scale):
                        core.frequency_filter(noise, scaled, window_size=synth.window_size))
     # python callables that the library does not know stay outside the kernel
     assert dp.DynamicSizeFilteredNoise(scale_fn=lambda x: torch.sigmoid(x)).raw_scale() is None
+
+
+@pytest.mark.parametrize('B,T,U,K', [(3, 40, 96, 96), (2, 25, 96, 64), (1, 300, 96, 96), (2, 30, 128, 32), (5, 11, 192, 96)])
+def test_fused_frequency_filter_equals_the_two_kernel_form(B, T, U, K, monkeypatch):
+    """ddspp_frequency_filter_eo (design on the matrix cores + time-varying FIR, impulse responses kept in LDS)
+    against ddspp_fir_from_magnitudes_eo + ddspp_time_varying_fir: same bits, with and without the fused scale_fn."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core, _lib
+    rng = np.random.default_rng(17)
+    N = T * U
+    raw = torch.as_tensor(rng.normal(0, 2, [B, T, K]).astype(np.float32), device='cuda')
+    noise = torch.as_tensor(rng.uniform(-1, 1, [B, N]).astype(np.float32), device='cuda')
+    synth = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=250 * U, initial_bias=-3.0)
+    Lw = 2 * (K - 1)
+    assert _lib.load().ddspp_frequency_filter_eo_supported(N, T, K, Lw, -1) == 1
+    for rs in (None, synth.raw_scale()):
+        mags = raw if rs is not None else synth.get_controls(raw)['magnitudes']
+        fused = core.frequency_filter(noise, mags, window_size=synth.window_size, raw_scale=rs)
+        monkeypatch.setenv('DDSPP_FIR_NO_FUSED', '1')
+        assert _lib.load().ddspp_frequency_filter_eo_supported(N, T, K, Lw, -1) == 0
+        split = core.frequency_filter(noise, mags, window_size=synth.window_size, raw_scale=rs)
+        monkeypatch.delenv('DDSPP_FIR_NO_FUSED')
+        assert fused.shape == split.shape == (B, N)
+        assert torch.equal(fused, split), (B, T, U, K, rs is not None)

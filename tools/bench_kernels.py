@@ -86,6 +86,11 @@ def main():
         x = core.uniform_noise((R, N), seed=1, device=dev)
         mn, av = timeit(lambda: core.fft_convolve(x, ir), args.reps)
         print(f'time_varying_fir         min {mn:8.3f} ms avg {av:8.3f} ms')
+    if 'noise' in which:
+        x = core.uniform_noise((R, N), seed=1, device=dev)
+        rs = noise.raw_scale()
+        mn, av = timeit(lambda: core.frequency_filter(x, mags, window_size=noise.window_size, raw_scale=rs), args.reps)
+        print(f'frequency_filter (raw magnitudes -> filtered noise) min {mn:8.3f} ms avg {av:8.3f} ms')
     if 'osc' in which:
         rows = min(args.osc_rows, R)
         c = additive._controls(amp[:rows], hd[:rows], inh[:rows], f0[:rows, :, :1].contiguous())
