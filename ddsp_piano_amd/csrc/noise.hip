@@ -456,10 +456,10 @@ __global__ void __launch_bounds__(256) tv_fir_kernel(const float* __restrict__ x
 // Persistent workgroups walk (row, window of 1024 outputs) tasks.  Per window:
 //   1. the noise blocks and the magnitudes of the (<= 16) frames that reach the window, prefetched into registers
 //      during the previous window's arithmetic, go to LDS (scale_fn applied to raw magnitudes on the way);
-//   2. E = M_even CE, O = M_odd CO on v_mfma_f32_16x16x4_f32: the 2 JT (E/O, 16-column block) units are dealt
-//      to the four wavefronts, whose table fragments stay in registers for the life of the workgroup;
-//   3. tap weights: every (frame, column) pair yields four taps of the frame's zero-padded FIR image in LDS
-//      (the zero pads are written once per workgroup);
+//   2. E = M_even CE, O = M_odd CO on v_mfma_f32_16x16x4_f32: wavefront jt < JT owns the 16-column block jt, its
+//      table fragments stay in registers for the life of the workgroup;
+//   3. tap weights straight from the accumulators: every (frame, column) pair yields four taps of the frame's
+//      zero-padded FIR image in LDS (the zero pads are written once per workgroup);
 //   4. the time-varying FIR of tv_fir_kernel: each wavefront 256 outputs, 64 FMAs per six ds_read_b128.
 // HBM sees the noise, 1.4 x the magnitudes and the output: the [R, T, Lw] impulse responses (0.58 GB written
 // and 0.8 GB read at batch 64) do not exist.
@@ -478,14 +478,12 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                        int nb, int seglen, int dc, float bias, ScaleFn scale) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int K = 2 * KH, KS = KH / 4, ASTR = K + 4, NJP = 16 * JT;
-    constexpr int UNITS = 2 * JT, UPW = (UNITS + 3) / 4;      // (E/O, column block) units, units per wavefront
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int gstride = nb * 4;                               // floats per staged frame image (<= 256)
     float* G = lds_dyn;                                       // [16][gstride]
     float* Xs = G + FUS_FRAMES * 256;                         // padded noise window
     float* M = Xs + 1536;                                     // [16][ASTR] magnitudes
-    float* S = M + FUS_FRAMES * ASTR;                         // [2][16][NJP] E and O
-    int* tix = reinterpret_cast<int*>(S + 2 * FUS_FRAMES * NJP);   // [NJP][4]
+    int* tix = reinterpret_cast<int*>(M + FUS_FRAMES * ASTR);       // [NJP][4]
     float* twe = reinterpret_cast<float*>(tix + 4 * NJP);
     float* two = twe + 4 * NJP;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -499,15 +497,16 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
         two[i] = j < NJ ? tap_wo[i] : 0.0f;
     }
     for (int i = threadIdx.x; i < FUS_FRAMES * 256; i += 256) G[i] = 0.0f;
-    float bfrag[UPW][KS];
-#pragma unroll
-    for (int v = 0; v < UPW; ++v) {
-        const int unit = min(wib + 4 * v, UNITS - 1);
-        const int eo = unit / JT, jt = unit - eo * JT;
-        const float* C = eo ? CO : CE;
+    // wavefront jt < JT owns the 16-column block jt: E and O fragments of the tables, and that block's tap weights
+    const int jt = min(wib, JT - 1);
+    float bE[KS], bO[KS];
+    {
         const int j = min(16 * jt + col, NJ - 1);
 #pragma unroll
-        for (int st = 0; st < KS; ++st) bfrag[v][st] = C[(4 * st + kq) * NJ + j];
+        for (int st = 0; st < KS; ++st) {
+            bE[st] = CE[(4 * st + kq) * NJ + j];
+            bO[st] = CO[(4 * st + kq) * NJ + j];
+        }
     }
 
     const int bpf = U / 4;                                    // input blocks per frame
@@ -574,34 +573,30 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
         }
         __syncthreads();
         if (task + (int)gridDim.x < ntasks) prefetch(task + gridDim.x);      // in flight during steps 2-4
-        // ---- 2. E / O blocks on the matrix cores
+        // ---- 2. E / O blocks on the matrix cores, 3. tap weights -> zero-padded FIR images (straight from the
+        // accumulators: lane holds E, O of frames 4 kq .. 4 kq + 3 at column 16 jt + col)
+        if (wib < JT) {
+            f32x4 accE = f32x4{0.f, 0.f, 0.f, 0.f}, accO = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* arow = M + col * ASTR + 2 * kq;
 #pragma unroll
-        for (int v = 0; v < UPW; ++v) {
-            const int unit = wib + 4 * v;
-            if (unit < UNITS) {
-                const int eo = unit / JT, jt = unit - eo * JT;
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* arow = M + col * ASTR + 2 * kq + eo;
-#pragma unroll
-                for (int st = 0; st < KS; ++st)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8 * st], bfrag[v][st], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(eo * FUS_FRAMES + 4 * kq + r) * NJP + 16 * jt + col] = acc[r];
+            for (int st = 0; st < KS; ++st) {
+                const float2 am = *reinterpret_cast<const float2*>(arow + 8 * st);
+                accE = __builtin_amdgcn_mfma_f32_16x16x4f32(am.x, bE[st], accE, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_16x16x4f32(am.y, bO[st], accO, 0, 0, 0);
             }
-        }
-        __syncthreads();
-        // ---- 3. tap weights -> zero-padded FIR images
-        for (int pidx = threadIdx.x; pidx < FUS_FRAMES * NJP; pidx += 256) {
-            const int fr = pidx / NJP, j = pidx - fr * NJP;
-            const float E = S[fr * NJP + j], O = S[(FUS_FRAMES + fr) * NJP + j];
+            const int j = 16 * jt + col;
             const int4 ti = *reinterpret_cast<const int4*>(tix + 4 * j);
             const float4 we = *reinterpret_cast<const float4*>(twe + 4 * j);
             const float4 wo = *reinterpret_cast<const float4*>(two + 4 * j);
-            float* dst = G + fr * gstride + padl;
-            if (ti.x >= 0) dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
-            if (ti.y >= 0) dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
-            if (ti.z >= 0) dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
-            if (ti.w >= 0) dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float E = accE[r], O = accO[r];
+                float* dst = G + (4 * kq + r) * gstride + padl;
+                if (ti.x >= 0) dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
+                if (ti.y >= 0) dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
+                if (ti.z >= 0) dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
+                if (ti.w >= 0) dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+            }
         }
         __syncthreads();
         // ---- 4. time-varying FIR: this wavefront's 256 outputs (see tv_fir_kernel)
@@ -912,8 +907,7 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
     const long long tasks = (long long)R * g.wpr;
     DDSPP_REQUIRE(tasks < (1ll << 31), "frequency_filter_eo: too many tasks");
     const int njp = 16 * ((NJ + 15) / 16);
-    const size_t lds = ((size_t)FUS_FRAMES * 256 + 1536 + (size_t)FUS_FRAMES * (K + 4) + 2 * FUS_FRAMES * njp +
-                        3 * 4 * njp) * sizeof(float);
+    const size_t lds = ((size_t)FUS_FRAMES * 256 + 1536 + (size_t)FUS_FRAMES * (K + 4) + 3 * 4 * njp) * sizeof(float);
     long long wgs = (long long)256 * env_int("DDSPP_FUSED_WGS_PER_CU", 8);
     if (wgs > tasks) wgs = tasks;
     const dim3 grid((unsigned)wgs), block(256);
