@@ -36,6 +36,7 @@ struct OscParams {
     const float* __restrict__ amp;     // [R, T]
     const float* __restrict__ hd;      // [R, T, H]
     const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts)
+    const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
     const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
     const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)
     float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
@@ -578,14 +579,28 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         vk[j] = vc - vs[j] * H;
         kmul[j] = (float)(vk[j] + 1);
     }
+    // Harmonics that are silent in every frame of the row (above Nyquist for this note, or a silent voice) never
+    // get a lane in the compacted oscillator bank, so their start phases are not needed: a 64-lane group made only
+    // of such harmonics reads frame 0 over and over (cache hits) instead of streaming its [T, 64] slice.
+    bool need[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) need[j] = true;
+    if (p.audible) {
+        int amax = 0;
+        for (int t0 = lane; t0 < T; t0 += 64) amax = max(amax, p.audible[(size_t)row * T + t0]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) need[j] = __any(valid[j] && vk[j] < amax);
+    }
     // raw loads and arithmetic are kept apart (and free of branches) so that a batch of frames is
     // fetched with all its loads in flight at once
     const float* shp = p.shifts ? p.shifts : p.hd;          // no shifts: any finite [R, T, H] buffer ...
     const float sh_on = p.shifts ? 1.0f : 0.0f;             // ... times 0
     auto hf_raw = [&](int tt, float* rf, float* rs) {
-        const size_t fr = (size_t)row * T + tt;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
+            const size_t fr = (size_t)row * T + (need[j] ? tt : 0);
             rf[j] = p.f0[fr * S + vs[j]];
             rs[j] = shp[fr * H + vk[j]];
         }
@@ -1103,6 +1118,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
 
     OscParams p{};
     p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
+    p.audible = audible;
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
     p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;
