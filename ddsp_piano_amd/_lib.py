@@ -22,7 +22,7 @@ SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'oscillator.hip', 'resample.hip
 ARCH = 'gfx950'
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
-PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize']}
+PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize']}
 
 DDSPP_OK = 0
 DDSPP_EINVAL = -22
