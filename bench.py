@@ -297,6 +297,11 @@ def main():
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
     if rank == 0 and not args.no_single_stream:
+        # PianoModel.call's form (piano_model.py:160): the outputs dict, i.e. the mix plus the last voice's stems
+        dd = time_steps(lambda: pg(feats, return_outputs_dict=True), 10, 2)
+        extra['outputs_dict_call'] = {'workload': 'the headline batch through group(features, return_outputs_dict=True)',
+                                      'ms_per_step': dd / 10 * 1e3, 'rtf': (B * N * 10 / dd) / sr}
+    if rank == 0 and not args.no_single_stream:
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)

@@ -109,9 +109,13 @@ def run(plan, inputs, noise=None, need_stems=True):
     """Execute the polyphonic DAG with voices batched.  Returns the ddsp-style outputs dict, or None
     when the inputs do not fit the batched kernels (caller then walks the DAG node by node).
 
-    need_stems=False (a plain ``group(features)`` call that only wants the audio): the additive
-    branch runs through the compacted kernel, which forms the per-segment mix directly -- the
-    `additive` / `voices` entries are then absent from the outputs dict."""
+    need_stems=False (a plain ``group(features)`` call that only wants the audio): the additive branch runs through
+    the compacted kernel, which forms the per-segment mix directly -- the `additive` / `noise` / `voices` entries
+    are then absent from the outputs dict.
+    need_stems='last' (``group(features, return_outputs_dict=True)``, what PianoModel.call does,
+    piano_model.py:160): the same fast mix, plus the entries the reference's dict has -- the re-used processors'
+    outputs, i.e. the LAST voice's stems and controls.
+    need_stems=True / 'all': every voice's stems ([B, P, N] under outputs['voices']), per-voice kernels."""
     P = plan.n_synths
     add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
     hd, vm = _stack_voices(add_ctl[1])               # [R, T, H]; the widest control decides the row order
@@ -140,7 +144,9 @@ def run(plan, inputs, noise=None, need_stems=True):
     vmi = 1 if vm else 0
 
     # --- additive branch ------------------------------------------------------------------------
-    compact = (not need_stems) and additive.inference and P * S <= 64 and N % 4 == 0
+    want_all = need_stems is True or need_stems == 'all'
+    want_last = need_stems == 'last'
+    compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
     ctl = additive._controls(amp, hd, inh, f0, want_counts=compact)
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
@@ -166,6 +172,14 @@ def run(plan, inputs, noise=None, need_stems=True):
     else:
         noise_sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
 
+    def per_voice(x, shape):       # rows -> [B, P, ...] (a transposed view when the rows are voice major)
+        return x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape)
+
+    last = P - 1
+
+    def voice(x, shape):
+        return per_voice(x, shape)[:, last]
+
     # --- add chain ------------------------------------------------------------------------------
     dry = torch.empty((B, N), dtype=torch.float32, device=dev)
     if compact:
@@ -173,7 +187,24 @@ def run(plan, inputs, noise=None, need_stems=True):
                                             vmi, _stream()))
         outputs = {'inputs': inputs}
         outputs.update(inputs)
-        outputs[plan.add.name] = {'signal': dry, 'controls': {}}
+        add_controls = {}
+        if want_last:
+            # what the node-by-node walk leaves behind: the three re-used processors hold the LAST voice's stems and
+            # controls (polyphonic_dag.py re-uses the objects).  Its additive stem is one more B-row launch; its
+            # noise stem is already a row block of noise_sig.
+            lc = {k: voice(ctl[k], sh).contiguous() for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
+                                                                   ('harmonic_shifts', (T, H)), ('f0_hz', (T, S)))}
+            additive_last = core.harmonic_synthesis_fused(lc['f0_hz'], lc['amplitudes'].reshape(B, T),
+                                                          lc['harmonic_distribution'], lc['harmonic_shifts'], N,
+                                                          additive.sample_rate, additive.inference)
+            noise_last = voice(noise_sig, (N,))
+            mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
+                noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
+            outputs[additive.name] = {'signal': additive_last, 'controls': lc}
+            outputs[noise_p.name] = {'signal': noise_last, 'controls': {'magnitudes': mags_last}}
+            add_controls = {'signal_1': noise_last, 'signal_2': additive_last} if P > 1 else \
+                {'signal_0': noise_last, 'signal_1': additive_last}
+        outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
         module_outputs = outputs[plan.add.name]
         if plan.reverb is not None:
             module_outputs = plan.reverb(dry, *[inputs[k] for k in plan.reverb_keys], return_outputs_dict=True)
@@ -183,15 +214,8 @@ def run(plan, inputs, noise=None, need_stems=True):
     _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), B, P, N, N,
                                             vmi, _stream()))
 
-    def per_voice(x, shape):       # rows -> [B, P, ...] (a transposed view when the rows are voice major)
-        return x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape)
-
     additive_sig = per_voice(additive_sig, (N,))
     noise_sig = per_voice(noise_sig, (N,))
-    last = P - 1
-
-    def voice(x, shape):
-        return per_voice(x, shape)[:, last]
 
     outputs = {'inputs': inputs}
     outputs.update(inputs)

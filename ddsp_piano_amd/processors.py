@@ -95,8 +95,9 @@ class ProcessorGroup:
         return list(self._processors)
 
     def __call__(self, inputs, return_outputs_dict=False, **kwargs):
-        if not return_outputs_dict:
-            kwargs.setdefault('need_stems', False)     # audio only: the batched route may skip voice stems
+        # audio only: the batched route skips the voice stems; outputs dict: it adds what the reference's dict holds
+        # (the last voice's stems, polyphonic_dag.py re-uses the processors); need_stems=True: every voice's stems
+        kwargs.setdefault('need_stems', 'last' if return_outputs_dict else False)
         outputs = self.get_controls(inputs, **kwargs)
         signal = self.get_signal(outputs)
         if return_outputs_dict:

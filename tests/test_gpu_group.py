@@ -104,7 +104,7 @@ def test_fast_path_zero_copy_views_and_no_reverb(voice_major, stems):
     orig = b.noise.get_signal
     b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
     if stems:
-        oa, ob = a(feats, return_outputs_dict=True), b(feats, return_outputs_dict=True)
+        oa, ob = a(feats, return_outputs_dict=True, need_stems=True), b(feats, return_outputs_dict=True)
         ya, yb = oa['signal'], ob['signal']
         for name in ('additive', 'noise'):             # the last voice's stems, as the node-by-node walk leaves them
             assert (oa['controls'][name]['signal'] - ob['controls'][name]['signal']).abs().max().item() < 2e-6
@@ -327,3 +327,33 @@ def test_parallelizer_views_feed_the_group_without_copies():
         noise.seed = 11
         outs.append(dp.ProcessorGroup(dag)({k: v for k, v in f.items() if k not in merged}))
     assert outs[0].shape == (B, T * 96) and torch.equal(outs[0], outs[1])
+
+
+def test_outputs_dict_routes_agree():
+    """group(features, return_outputs_dict=True) -- PianoModel.call's form (piano_model.py:160) -- runs the compacted
+    mix and adds the last voice's stems; need_stems=True computes every voice's stems.  Same dict entries, same audio."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(8)
+    B, P, T, H, K, S, sr, L = 2, 4, 25, 128, 96, 1, 24000, 3000
+    feats = {k: torch.as_tensor(v, device='cuda') for k, v in _features(rng, B, P, T, H, K, S, L).items()}
+    N = T * 96
+    noises = [torch.as_tensor(rng.uniform(-1, 1, [B, N]).astype(np.float32), device='cuda') for _ in range(P)]
+    outs = {}
+    for mode in ('last', True, False):
+        dag, gnoise = _build(dp, P, sr)
+        gnoise.noise_override = list(noises)
+        pg = dp.ProcessorGroup(dag)
+        outs[mode] = pg(feats, return_outputs_dict=True, need_stems=mode) if mode is not False else \
+            {'signal': pg(feats), 'controls': None}
+    last, full, audio = outs['last'], outs[True], outs[False]
+    assert torch.equal(last['signal'], audio['signal'])                       # same kernels as the audio-only call
+    assert (last['signal'] - full['signal']).abs().max().item() < 5e-6       # summation order of the voices differs
+    cl, cf = last['controls'], full['controls']
+    assert 'voices' not in cl and cf['voices']['additive'].shape == (B, P, N)
+    for name in ('additive', 'noise'):
+        assert torch.equal(cl[name]['signal'], cf[name]['signal']), name     # the last voice's stems: same kernels
+        for k in cf[name]['controls']:
+            assert torch.equal(cl[name]['controls'][k], cf[name]['controls'][k]), (name, k)
+    assert set(cl['add']['controls']) == set(cf['add']['controls'])
+    assert (cl['add']['signal'] - cf['add']['signal']).abs().max().item() < 5e-6
+    assert cl['out'] is cl['reverb'] and 'reverb_ir' in cl and 'amplitudes_0' in cl
