@@ -732,12 +732,20 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
     const int row = (int)(gid / VP), v = (int)(gid - (size_t)row * VP);
     float a = 0.0f;
     int span = 0;
-    for (int c = 0; c <= npre; ++c) {
-        if (c == span * cps && span < spans) {
-            astart[((size_t)row * spans + span) * VP + v] = a;
-            ++span;
+    constexpr int NB = 16;              // end phases fetched per batch: the adds are sequential, the loads are not
+    for (int c0 = 0; c0 <= npre; c0 += NB) {
+        float e[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) e[u] = ework[((size_t)row * npre + min(c0 + u, max(npre - 1, 0))) * VP + v];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u;
+            if (c <= npre && c == span * cps && span < spans) {
+                astart[((size_t)row * spans + span) * VP + v] = a;
+                ++span;
+            }
+            if (c < npre) a = a + e[u];
         }
-        if (c < npre) a = a + ework[((size_t)row * npre + c) * VP + v];
     }
 }
 
@@ -1107,7 +1115,10 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     sp = (nchunks + cps - 1) / cps;
     const int vpl_pre = pick_vpl(V);
     const int VP = vpl_pre * 64;
-    const int wmax = (P * V + 127) / 128;              // partial rows per segment: 128 oscillators per wavefront slot
+    // A wavefront slot carries 128 audible oscillators (2 per lane); when that leaves the chip short of wavefronts
+    // (single segments: B * spans * slots < ~2 per SIMD) it carries 64, twice the wavefronts at half the length.
+    const int vpl_c = ((long long)B * sp * ((P * V + 127) / 128) < env_int("DDSPP_OSC_COMPACT_VPL1_BELOW", 2048)) ? 1 : 2;
+    const int wmax = (P * V + 64 * vpl_c - 1) / (64 * vpl_c);      // partial rows (wavefront slots) per segment
 
     float* astart = (float*)workspace;
     float* ework = astart + (size_t)R * sp * VP;           // chunk end phases (chunk-parallel pre-pass only)
@@ -1177,8 +1188,12 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots; p.vmajor = voice_major ? 1 : 0;
     p.nk = nk; p.wcount = wcount; p.out = partial;
     const size_t lds = ((size_t)4 * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
-    hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256), lds,
-                       stream, p);
+    if (vpl_c == 1)
+        hipLaunchKernelGGL((osc_kernel<1, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256),
+                           lds, stream, p);
+    else
+        hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256),
+                           lds, stream, p);
     // 4. slots -> audio
     hipLaunchKernelGGL(osc_partial_sum_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
                        partial, wcount, audio, B, N, wmax, sp, cps);
