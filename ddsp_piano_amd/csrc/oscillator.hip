@@ -722,17 +722,182 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     }
 }
 
+// Chunk-parallel pre-pass for a few long rows (a whole file as one segment): one wavefront per (row, chunk) writes
+// the chunk's end phase e = (sum of the chunk's 1000 omegas, sequentially in float32) % 2 pi.  All frames the chunk
+// touches are fetched in one batch; a chunk whose oscillators keep their frequency (a held note -- nearly all of
+// them) is 1000 plain adds of a constant, other chunks interpolate the frequency per sample out of LDS.  Same
+// arithmetic as osc_kernel<.., MODE_PREPASS> (which walks every chunk through the full block machinery: 0.50 ms for
+// a 136 s file against 0.1 ms here) and as osc_prepass_fused_kernel.
+constexpr int PRE_FR = 24;              // frames a chunk may touch (1000 / U + 3)
+template <int VPL>
+__global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int task = wave_uniform(blockIdx.x * 4 + wib);
+    if (task >= p.R * p.npre) return;
+    const int row = task / p.npre, chunk = task - row * p.npre;
+    const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
+    float* hfs = lds_dyn + (size_t)wib * PRE_FR * 64 * VPL;          // [frame][j][lane]
+    int vk[VPL], vs[VPL], vidx[VPL];
+    bool valid[VPL];
+    float kmul[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int v = lane + 64 * j;
+        vidx[j] = v;
+        valid[j] = v < p.V;
+        const int vc = min(v, p.V - 1);
+        vs[j] = vc / H;
+        vk[j] = vc - vs[j] * H;
+        kmul[j] = (float)(vk[j] + 1);
+    }
+    const int n_lo = chunk * DDSPP_CHUNK, n_hi = min(n_lo + DDSPP_CHUNK, N);
+    const int t_lo = n_lo / U;
+    const int nfr = (n_hi - 1) / U - t_lo + 2;                       // frames t_lo .. t_last + 1
+    // ---- all frames of the chunk in one batch: branch-free addresses, every load issued before the first use
+    const float* shp = p.shifts ? p.shifts : p.hd;         // no shifts: any finite [R, T, H] buffer, times 0
+    const float sh_on = p.shifts ? 1.0f : 0.0f;
+    const float* f0p[VPL];
+    const float* shq[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        f0p[j] = p.f0 + (size_t)row * T * S + vs[j];
+        shq[j] = shp + (size_t)row * T * H + vk[j];
+    }
+    float rf[PRE_FR][VPL], rs[PRE_FR][VPL];
+#pragma unroll
+    for (int u = 0; u < PRE_FR; ++u) {
+        const int fr = wave_uniform(min(t_lo + min(u, nfr - 1), T - 1));
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            rf[u][j] = f0p[j][(size_t)fr * S];
+            rs[u][j] = shq[j][(size_t)fr * H];
+        }
+    }
+    bool same = true;
+    float hf0[VPL];
+#pragma unroll
+    for (int u = 0; u < PRE_FR; ++u)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            float f = rf[u][j] * kmul[j];
+            f = f * (1.0f + rs[u][j] * sh_on);
+            f = valid[j] ? f : 0.0f;
+            if (u == 0) hf0[j] = f;
+            same = same && (f == hf0[j]);
+            hfs[(u * VPL + j) * 64 + lane] = f;
+        }
+    float ph[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) ph[j] = 0.0f;
+    if (__all(same)) {
+        float om[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) om[j] = omega_of<false>(hf0[j], p.sr, p.rsr);
+        for (int n = n_lo; n < n_hi; n += BLK) {          // chunk lengths are multiples of BLK (U and 1000 are)
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) ph[j] = ph[j] + om[j];
+        }
+    } else {
+        float x0[VPL], x1[VPL];
+        int tt = 0, r = n_lo - t_lo * U;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            x0[j] = hfs[(0 * VPL + j) * 64 + lane];
+            x1[j] = hfs[(1 * VPL + j) * 64 + lane];
+        }
+        for (int n = n_lo; n < n_hi; ++n) {
+            const float wl = wlin_c[n];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const float fe = x0[j] + (x1[j] - x0[j]) * wl;
+                ph[j] = ph[j] + omega_of<false>(fe, p.sr, p.rsr);
+            }
+            if (++r == U) {
+                r = 0;
+                ++tt;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    x0[j] = x1[j];
+                    x1[j] = hfs[(min(tt + 1, nfr - 1) * VPL + j) * 64 + lane];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) p.ework[((size_t)row * p.npre + chunk) * p.VP + vidx[j]] = mod_2pi(ph[j]);
+}
+
 // Sequential (float32) scan of the chunk end phases: astart[row, span, v] = e[0] + ... + e[c0-1]
 // in exactly the order of `tf.cumsum(offsets, axis=1)` in ddsp.core.angular_cumsum.
+// The adds of one (row, oscillator) are a serial chain, the loads are not: a workgroup owns 64 oscillators of a
+// row, its four wavefronts fetch the next SCAN_CT chunks x 64 values into registers (all loads in flight) while
+// wavefront 0 adds up the current tile out of LDS.  (A thread per chain with its own loads took 0.38 ms for a
+// 136 s file: sixteen rows are twelve wavefronts, each paying the memory latency two hundred times.)
+constexpr int SCAN_CT = 256;           // chunks per tile: 64 KB of LDS, 64 registers per thread
 __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __restrict__ ework,
                                                             float* __restrict__ astart, int R,
                                                             int npre, int VP, int spans, int cps) {
+    __shared__ float tile[SCAN_CT * 64];
+    const int groups = VP / 64;
+    const int row = blockIdx.x / groups, v0 = (blockIdx.x - row * groups) * 64;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    constexpr int PER = SCAN_CT / 4;                      // chunks each wavefront fetches per tile
+    float pre[PER];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = min(c0 + wib * PER + u, npre - 1);
+            pre[u] = ework[((size_t)row * npre + c) * VP + v0 + lane];
+        }
+    };
+    fetch(0);
+    float a = 0.0f;
+    int span = 0, until = 0;                              // chunks left before the next span starts
+    float* dst = astart + (size_t)row * spans * VP + v0 + lane;
+    for (int c0 = 0; c0 <= npre; c0 += SCAN_CT) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) tile[(wib * PER + u) * 64 + lane] = pre[u];
+        __syncthreads();
+        if (c0 + SCAN_CT <= npre) fetch(c0 + SCAN_CT);     // in flight while wavefront 0 scans
+        if (wib == 0) {
+            for (int u0 = 0; u0 < SCAN_CT; u0 += 16) {
+                float e[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) e[u] = tile[(u0 + u) * 64 + lane];
+                if (c0 + u0 > npre) break;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = c0 + u0 + u;
+                    if (until == 0 && span < spans && c <= npre) {      // c == span * cps
+                        *dst = a;
+                        dst += VP;
+                        ++span;
+                        until = cps;
+                    }
+                    --until;
+                    if (c < npre) a = a + e[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Few chunks (a 3 s segment has 72): one thread per chain, loads batched by 16.
+__global__ void __launch_bounds__(256) osc_offset_scan_short_kernel(const float* __restrict__ ework,
+                                                                  float* __restrict__ astart, int R,
+                                                                  int npre, int VP, int spans, int cps) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)R * VP) return;
     const int row = (int)(gid / VP), v = (int)(gid - (size_t)row * VP);
     float a = 0.0f;
     int span = 0;
-    constexpr int NB = 16;              // end phases fetched per batch: the adds are sequential, the loads are not
+    constexpr int NB = 16;
     for (int c0 = 0; c0 <= npre; c0 += NB) {
         float e[NB];
 #pragma unroll
@@ -747,6 +912,19 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
             if (c < npre) a = a + e[u];
         }
     }
+}
+
+static int env_int(const char* name, int dflt);
+
+static void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
+                               hipStream_t stream) {
+    const size_t nthr = (size_t)R * VP;
+    if (npre > SCAN_CT && !env_int("DDSPP_OSC_SHORT_SCAN", 0))
+        hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)(nthr / 64)), dim3(256), 0, stream, ework, astart, R,
+                           npre, VP, spans, cps);
+    else
+        hipLaunchKernelGGL(osc_offset_scan_short_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                           ework, astart, R, npre, VP, spans, cps);
 }
 
 // nk[b, span, p] = number of leading harmonics of voice p that have a non-zero amplitude
@@ -938,10 +1116,7 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
             const int nblk_pre = p.R * p.npre;
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), blk, lds,
                                stream, p);
-            const size_t nthr = (size_t)p.R * p.VP;
-            hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256),
-                               0, stream, p.ework, const_cast<float*>(p.astart), p.R, p.npre, p.VP,
-                               p.spans, p.cps);
+            launch_offset_scan(p.ework, const_cast<float*>(p.astart), p.R, p.npre, p.VP, p.spans, p.cps, stream);
         }
         if (sum)
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true>), dim3(nblk_main), blk, lds, stream, p);
@@ -1156,9 +1331,16 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
             }
         } else {
             q.ework = ework;
+            const bool chunk_kernel = vpl_pre <= 2 && DDSPP_CHUNK / U + 3 <= PRE_FR && !env_int("DDSPP_OSC_OLD_CHUNK_PREPASS", 0);
+            if (chunk_kernel) {
+                const unsigned wgs = (unsigned)((R * q.npre + 3) / 4);
+                const size_t clds = (size_t)4 * PRE_FR * 64 * vpl_pre * sizeof(float);
+                if (vpl_pre == 1) hipLaunchKernelGGL((osc_prepass_chunk_kernel<1>), dim3(wgs), dim3(256), clds, stream, q);
+                else hipLaunchKernelGGL((osc_prepass_chunk_kernel<2>), dim3(wgs), dim3(256), clds, stream, q);
+            }
             const dim3 grid((unsigned)(R * q.npre)), blk(64);
             const size_t plds = ((size_t)(TILE * TSTRIDE) + 2 * 32) * sizeof(float);
-            switch (vpl_pre) {
+            if (!chunk_kernel) switch (vpl_pre) {
                 case 1: hipLaunchKernelGGL((osc_kernel<1, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
                 case 2: hipLaunchKernelGGL((osc_kernel<2, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
                 case 3: hipLaunchKernelGGL((osc_kernel<3, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
@@ -1166,9 +1348,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
                 case 6: hipLaunchKernelGGL((osc_kernel<6, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
                 default: hipLaunchKernelGGL((osc_kernel<8, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
             }
-            const size_t nthr = (size_t)R * VP;
-            hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                               ework, astart, R, q.npre, VP, sp, cps);
+            launch_offset_scan(ework, astart, R, q.npre, VP, sp, cps, stream);
         }
     }
     // 2. audible-harmonic counts per (segment, span, voice)

@@ -357,3 +357,32 @@ def test_outputs_dict_routes_agree():
     assert set(cl['add']['controls']) == set(cf['add']['controls'])
     assert (cl['add']['signal'] - cf['add']['signal']).abs().max().item() < 5e-6
     assert cl['out'] is cl['reverb'] and 'reverb_ir' in cl and 'amplitudes_0' in cl
+
+
+def test_chunk_prepass_kernel_equals_the_block_machinery(monkeypatch):
+    """Few long rows: the dedicated chunk pre-pass (constant-frequency chunks as plain adds, moving ones interpolated
+    out of LDS) and the tiled offset scan give the bits of osc_kernel<MODE_PREPASS> + the per-thread scan."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(31)
+    B, P, T, H, sr = 1, 3, 3200, 128, 24000            # 307 chunks: tiled scan; pitch moves in the middle
+    N = T * 96
+    raw = synth_controls(rng, B * P, T, H, S=1, silent_frac=0.0)
+    raw['f0_hz'][:, T // 2:] *= np.float32(2 ** (2 / 12))
+    raw['f0_hz'][1, 100:160] *= np.linspace(1.0, 1.1, 60, dtype=np.float32)[:, None]        # a glide: frames differ
+    syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+    ctl = syn.get_controls(*[torch.as_tensor(raw[k], device='cuda') for k in
+                             ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')])
+    amp = ctl['amplitudes'].reshape(B * P, T).contiguous()
+    args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
+    new = core.polyphonic_additive(*args)
+    monkeypatch.setenv('DDSPP_OSC_OLD_CHUNK_PREPASS', '1')
+    old = core.polyphonic_additive(*args)
+    monkeypatch.delenv('DDSPP_OSC_OLD_CHUNK_PREPASS')
+    assert torch.isfinite(new).all() and new.abs().max().item() > 0
+    assert torch.equal(new, old)
+    monkeypatch.setenv('DDSPP_OSC_SHORT_SCAN', '1')            # a thread per chain instead of the tiled scan
+    assert torch.equal(core.polyphonic_additive(*args), new)
+    monkeypatch.delenv('DDSPP_OSC_SHORT_SCAN')
+    for spans in (1, 5, 307):                                 # and the span split stays invisible
+        assert (core.polyphonic_additive(*args, spans=spans) - new).abs().max().item() < 3e-6
