@@ -328,7 +328,9 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rtf': value / sr,
-            'config': {'workload': f'BASELINE config 3 per GPU: batch={B} x {args.seconds:g} s segments, '
+            'config': {'workload': ('BASELINE config 3 per GPU: ' if (B, P, H, K, S, sr, args.seconds, L) ==
+                                    (64, 16, 128, 96, 1, 24000, 3.0, 72000) else 'custom shape per GPU: ') +
+                                   f'batch={B} x {args.seconds:g} s segments, '
                                    f'poly={P}, {sr} Hz, 250 Hz controls, H={H}, K={K}, S={S}, '
                                    f'{args.ir_seconds:g} s reverb IR (L={L}); global batch {world * B}'
                                    + (' = config 4' if world * B == 512 else ''),
