@@ -293,12 +293,12 @@ def main():
     if rank == 0 and not args.no_single_stream:
         f1, _ = make_features(1, P, T, H, K, S, L, device, seed=7)
         pg1 = build_group(dp, P, sr)
-        d1 = time_steps(lambda: pg1(f1), 20, 3)
+        d1 = min(time_steps(lambda: pg1(f1), 20, 3) for _ in range(3))          # best of three runs of 20
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
     if rank == 0 and not args.no_single_stream:
         # PianoModel.call's form (piano_model.py:160): the outputs dict, i.e. the mix plus the last voice's stems
-        dd = time_steps(lambda: pg(feats, return_outputs_dict=True), 10, 2)
+        dd = min(time_steps(lambda: pg(feats, return_outputs_dict=True), 10, 2) for _ in range(2))
         extra['outputs_dict_call'] = {'workload': 'the headline batch through group(features, return_outputs_dict=True)',
                                       'ms_per_step': dd / 10 * 1e3, 'rtf': (B * N * 10 / dd) / sr}
     if rank == 0 and not args.no_single_stream:
@@ -306,7 +306,7 @@ def main():
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
         pgw = build_group(dp, P, sr)
-        dw = time_steps(lambda: pgw(fw), 5, 2)
+        dw = min(time_steps(lambda: pgw(fw), 5, 2) for _ in range(3))
         extra['whole_file'] = {'workload': f'B=1 x {Tw / 250:g} s in one segment, poly={P}, 2 s IR',
                                'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
         del fw, pgw
