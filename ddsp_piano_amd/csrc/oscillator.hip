@@ -60,7 +60,7 @@ enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
 
 constexpr int BLK = 8;        // samples per unrolled block; divides U and the 1000-sample chunk
 constexpr int TILE = 32;      // samples per LDS reduction tile
-constexpr int TSTRIDE = 65;   // words per tile row
+constexpr int TSTRIDE = 68;   // words per tile row: 16-byte aligned rows, 17 quads apart -> ds_read_b128 conflict free
 
 template <bool FAST>
 __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
@@ -408,10 +408,15 @@ osc_kernel(const OscParams p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int col = lane & 31, half = lane >> 5;
-        float s = 0.0f;
-        const float* src = tile + col * TSTRIDE + half * 32;
+        // eight 16-byte reads, four running sums (a single chain of 32 dependent adds costs ~5 cycles per add)
+        const float4* src = reinterpret_cast<const float4*>(tile + col * TSTRIDE + half * 32);
+        float4 s4 = src[0];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) s += src[i];
+        for (int i = 1; i < 8; ++i) {
+            const float4 v = src[i];
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        float s = (s4.x + s4.y) + (s4.z + s4.w);
         s += __shfl_xor(s, 32);
         if (p.groups == 1) {
             if (lane < count) out_row[nt0 + lane] = s;
