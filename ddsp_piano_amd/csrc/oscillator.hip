@@ -84,14 +84,14 @@ osc_kernel(const OscParams p) {
     int row, c0, c1;
     int cw = 0;                                            // compact mode: wavefront slot inside (segment, span)
     if (COMPACT) {
-        // workgroups (of 4 wavefront slots) per (segment, span): nslots / 4.  Workgroup index = slot group major,
+        // workgroups (of blockDim / 64 wavefront slots) per (segment, span).  Workgroup index = slot group major,
         // (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so every XCD gets the same
         // mix of busy (low slots) and idle (slots past the audible set, exit at once) workgroups, and the busy
         // ones are dispatched first.  (Slot-group minor with 4 groups parks all the work on half of the XCDs.)
         const int nbs = p.R * p.spans;
         const int g = task / nbs;
         const int bs = task - g * nbs;
-        cw = g * 4 + wib;                                  // then cw += nslots until the audible set is covered
+        cw = g * (int)(blockDim.x >> 6) + wib;             // then cw += nslots until the audible set is covered
         row = bs / p.spans;                                // = segment b
         const int span = bs - row * p.spans;
         c0 = span * p.cps;
@@ -110,7 +110,7 @@ osc_kernel(const OscParams p) {
     const int vbase = grp * p.vgrp;                       // first oscillator of this wavefront
     const int vlast = min(vbase + p.vgrp, p.V) - 1;       // last one (inclusive)
     float* tile = lds_dyn + (COMPACT ? wib : grp) * (TILE * TSTRIDE);
-    float* comb = lds_dyn + (COMPACT ? 4 : p.groups) * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
+    float* comb = lds_dyn + (COMPACT ? (int)(blockDim.x >> 6) : p.groups) * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
     int comb_buf = 0;
 
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
@@ -1368,16 +1368,21 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     // cw + nslots, ... when fewer slots than wmax are launched); a piano has about a third of its P * H partials
     // below Nyquist, the slots past the audible set exit at once (cheap: slot-group-major workgroup order)
     int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", wmax);
-    nslots = (nslots + 3) / 4 * 4;
-    if (nslots < 4) nslots = 4;
+    // wavefront slots per workgroup: slots past the audible set exit at once, but their workgroup keeps its LDS until
+    // its busy slots are done, which left ~5 of 16 wavefront places per CU idle with four-slot workgroups
+    // (batch 64: 2.51 ms per step with 4, 2.41 with 2, 2.36-2.41 with 1)
+    int wpw = env_int("DDSPP_OSC_COMPACT_WPW", 1);
+    if (wpw != 1 && wpw != 2 && wpw != 4) wpw = 1;
+    nslots = (nslots + wpw - 1) / wpw * wpw;
+    if (nslots < wpw) nslots = wpw;
     p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots; p.vmajor = voice_major ? 1 : 0;
     p.nk = nk; p.wcount = wcount; p.out = partial;
-    const size_t lds = ((size_t)4 * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
+    const size_t lds = ((size_t)wpw * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
     if (vpl_c == 1)
-        hipLaunchKernelGGL((osc_kernel<1, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256),
+        hipLaunchKernelGGL((osc_kernel<1, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / wpw))), dim3(64 * wpw),
                            lds, stream, p);
     else
-        hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / 4))), dim3(256),
+        hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / wpw))), dim3(64 * wpw),
                            lds, stream, p);
     // 4. slots -> audio
     hipLaunchKernelGGL(osc_partial_sum_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
