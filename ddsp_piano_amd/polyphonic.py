@@ -10,6 +10,8 @@ two routes against each other.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, core
@@ -67,6 +69,17 @@ def recognise(dag):
         if any('/' in k for k in reverb_keys):
             return None
     return Plan(additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, p)
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _same_buffer_slices(tensors, step_elems):
@@ -143,10 +156,41 @@ def run(plan, inputs, noise=None, need_stems=True):
     dev = hd.device
     vmi = 1 if vm else 0
 
-    # --- additive branch ------------------------------------------------------------------------
     want_all = need_stems is True or need_stems == 'all'
     want_last = need_stems == 'last'
     compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
+    # --- noise branch ---------------------------------------------------------------------------
+    fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
+
+    def noise_branch(noise):
+        nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
+        if noise is None:
+            override = getattr(noise_p, 'noise_override', None)
+            if override:
+                noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=0 if vm else 1)
+        if noise is None:
+            noise = noise_p.draw_noise(R, N, dev)
+        noise = core.tf_float32(noise).reshape(R, N)
+        if fuse_scale:
+            sig = core.frequency_filter(noise, mags, window_size=noise_p.window_size, raw_scale=noise_p.raw_scale())
+        else:
+            sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
+        return nctl, sig
+
+    # The noise branch does not depend on the additive one until the mix: it is enqueued on a side stream first, so
+    # the latency-bound parts of the additive chain (the one-wavefront-per-row pre-pass, kernel tails) overlap with it.
+    # (worth the two stream joins only for large batches / long files: 2 % there, a loss for a single 3 s segment)
+    side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= (1 << 24) and
+                                 os.environ.get('DDSPP_NO_SIDE_STREAM') != '1' and
+                                 not torch.cuda.is_current_stream_capturing()) else None
+    if side is not None:
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            nctl, noise_sig = noise_branch(noise)
+    else:
+        nctl, noise_sig = noise_branch(noise)
+    # --- additive branch ------------------------------------------------------------------------
     ctl = additive._controls(amp, hd, inh, f0, want_counts=compact)
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
@@ -157,20 +201,11 @@ def run(plan, inputs, noise=None, need_stems=True):
         additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                      ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
                                                      additive.sample_rate, additive.inference)
-    # --- noise branch ---------------------------------------------------------------------------
-    fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
-    nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
-    if noise is None:
-        override = getattr(noise_p, 'noise_override', None)
-        if override:
-            noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=0 if vm else 1)
-    if noise is None:
-        noise = noise_p.draw_noise(R, N, dev)
-    noise = core.tf_float32(noise).reshape(R, N)
-    if fuse_scale:
-        noise_sig = core.frequency_filter(noise, mags, window_size=noise_p.window_size, raw_scale=noise_p.raw_scale())
-    else:
-        noise_sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
+    if side is not None:
+        cur.wait_stream(side)
+        noise_sig.record_stream(cur)
+        if nctl is not None:
+            nctl['magnitudes'].record_stream(cur)
 
     def per_voice(x, shape):       # rows -> [B, P, ...] (a transposed view when the rows are voice major)
         return x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape)
