@@ -386,3 +386,26 @@ def test_chunk_prepass_kernel_equals_the_block_machinery(monkeypatch):
     monkeypatch.delenv('DDSPP_OSC_SHORT_SCAN')
     for spans in (1, 5, 307):                                 # and the span split stays invisible
         assert (core.polyphonic_additive(*args, spans=spans) - new).abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize('B,P,T,H,K,L', [
+    (2, 2, 1, 64, 32, 100),       # a single control frame
+    (1, 1, 2, 64, 32, 7),         # two frames, one voice, a 7-tap "room"
+    (1, 2, 5, 1, 32, 50),         # one harmonic
+    (1, 2, 5, 200, 64, 50),       # a harmonic count that is no multiple of the wavefront
+    (1, 17, 4, 32, 32, 50),       # more voices than the maestro model has
+])
+def test_odd_shapes_match_the_oracle(B, P, T, H, K, L):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(100 + T + H + P)
+    sr = 24000
+    feats = _features(rng, B, P, T, H, K, 1, L)
+    N = T * 96
+    noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
+    odag, _ = _build(O, P, sr)
+    ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': z} for z in noises]})
+    gdag, gnoise = _build(dp, P, sr)
+    gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
+    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}).cpu().numpy()
+    assert got.shape == ref.shape == (B, N)
+    assert rms_err(got, ref) < TOL * max(1.0, rms(ref))
