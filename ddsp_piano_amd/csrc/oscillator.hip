@@ -1325,8 +1325,15 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
         const bool memo = R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
         if (memo) {
             q.ework = astart;
-            const int tasks = R;
-            switch (vpl_pre) {
+            // one wavefront per 64 oscillators of a row when the rows alone leave SIMDs with a single wavefront: the walk
+            // is a chain of memory latencies (frames in batches), and 64 loads per batch fit the 63-deep load counter
+            const bool split = V % 64 == 0 && (long long)R * (V / 64) <= 8192 && !env_int("DDSPP_OSC_PREPASS_WHOLE_ROWS", 0);
+            const int tasks = split ? R * (V / 64) : R;
+            if (split) {
+                q.groups = V / 64;
+                q.vgrp = 64;
+            }
+            switch (split ? 1 : vpl_pre) {
                 case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
                 case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
                 case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
