@@ -24,7 +24,7 @@ struct InharmParams {
     float* __restrict__ amp_out;                      // [R, T]
     float* __restrict__ hd_out;                       // [R, T, H]
     float* __restrict__ shifts_out;                   // [R, T, H]
-    int* __restrict__ count_out;                      // [R, T] audible leading harmonics per frame, or null
+    int* __restrict__ count_out;                      // [R, T] audible leading harmonics per frame (+ bit 16: frequencies moved), or null
     int R, T, H, S;
     float nyquist, min_frequency, n_substrings;
     int normalize_after_nyquist_cut, normalize_below_nyquist;
@@ -43,10 +43,18 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
     if (frame0 >= nframes) return;
     const int H = p.H;
     float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
+    // for the "frequencies moved" flag: lane s < S holds f0[frame, s] of the batch's frames and of the frame before
+    float sub_f0[CTL_FPW + 1], in_before;
+    {
+        const size_t fb = frame0 > 0 ? frame0 - 1 : 0;
+        sub_f0[0] = p.f0_hz[fb * p.S + min(lane, p.S - 1)];
+        in_before = p.inharm_coef[fb];
+    }
 #pragma unroll
     for (int u = 0; u < CTL_FPW; ++u) {
         const size_t fr = min(frame0 + u, nframes - 1);
         raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
+        sub_f0[u + 1] = p.f0_hz[fr * p.S + min(lane, p.S - 1)];
         raw_in[u] = p.inharm_coef[fr];
         raw_amp[u] = p.amplitudes[fr];
 #pragma unroll
@@ -124,7 +132,14 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
-            if (lane == 0) p.count_out[frame] = last;
+            // bit 16: the frame's frequencies may differ from the previous frame's (any f0 sub-string or the clamped
+            // inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
+            // frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.
+            const int t = (int)(frame % (size_t)p.T);
+            const float in_prev = u > 0 ? raw_in[u > 0 ? u - 1 : 0] : in_before;
+            const bool moved = t > 0 && (sub_f0[u + 1] != sub_f0[u] || inharm != fmaxf(in_prev, 0.0f));
+            const int flag = __any(moved) ? (1 << 16) : 0;
+            if (lane == 0) p.count_out[frame] = last | flag;
         }
     }
 }

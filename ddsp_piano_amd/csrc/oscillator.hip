@@ -37,6 +37,7 @@ struct OscParams {
     const float* __restrict__ hd;      // [R, T, H]
     const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts)
     const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
+    int dbg_noflags;                   // DDSPP_OSC_NO_FLAGS=1: ignore bit 16 of audible, stream the controls instead (A/B switch)
     const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
     const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)
     float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     for (int j = 0; j < VPL; ++j) need[j] = true;
     if (p.audible) {
         int amax = 0;
-        for (int t0 = lane; t0 < T; t0 += 64) amax = max(amax, p.audible[(size_t)row * T + t0]);
+        for (int t0 = lane; t0 < T; t0 += 64) amax = max(amax, p.audible[(size_t)row * T + t0] & 0xffff);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
 #pragma unroll
@@ -631,7 +632,33 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     float x_prev[VPL];
     hf_of(0, x_prev);
     int t_checked = 0, last_change = 0;
+    // With the per-frame flags of the get_controls kernel (bit 16 of p.audible: frequencies may have moved) the
+    // detector reads one int per frame, 64 frames per load, instead of streaming the [T, V] controls.
+    int fl_base = 1;                   // first frame of the loaded batch of flags
+    unsigned long long fl_mask = 0;    // bit i: frame fl_base + i moved
+    int fl_before = 0;                 // last moved frame before fl_base
+    bool fl_loaded = false;
+    auto flagged_upto = [&](int t_need) {      // last_change := largest t <= t_need whose frequencies moved (0: none)
+        while (!fl_loaded || t_need >= fl_base + 64) {
+            if (fl_loaded) {
+                if (fl_mask) fl_before = fl_base + 63 - __builtin_clzll(fl_mask);
+                fl_base += 64;
+            }
+            const int tf = fl_base + lane;
+            const int v = tf <= T - 1 ? p.audible[(size_t)row * T + tf] : 0;
+            fl_mask = __ballot((v >> 16) & 1);
+            fl_loaded = true;
+        }
+        const int nbits = t_need - fl_base + 1;                       // frames fl_base .. t_need of the batch
+        const unsigned long long m = nbits >= 64 ? fl_mask : (nbits <= 0 ? 0ull : (fl_mask & ((1ull << nbits) - 1)));
+        last_change = m ? fl_base + 63 - __builtin_clzll(m) : fl_before;
+        t_checked = max(t_checked, t_need);
+    };
     auto check_upto = [&](int t_need) {
+        if (p.audible && !p.dbg_noflags) {
+            flagged_upto(t_need);
+            return;
+        }
         while (t_checked < t_need) {
             float rf[FB][VPL], rs[FB][VPL];
 #pragma unroll
@@ -983,7 +1010,7 @@ __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __rest
     const int n_lo = span * cps * DDSPP_CHUNK, n_hi = min((span + 1) * cps * DDSPP_CHUNK, N);
     const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
     int best = 0;
-    for (int t = t_lo; t <= t_hi; ++t) best = max(best, audible[(size_t)row * T + t]);
+    for (int t = t_lo; t <= t_hi; ++t) best = max(best, audible[(size_t)row * T + t] & 0xffff);
     const int B = R / P;
     const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
     nk[((size_t)b * spans + span) * P + v] = best;
@@ -1310,6 +1337,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     OscParams p{};
     p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
     p.audible = audible;
+    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
     p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;

@@ -103,9 +103,10 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
 /* InHarmonic.get_controls / MultiInharmonic.get_controls -- inharm_synth.py:167-219, :254-270
  * (+ get_inharmonic_freq :20-46).  amplitudes[R,T], harmonic_distribution[R,T,H], inharm_coef[R,T],
  * f0_hz[R,T,S] -> amplitudes_out[R,T] (already divided by S), harmonic_distribution_out[R,T,H],
- * harmonic_shifts_out[R,T,H]; audible_out[R,T] (int32, may be NULL): 1 + index of the last harmonic with
- * amplitudes_out * harmonic_distribution_out != 0 in the frame, which ddspp_polyphonic_additive accepts as
- * `audible` so that it need not scan the [R,T,H] tensor again. */
+ * harmonic_shifts_out[R,T,H]; audible_out[R,T] (int32, may be NULL): bits 0-15 = 1 + index of the last harmonic
+ * with amplitudes_out * harmonic_distribution_out != 0 in the frame, bit 16 = some f0_hz sub-string or the clamped
+ * inharm_coef differs from the previous frame's (the harmonic frequencies may have moved).
+ * ddspp_polyphonic_additive accepts it as `audible`, so that it need not scan the [R,T,H] tensors again. */
 int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
                               const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
                               float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
