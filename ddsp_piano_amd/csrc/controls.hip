@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
     float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
     // for the "frequencies moved" flag: lane s < S holds f0[frame, s] of the batch's frames and of the frame before
     float sub_f0[CTL_FPW + 1], in_before;
+    const int t_first = (int)(frame0 % (size_t)p.T);
     {
         const size_t fb = frame0 > 0 ? frame0 - 1 : 0;
         sub_f0[0] = p.f0_hz[fb * p.S + min(lane, p.S - 1)];
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
     for (int u = 0; u < CTL_FPW; ++u) {
         const size_t fr = min(frame0 + u, nframes - 1);
         raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
-        sub_f0[u + 1] = p.f0_hz[fr * p.S + min(lane, p.S - 1)];
+        sub_f0[u + 1] = p.S > 1 ? p.f0_hz[fr * p.S + min(lane, p.S - 1)] : raw_f0[u];   // (one sub-string: already here)
         raw_in[u] = p.inharm_coef[fr];
         raw_amp[u] = p.amplitudes[fr];
 #pragma unroll
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             // bit 16: the frame's frequencies may differ from the previous frame's (any f0 sub-string or the clamped
             // inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
             // frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.
-            const int t = (int)(frame % (size_t)p.T);
+            const int t = (t_first + u) % p.T;                    // frame index inside its row (32-bit; one 64-bit modulo per wavefront)
             const float in_prev = u > 0 ? raw_in[u > 0 ? u - 1 : 0] : in_before;
             const bool moved = t > 0 && (sub_f0[u + 1] != sub_f0[u] || inharm != fmaxf(in_prev, 0.0f));
             const int flag = __any(moved) ? (1 << 16) : 0;
