@@ -617,7 +617,9 @@ _plan_lock = threading.Lock()
 
 
 def _fftconv_plan(b, b_ir, n, l, device):
-    key = (b, b_ir, n, l, str(device))
+    # a plan carries its stream and work buffer while it executes: one plan per (shape, stream), so that callers that
+    # keep several segments in flight on different streams never share one
+    key = (b, b_ir, n, l, str(device), int(_stream().value or 0))
     with _plan_lock:
         plan = _plan_cache.get(key)
         if plan is None:

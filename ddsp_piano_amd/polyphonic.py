@@ -75,7 +75,7 @@ _side_streams = {}
 
 
 def _side_stream(device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)     # one per caller stream
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
