@@ -151,10 +151,11 @@ def load():
                 f'libddspp.so is missing at {LIB_PATH} and could not be built ({e}). '
                 'The DDSP-Piano MI355X synthesis path has no CPU fallback: run '
                 '`python -c "import __graft_entry__ as g; g.build()"` on a machine with hipcc.') from e
+    path = os.environ.get('DDSPP_LIB') or LIB_PATH        # DDSPP_LIB: another build of the same sources (A/B timing)
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
     except OSError as e:
-        raise RuntimeError(f'cannot load {LIB_PATH}: {e}. No CPU fallback exists.') from e
+        raise RuntimeError(f'cannot load {path}: {e}. No CPU fallback exists.') from e
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
