@@ -908,7 +908,7 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
     DDSPP_REQUIRE(tasks < (1ll << 31), "frequency_filter_eo: too many tasks");
     const int njp = 16 * ((NJ + 15) / 16);
     const size_t lds = ((size_t)FUS_FRAMES * 256 + 1536 + (size_t)FUS_FRAMES * (K + 4) + 3 * 4 * njp) * sizeof(float);
-    long long wgs = (long long)256 * env_int("DDSPP_FUSED_WGS_PER_CU", 8);
+    long long wgs = (long long)256 * env_int("DDSPP_FUSED_WGS_PER_CU", 32);
     if (wgs > tasks) wgs = tasks;
     const dim3 grid((unsigned)wgs), block(256);
     const ScaleFn sf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
