@@ -43,19 +43,10 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
     if (frame0 >= nframes) return;
     const int H = p.H;
     float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
-    // for the "frequencies moved" flag: lane s < S holds f0[frame, s] of the batch's frames and of the frame before
-    float sub_f0[CTL_FPW + 1], in_before;
-    const int t_first = (int)(frame0 % (size_t)p.T);
-    {
-        const size_t fb = frame0 > 0 ? frame0 - 1 : 0;
-        sub_f0[0] = p.f0_hz[fb * p.S + min(lane, p.S - 1)];
-        in_before = p.inharm_coef[fb];
-    }
 #pragma unroll
     for (int u = 0; u < CTL_FPW; ++u) {
         const size_t fr = min(frame0 + u, nframes - 1);
         raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
-        sub_f0[u + 1] = p.S > 1 ? p.f0_hz[fr * p.S + min(lane, p.S - 1)] : raw_f0[u];   // (one sub-string: already here)
         raw_in[u] = p.inharm_coef[fr];
         raw_amp[u] = p.amplitudes[fr];
 #pragma unroll
@@ -133,15 +124,24 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
-            // bit 16: the frame's frequencies may differ from the previous frame's (any f0 sub-string or the clamped
-            // inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
-            // frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.
-            const int t = (t_first + u) % p.T;                    // frame index inside its row (32-bit; one 64-bit modulo per wavefront)
-            const float in_prev = u > 0 ? raw_in[u > 0 ? u - 1 : 0] : in_before;
-            const bool moved = t > 0 && (sub_f0[u + 1] != sub_f0[u] || inharm != fmaxf(in_prev, 0.0f));
-            const int flag = __any(moved) ? (1 << 16) : 0;
-            if (lane == 0) p.count_out[frame] = last | flag;
+            if (lane == 0) p.count_out[frame] = last;        // bit 16 is added by frames_moved_kernel
         }
+    }
+}
+
+// Bit 16 of the per-frame info word: the frame's frequencies may differ from the previous frame's (some f0 sub-string
+// or the clamped inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
+// frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.  A kernel of
+// its own over the [R, T] scalars: inside the get_controls kernel the same test cost 0.05 ms.
+__global__ void __launch_bounds__(256) frames_moved_kernel(const float* __restrict__ f0, const float* __restrict__ inh,
+                                                         int* __restrict__ info, int R, int T, int S) {
+    const size_t n = (size_t)R * T;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256) {
+        const int t = (int)(g % (size_t)T);
+        if (t == 0) continue;
+        bool moved = fmaxf(inh[g], 0.0f) != fmaxf(inh[g - 1], 0.0f);
+        for (int s = 0; s < S; ++s) moved = moved || f0[g * S + s] != f0[(g - 1) * S + s];
+        if (moved) info[g] |= 1 << 16;
     }
 }
 
@@ -260,6 +260,9 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
     else if (hpl <= 2) hipLaunchKernelGGL(inharmonic_controls_kernel<2>, grid, block, 0, stream, p);
     else if (hpl <= 4) hipLaunchKernelGGL(inharmonic_controls_kernel<4>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(inharmonic_controls_kernel<8>, grid, block, 0, stream, p);
+    if (audible_out)
+        hipLaunchKernelGGL(frames_moved_kernel, dim3(stream_grid(frames)), dim3(256), 0, stream, f0_hz, inharm_coef,
+                           audible_out, R, T, S);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
