@@ -116,14 +116,13 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
         if (p.count_out) {
             // 1 + index of the last harmonic whose sample-rate amplitude amp * hd is not zero in this frame
             // (what ddspp_polyphonic_additive needs to know to skip the silent top of the harmonic range)
-            int last = 0;
+            int last = 0;                                      // wave-uniform: one ballot per 64 harmonics, no shuffles
 #pragma unroll
             for (int j = 0; j < HPL; ++j) {
                 const int k = lane + 64 * j;
-                if (k < H && amp * hd[j] != 0.0f) last = k + 1;
+                const unsigned long long live = __ballot(k < H && amp * hd[j] != 0.0f);
+                if (live) last = 64 * j + 64 - __builtin_clzll(live);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
             if (lane == 0) p.count_out[frame] = last;        // bit 16 is added by frames_moved_kernel
         }
     }
