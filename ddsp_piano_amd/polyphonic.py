@@ -180,7 +180,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     # The noise branch does not depend on the additive one until the mix: it is enqueued on a side stream first, so
     # the latency-bound parts of the additive chain (the one-wavefront-per-row pre-pass, kernel tails) overlap with it.
     # (worth the two stream joins only for large batches / long files: 2 % there, a loss for a single 3 s segment)
-    side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= (1 << 24) and
+    side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= int(os.environ.get('DDSPP_SIDE_STREAM_MIN', 1 << 24)) and
                                  os.environ.get('DDSPP_NO_SIDE_STREAM') != '1' and
                                  not torch.cuda.is_current_stream_capturing()) else None
     if side is not None:
