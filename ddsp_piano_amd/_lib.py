@@ -111,6 +111,7 @@ SIGNATURES = {
                                              c_float, c_float, c_void_p]),
     'ddspp_frequency_filter_eo_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'ddspp_frequency_filter_eo': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 + [c_void_p]),
+    'ddspp_frequency_filter_eo_voices': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 + [c_int] * 3 + [c_void_p]),
     'ddspp_time_varying_fir': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     'ddspp_uniform_noise': (c_int, [c_void_p, c_size_t, c_uint64, c_uint64, c_void_p]),

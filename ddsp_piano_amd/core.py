@@ -706,6 +706,13 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
     return out if padded == audio_size else out[:, :audio_size].contiguous()
 
 
+def frequency_filter_voice_sums(audio, magnitudes, window_size, raw_scale, n_voices, voices_per_row, voice_major):
+    """frequency_filter over the rows of a polyphonic group with `voices_per_row` consecutive voices of a segment
+    summed into one output row ([R / voices_per_row, N], segment major); None when the fused kernel does not apply."""
+    return _frequency_filter_fused(audio, magnitudes, window_size, 'same', raw_scale,
+                                   voices=(int(n_voices), int(voices_per_row), bool(voice_major)))
+
+
 def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale=None):
     """ddsp.core.frequency_filter -- call site filtered_noise_synth.py:41-42."""
     fused = _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale)
@@ -715,7 +722,7 @@ def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale
     return fft_convolve(audio, impulse_response, padding=padding)
 
 
-def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale):
+def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, voices=None):
     """FIR design + time-varying FIR in one kernel (ddspp_frequency_filter_eo) when the shape fits, else None.
     Bit-identical to the two-kernel form; the [B, T, Lw] impulse responses are never materialised."""
     if padding != 'same' or not (torch.is_tensor(audio) and torch.is_tensor(magnitudes)):
@@ -741,11 +748,21 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale):
         code, bias, prm = -1, 0.0, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0)
     else:
         code, bias, prm = raw_scale
-    out = torch.empty((b, n), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ddspp_frequency_filter_eo(_ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo),
-                                             _ptr(out), b, n, t, k, lw, nj, -1, int(code), float(bias),
-                                             prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
-                                             _stream()))
+    if voices is None:
+        out = torch.empty((b, n), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ddspp_frequency_filter_eo(_ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo),
+                                                 _ptr(out), b, n, t, k, lw, nj, -1, int(code), float(bias),
+                                                 prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+                                                 _stream()))
+        return out
+    n_voices, vq, vmajor = voices
+    if n_voices % vq or b % n_voices:
+        return None
+    out = torch.empty((b // vq, n), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ddspp_frequency_filter_eo_voices(
+        _ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), b, n, t, k, lw, nj, -1,
+        int(code), float(bias), prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'], n_voices, vq,
+        int(vmajor), _stream()))
     return out
 
 

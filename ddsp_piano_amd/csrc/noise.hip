@@ -473,9 +473,9 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                        const float* __restrict__ CE, const float* __restrict__ CO,     // [KH, NJ]
                        const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
                        const float* __restrict__ tap_wo,     // [NJ, 4]
-                       float* __restrict__ out,              // [R, N]
+                       float* __restrict__ out,              // [R / vq, N]
                        int R, int N, int T, int U, int Lw, int NJ, int delay, int windows_per_row, int padl,
-                       int nb, int seglen, int dc, float bias, ScaleFn scale) {
+                       int nb, int seglen, int dc, float bias, ScaleFn scale, int vq, int n_voices, int vmajor) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int K = 2 * KH, KS = KH / 4, ASTR = K + 4, NJP = 16 * JT;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -517,19 +517,29 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
     const int sg = 2 * h + (g0 ? 0 : 1);
     const int a = g0 ? (w < 4 ? w : (w < 16 ? w - 8 : w - 12)) : (w < 12 ? w - 4 : (w < 20 ? w - 8 : w - 16));
     const int bq0 = 4 * (dc - 3 + sg * seglen);
-    const int ntasks = R * windows_per_row;
+    // vq > 1: the filtered noise of vq consecutive voices of a segment is summed in registers and leaves as ONE row
+    // (out[b, q] = sum_i voice q vq + i), a quarter of the writes and of the mixer's reads for vq = 4.  The vq
+    // (voice, window) units of an output window are walked back to back by the same workgroup.
+    const int ntasks = (R / vq) * windows_per_row;             // output (row, window) tasks
+    const int n_seg = R / n_voices, pq = n_voices / vq;        // segments, output rows per segment
 
     // registers holding the NEXT window's inputs
     float4 xv[2], mv[2];
-    auto window_geometry = [&](int task, int& row, int& nB0, int& f_lo, int& jb_min) {
-        row = task / windows_per_row;
-        nB0 = (task - row * windows_per_row) * FUS_BW;
+    auto window_geometry = [&](int task, int iv, int& row, int& nB0, int& f_lo, int& jb_min) {
+        const int orow = task / windows_per_row;
+        if (vq == 1) {
+            row = orow;
+        } else {
+            const int b = orow / pq, v = (orow - b * pq) * vq + iv;
+            row = vmajor ? v * n_seg + b : b * n_voices + v;
+        }
+        nB0 = (task - orow * windows_per_row) * FUS_BW;
         f_lo = max(nB0 + delay - (Lw - 1), 0) / U;
         jb_min = (nB0 + delay + 3) / 4 + 4 - 4 * seglen;
     };
-    auto prefetch = [&](int task) {
+    auto prefetch = [&](int task, int iv) {
         int row, nB0, f_lo, jb_min;
-        window_geometry(task, row, nB0, f_lo, jb_min);
+        window_geometry(task, iv, row, nB0, f_lo, jb_min);
         const float4* xg = reinterpret_cast<const float4*>(x + (size_t)row * N);
 #pragma unroll
         for (int u = 0; u < 2; ++u) xv[u] = xg[min(max(jb_min + (int)threadIdx.x + 256 * u, 0), nblk - 1)];
@@ -542,11 +552,13 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
             mv[u] = reinterpret_cast<const float4*>(mags + ((size_t)row * T + f) * K)[c4];
         }
     };
-    if ((int)blockIdx.x < ntasks) prefetch(blockIdx.x);
+    if ((int)blockIdx.x < ntasks) prefetch(blockIdx.x, 0);
     __syncthreads();
-    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    float4 vsum = make_float4(0.f, 0.f, 0.f, 0.f);            // this lane's four outputs, summed over the vq voices
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x)
+    for (int iv = 0; iv < vq; ++iv) {
         int row, nB0, f_lo, jb_min;
-        window_geometry(task, row, nB0, f_lo, jb_min);
+        window_geometry(task, iv, row, nB0, f_lo, jb_min);
         const int f_hi = min(min(nB0 + FUS_BW - 1 + delay, N - 1) / U, T - 1);
         // ---- 1. registers -> LDS
 #pragma unroll
@@ -572,7 +584,8 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
             }
         }
         __syncthreads();
-        if (task + (int)gridDim.x < ntasks) prefetch(task + gridDim.x);      // in flight during steps 2-4
+        if (iv + 1 < vq) prefetch(task, iv + 1);                              // in flight during steps 2-4
+        else if (task + (int)gridDim.x < ntasks) prefetch(task + gridDim.x, 0);
         // ---- 2. E / O blocks on the matrix cores, 3. tap weights -> zero-padded FIR images (straight from the
         // accumulators: lane holds E, O of frames 4 kq .. 4 kq + 3 at column 16 jt + col)
         if (wib < JT) {
@@ -651,7 +664,9 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                 quad[k] = keep + __shfl_xor(send, 4);
             }
             const int n = np0 + FIR_OPL * a + 4 * sg;
-            if (n < N) *reinterpret_cast<float4*>(out + (size_t)row * N + n) = make_float4(quad[0], quad[1], quad[2], quad[3]);
+            if (iv == 0) vsum = make_float4(quad[0], quad[1], quad[2], quad[3]);
+            else { vsum.x += quad[0]; vsum.y += quad[1]; vsum.z += quad[2]; vsum.w += quad[3]; }
+            if (iv == vq - 1 && n < N) *reinterpret_cast<float4*>(out + (size_t)(task / windows_per_row) * N + n) = vsum;
         }
         __syncthreads();                 // LDS is rewritten by the next window
     }
@@ -888,24 +903,24 @@ int ddspp_frequency_filter_eo_supported(int N, int T, int K, int Lw, int delay_c
     return fused_geometry(N, T, K, Lw, delay_compensation, &g) ? 1 : 0;
 }
 
-// ddsp.core.frequency_filter (frequency_impulse_response + framed fft_convolve) in one kernel; call only for
-// shapes ddspp_frequency_filter_eo_supported accepts.  Tables and scale arguments as ddspp_fir_from_magnitudes_eo.
-int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const float* CE, const float* CO,
-                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R,
-                              int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
-                              float bias, float exponent, float max_value, float threshold, float gain,
-                              hipStream_t stream) {
+static int launch_fused_noise(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R, int N,
+                              int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind, float bias,
+                              float exponent, float max_value, float threshold, float gain, int vq, int n_voices,
+                              int voice_major, hipStream_t stream) {
     DDSPP_REQUIRE(audio && magnitudes && CE && CO && tap_idx && tap_we && tap_wo && out,
                   "frequency_filter_eo: null buffer");
     DDSPP_REQUIRE(R > 0, "frequency_filter_eo: bad dims");
     DDSPP_REQUIRE(scale_kind >= -1 && scale_kind <= 2, "frequency_filter_eo: unknown scale_fn %d", scale_kind);
+    DDSPP_REQUIRE(vq >= 1 && n_voices >= 1 && n_voices % vq == 0 && R % n_voices == 0,
+                  "frequency_filter_eo: %d voices per output row do not divide %d voices / %d rows", vq, n_voices, R);
     FusedGeom g;
     DDSPP_REQUIRE(fused_geometry(N, T, K, Lw, delay_compensation, &g) && NJ == K / 2,
                   "frequency_filter_eo: shape not supported (N=%d T=%d K=%d Lw=%d)", N, T, K, Lw);
     DDSPP_REQUIRE((uintptr_t)audio % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)magnitudes % 16 == 0,
                   "frequency_filter_eo: buffers must be 16-byte aligned");
-    const long long tasks = (long long)R * g.wpr;
-    DDSPP_REQUIRE(tasks < (1ll << 31), "frequency_filter_eo: too many tasks");
+    const long long tasks = (long long)(R / vq) * g.wpr;
+    DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
     const int njp = 16 * ((NJ + 15) / 16);
     const size_t lds = ((size_t)FUS_FRAMES * 256 + 1536 + (size_t)FUS_FRAMES * (K + 4) + 3 * 4 * njp) * sizeof(float);
     long long wgs = (long long)256 * env_int("DDSPP_FUSED_WGS_PER_CU", 32);
@@ -915,13 +930,39 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
 #define DDSPP_FUSED_LAUNCH(KH, JT)                                                                              \
     hipLaunchKernelGGL((noise_fir_fused_kernel<KH, JT>), grid, block, lds, stream, audio, magnitudes, CE, CO,    \
                        tap_idx, tap_we, tap_wo, out, R, N, T, g.U, Lw, NJ, g.delay, g.wpr, g.padl, g.nb,         \
-                       g.seglen, g.dc, bias, sf)
+                       g.seglen, g.dc, bias, sf, vq, n_voices, voice_major)
     if (K == 32) DDSPP_FUSED_LAUNCH(16, 1);
     else if (K == 64) DDSPP_FUSED_LAUNCH(32, 2);
     else DDSPP_FUSED_LAUNCH(48, 3);
 #undef DDSPP_FUSED_LAUNCH
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
+}
+
+// ddsp.core.frequency_filter (frequency_impulse_response + framed fft_convolve) in one kernel; call only for
+// shapes ddspp_frequency_filter_eo_supported accepts.  Tables and scale arguments as ddspp_fir_from_magnitudes_eo.
+int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R,
+                              int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
+                              float bias, float exponent, float max_value, float threshold, float gain,
+                              hipStream_t stream) {
+    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, R, N, T, K, Lw, NJ,
+                              delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain, 1, 1, 0,
+                              stream);
+}
+
+// The same for the rows of a polyphonic group (rows = n_segments x n_voices, segment major or voice major), with the
+// filtered noise of `voices_per_row` consecutive voices summed into one output row: out[R / voices_per_row, N],
+// out[b, q] = sum_i filtered(voice q * voices_per_row + i of segment b).  Feeds ddspp_mix_voices.
+int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                                     const int* tap_idx, const float* tap_we, const float* tap_wo, float* out,
+                                     int R, int N, int T, int K, int Lw, int NJ, int delay_compensation,
+                                     int scale_kind, float bias, float exponent, float max_value, float threshold,
+                                     float gain, int n_voices, int voices_per_row, int voice_major,
+                                     hipStream_t stream) {
+    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, R, N, T, K, Lw, NJ,
+                              delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain,
+                              voices_per_row, n_voices, voice_major, stream);
 }
 
 // U(-1, 1) noise, Philox4x32-10(counter = offset + i / 4, key = seed); n % 4 == 0.

@@ -173,6 +173,16 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
                               int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
                               float bias, float exponent, float max_value, float threshold, float gain,
                               hipStream_t stream);
+/* The same for the R = n_segments * n_voices rows of a polyphonic group (segment major, or voice major as
+ * ddspp_polyphonic_additive), with the filtered noise of `voices_per_row` consecutive voices of a segment summed in
+ * registers into ONE output row: out[R / voices_per_row, N] -- the noise half of the `add` chain of
+ * polyphonic_dag.py:28-37 without a [R, N] round trip; ddspp_mix_voices adds the rows to the additive mix. */
+int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes, const float* CE, const float* CO,
+                                     const int* tap_idx, const float* tap_we, const float* tap_wo, float* out,
+                                     int R, int N, int T, int K, int Lw, int NJ, int delay_compensation,
+                                     int scale_kind, float bias, float exponent, float max_value, float threshold,
+                                     float gain, int n_voices, int voices_per_row, int voice_major,
+                                     hipStream_t stream);
 
 /* stand-in for the reference's unseeded tf.random.uniform([B, N], -1, 1)
  * (filtered_noise_synth.py:39-40): Philox4x32-10, counter = offset + i / 4, key = seed. */
