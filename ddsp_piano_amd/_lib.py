@@ -122,6 +122,9 @@ SIGNATURES = {
     'ddspp_fftconv_fft_size': (c_int, [c_void_p]),
     'ddspp_fftconv_execute': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_fftconv_transform_ir': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_fftconv_execute_prepared': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                               c_size_t, c_void_p]),
     'ddspp_fdn_transfer': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'ddspp_fdn_add_early': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ddspp_irfft_plan_create': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),

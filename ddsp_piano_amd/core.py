@@ -616,10 +616,10 @@ _plan_cache = {}
 _plan_lock = threading.Lock()
 
 
-def _fftconv_plan(b, b_ir, n, l, device):
+def _fftconv_plan(b, b_ir, n, l, device, key_stream=None):
     # a plan carries its stream and work buffer while it executes: one plan per (shape, stream), so that callers that
     # keep several segments in flight on different streams never share one
-    key = (b, b_ir, n, l, str(device), int(_stream().value or 0))
+    key = (b, b_ir, n, l, str(device), int((_stream().value or 0) if key_stream is None else key_stream))
     with _plan_lock:
         plan = _plan_cache.get(key)
         if plan is None:
@@ -659,6 +659,34 @@ def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False,
     _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
                                          int(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
                                          nbytes, _stream()))
+    return out
+
+
+def fft_convolve_prepare(batch, n_samples, ir, mask_dry=False, key_stream=None):
+    """First half of the single-frame fft_convolve: transform the impulse responses [B_ir, L] on the CURRENT stream
+    (which may be a side stream: the IR is known before the audio).  Returns the state fft_convolve_finish needs."""
+    ir = tf_float32(ir).contiguous()
+    b_ir, l = ir.shape
+    plan = _fftconv_plan(int(batch), int(b_ir), int(n_samples), int(l), ir.device, key_stream=key_stream)
+    lib = _lib_()
+    nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ir.device)
+    _lib.check(lib.ddspp_fftconv_transform_ir(plan, _ptr(ir), int(mask_dry), _ptr(ws), nbytes, _stream()))
+    return {'plan': plan, 'ws': ws, 'nbytes': nbytes, 'n': int(n_samples), 'l': int(l), 'batch': int(batch), 'ir': ir}
+
+
+def fft_convolve_finish(state, audio, padding='same', delay_compensation=-1, add_dry=False):
+    """Second half: audio [B, N] against the prepared impulse-response spectra, on the current stream (the caller has
+    made it wait for the stream fft_convolve_prepare ran on)."""
+    audio = tf_float32(audio)
+    b, n = audio.shape
+    if (b, n) != (state['batch'], state['n']):
+        raise ValueError(f'audio {tuple(audio.shape)} does not match the prepared {(state["batch"], state["n"])}')
+    out_len = n if padding == 'same' else state['l'] + n - 1
+    out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
+    _lib.check(_lib_().ddspp_fftconv_execute_prepared(state['plan'], _ptr(audio), n, _ptr(out), out_len,
+                                                      int(delay_compensation), int(add_dry), _ptr(state['ws']),
+                                                      state['nbytes'], _stream()))
     return out
 
 

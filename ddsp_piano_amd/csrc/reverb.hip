@@ -203,10 +203,38 @@ int ddspp_fftconv_fft_size(const ddspp_fftconv_plan* pl) { return pl ? pl->nfft 
 //   delay < 0 -> (L - 1) // 2 - 1 (ddsp.core.crop_and_compensate_delay)
 // audio rows may be strided (audio_stride >= N floats).  Not re-entrant per plan: one execution of a
 // given plan at a time (the rocFFT execution info carries the stream and work buffer).
-int ddspp_fftconv_execute(ddspp_fftconv_plan* pl, const float* audio, int audio_stride, const float* ir,
-                          float* out, int out_len, int delay, int mask_dry, int add_dry, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream) {
-    DDSPP_REQUIRE(pl && audio && ir && out && workspace, "fftconv_execute: null argument");
+// First half of ddspp_fftconv_execute: the (dry-masked) impulse responses -> their spectra, kept in `workspace`.
+// The impulse response is an input of the call, so a caller can enqueue this early, on another stream, while the
+// audio it will convolve is still being synthesised; ddspp_fftconv_execute_prepared then finishes on the same
+// workspace once both are done.
+int ddspp_fftconv_transform_ir(ddspp_fftconv_plan* pl, const float* ir, int mask_dry, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(pl && ir && workspace, "fftconv_transform_ir: null argument");
+    DDSPP_REQUIRE(workspace_bytes >= pl->total_bytes, "fftconv_transform_ir: workspace too small (%zu < %zu)",
+                  workspace_bytes, pl->total_bytes);
+    DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "fftconv_transform_ir: workspace must be 256-byte aligned");
+    char* ws = (char*)workspace;
+    float* ir_p = (float*)(ws + pl->off_ir_p);
+    float2* ir_f = (float2*)(ws + pl->off_ir_f);
+    const int nfft = pl->nfft;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_grid((size_t)pl->B_ir * (nfft / 4))), dim3(256), 0, stream,
+                       ir, ir_p, pl->B_ir, pl->L, pl->L, nfft, mask_dry);
+    DDSPP_LAUNCH_CHECK();
+    DDSPP_FFT_CHECK(rocfft_execution_info_set_stream(pl->info, stream));
+    if (pl->rocfft_work_bytes)
+        DDSPP_FFT_CHECK(rocfft_execution_info_set_work_buffer(pl->info, ws + pl->off_work, pl->rocfft_work_bytes));
+    void* in2[1] = {ir_p};
+    void* out2[1] = {ir_f};
+    DDSPP_FFT_CHECK(rocfft_execute(pl->fwd_ir, in2, out2, pl->info));
+    return DDSPP_OK;
+}
+
+// Second half: audio -> spectrum, product with the impulse-response spectra ddspp_fftconv_transform_ir left in
+// `workspace`, inverse transform, crop (+ dry).  Same arguments as ddspp_fftconv_execute, minus the impulse response.
+int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* pl, const float* audio, int audio_stride, float* out,
+                                   int out_len, int delay, int add_dry, void* workspace, size_t workspace_bytes,
+                                   hipStream_t stream) {
+    DDSPP_REQUIRE(pl && audio && out && workspace, "fftconv_execute: null argument");
     DDSPP_REQUIRE(workspace_bytes >= pl->total_bytes, "fftconv_execute: workspace too small (%zu < %zu)",
                   workspace_bytes, pl->total_bytes);
     DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "fftconv_execute: workspace must be 256-byte aligned");
@@ -218,26 +246,19 @@ int ddspp_fftconv_execute(ddspp_fftconv_plan* pl, const float* audio, int audio_
     DDSPP_REQUIRE(!add_dry || out_len <= pl->N, "fftconv_execute: add_dry needs out_len <= n_samples");
     char* ws = (char*)workspace;
     float* audio_p = (float*)(ws + pl->off_audio_p);
-    float* ir_p = (float*)(ws + pl->off_ir_p);
     float2* audio_f = (float2*)(ws + pl->off_audio_f);
     float2* ir_f = (float2*)(ws + pl->off_ir_f);
     const int nfft = pl->nfft, nbins = nfft / 2 + 1;
 
     hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_grid((size_t)pl->B * (nfft / 4))), dim3(256), 0, stream,
                        audio, audio_p, pl->B, pl->N, audio_stride, nfft, 0);
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_grid((size_t)pl->B_ir * (nfft / 4))), dim3(256), 0, stream,
-                       ir, ir_p, pl->B_ir, pl->L, pl->L, nfft, mask_dry);
     DDSPP_LAUNCH_CHECK();
-
     DDSPP_FFT_CHECK(rocfft_execution_info_set_stream(pl->info, stream));
     if (pl->rocfft_work_bytes)
         DDSPP_FFT_CHECK(rocfft_execution_info_set_work_buffer(pl->info, ws + pl->off_work, pl->rocfft_work_bytes));
     void* in1[1] = {audio_p};
     void* out1[1] = {audio_f};
     DDSPP_FFT_CHECK(rocfft_execute(pl->fwd_audio, in1, out1, pl->info));
-    void* in2[1] = {ir_p};
-    void* out2[1] = {ir_f};
-    DDSPP_FFT_CHECK(rocfft_execute(pl->fwd_ir, in2, out2, pl->info));
     hipLaunchKernelGGL(spectrum_multiply_kernel, dim3(stream_grid((size_t)pl->B * nbins)), dim3(256), 0, stream,
                        audio_f, ir_f, pl->B, pl->B_ir, nbins);
     DDSPP_LAUNCH_CHECK();
@@ -248,6 +269,16 @@ int ddspp_fftconv_execute(ddspp_fftconv_plan* pl, const float* audio, int audio_
                        audio_p, add_dry ? audio : nullptr, out, pl->B, out_len, nfft, start, audio_stride);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
+}
+
+int ddspp_fftconv_execute(ddspp_fftconv_plan* pl, const float* audio, int audio_stride, const float* ir,
+                          float* out, int out_len, int delay, int mask_dry, int add_dry, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(pl && audio && ir && out && workspace, "fftconv_execute: null argument");
+    const int rc = ddspp_fftconv_transform_ir(pl, ir, mask_dry, workspace, workspace_bytes, stream);
+    if (rc != DDSPP_OK) return rc;
+    return ddspp_fftconv_execute_prepared(pl, audio, audio_stride, out, out_len, delay, add_dry, workspace,
+                                          workspace_bytes, stream);
 }
 
 }  // extern "C"

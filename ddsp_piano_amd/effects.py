@@ -50,6 +50,21 @@ class Reverb(Processor):
         return core._fft_convolve_single(audio, ir, 'same', 0, mask_dry=True, add_dry=self._add_dry)
 
 
+    # The impulse response is an input of the group, known before the dry mix exists: the batched group transforms it
+    # early (begin, on its side stream) and convolves when the mix is there (finish).  Same kernels as get_signal.
+    def begin(self, batch, n_samples, ir, key_stream=None):
+        if self.trainable or ir is None:
+            return None
+        ir = core.tf_float32(ir)
+        ir = self._match_dimensions(None, ir).contiguous()
+        if ir.dim() != 2 or (ir.shape[0] != batch and ir.shape[0] != 1):
+            return None
+        return core.fft_convolve_prepare(batch, n_samples, ir, mask_dry=True, key_stream=key_stream)
+
+    def finish(self, state, audio):
+        return core.fft_convolve_finish(state, audio, 'same', 0, add_dry=self._add_dry)
+
+
 FDN_DELAY_VALUES = (233., 311., 421., 461., 587., 613., 789., 891.)                      # fdn_reverb.py:96
 FDN_DELAYS_ALLPASS = ((131., 151., 337., 353.), (103., 173., 331., 373.), (89., 181., 307., 401.),
                       (79., 197., 281., 419.), (61., 211., 257., 431.), (47., 229., 251., 443.),

@@ -196,10 +196,14 @@ def run(plan, inputs, noise=None, need_stems=True):
     side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= int(os.environ.get('DDSPP_SIDE_STREAM_MIN', 1 << 24)) and
                                  os.environ.get('DDSPP_NO_SIDE_STREAM') != '1' and
                                  not torch.cuda.is_current_stream_capturing()) else None
+    rev_state = None
     if side is not None:
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if type(plan.reverb) is Reverb and len(plan.reverb_keys) == 1 and os.environ.get('DDSPP_NO_EARLY_IR') != '1':
+                # the room's impulse response is an input: its spectrum is ready long before the dry mix
+                rev_state = plan.reverb.begin(B, N, inputs[plan.reverb_keys[0]], key_stream=cur.cuda_stream)
             nctl, noise_sig, noise_vq = noise_branch(noise)
     else:
         nctl, noise_sig, noise_vq = noise_branch(noise)
@@ -219,6 +223,14 @@ def run(plan, inputs, noise=None, need_stems=True):
         noise_sig.record_stream(cur)
         if nctl is not None:
             nctl['magnitudes'].record_stream(cur)
+        if rev_state is not None:
+            rev_state['ws'].record_stream(cur)
+
+    def run_reverb(dry):
+        if rev_state is not None:
+            ir = inputs[plan.reverb_keys[0]]
+            return {'signal': plan.reverb.finish(rev_state, dry), 'controls': {'audio': dry, 'ir': ir}}
+        return plan.reverb(dry, *[inputs[k] for k in plan.reverb_keys], return_outputs_dict=True)
 
     def per_voice(x, shape):       # rows -> [B, P, ...] (a transposed view when the rows are voice major)
         return x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape)
@@ -259,7 +271,7 @@ def run(plan, inputs, noise=None, need_stems=True):
         outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
         module_outputs = outputs[plan.add.name]
         if plan.reverb is not None:
-            module_outputs = plan.reverb(dry, *[inputs[k] for k in plan.reverb_keys], return_outputs_dict=True)
+            module_outputs = run_reverb(dry)
             outputs[plan.reverb.name] = module_outputs
         outputs['out'] = module_outputs
         return outputs
@@ -288,8 +300,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     outputs['voices'] = {'additive': additive_sig, 'noise': noise_sig}
 
     if plan.reverb is not None:
-        rev_args = [inputs[k] for k in plan.reverb_keys]
-        module_outputs = plan.reverb(dry, *rev_args, return_outputs_dict=True)
+        module_outputs = run_reverb(dry)
         outputs[plan.reverb.name] = module_outputs
     outputs['out'] = module_outputs
     return outputs

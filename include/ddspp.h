@@ -204,6 +204,15 @@ int ddspp_fftconv_fft_size(const ddspp_fftconv_plan* plan);
 int ddspp_fftconv_execute(ddspp_fftconv_plan* plan, const float* audio, int audio_stride, const float* ir,
                           float* out, int out_len, int delay, int mask_dry, int add_dry, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
+/* The two halves of ddspp_fftconv_execute, for callers that have the impulse response before the audio: transform_ir
+ * (pad, dry mask, R2C of the impulse responses into `workspace`) may be enqueued early, on another stream;
+ * execute_prepared (audio R2C, product, C2R, crop + dry) finishes on the same workspace once both are done. */
+int ddspp_fftconv_transform_ir(ddspp_fftconv_plan* plan, const float* ir, int mask_dry, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream);
+int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* plan, const float* audio, int audio_stride, float* out,
+                                   int out_len, int delay, int add_dry, void* workspace, size_t workspace_bytes,
+                                   hipStream_t stream);
+
 
 /* ---- FDN reverb impulse-response generation ---------------------------------- */
 
