@@ -164,9 +164,11 @@ def run(plan, inputs, noise=None, need_stems=True):
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
     # (batch 64, same box: 2.12 ms per step with per-voice rows, 2.08 / 2.05 / 2.03 / 2.04 with 2 / 4 / 8 / 16)
     voice_sums = int(os.environ.get('DDSPP_VOICE_SUMS', 0)) or next(v for v in (8, 4, 2, 1) if P % v == 0)
-    if not (compact and not want_last and voice_sums > 1 and P % voice_sums == 0 and
+    if not (compact and voice_sums > 1 and P % voice_sums == 0 and
             os.environ.get('DDSPP_NO_VOICE_SUMS') != '1'):
         voice_sums = 1
+
+    last_stem = {}
 
     def noise_branch(noise):
         nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
@@ -183,6 +185,12 @@ def run(plan, inputs, noise=None, need_stems=True):
                                                    noise_p.window_size, noise_p.raw_scale() if fuse_scale else None,
                                                    P, voice_sums, vm)
             if sig is not None:
+                if want_last:          # the last voice's own stem: one more B-row pass over the same noise rows
+                    rows_last = (noise.reshape(P, B, N)[P - 1] if vm else noise.reshape(B, P, N)[:, P - 1]).contiguous()
+                    m_src = mags if fuse_scale else nctl['magnitudes']
+                    m_last = (m_src.reshape(P, B, T, K)[P - 1] if vm else m_src.reshape(B, P, T, K)[:, P - 1]).contiguous()
+                    last_stem['noise'] = core.frequency_filter(rows_last, m_last, window_size=noise_p.window_size,
+                                                               raw_scale=noise_p.raw_scale() if fuse_scale else None)
                 return nctl, sig, voice_sums
         if fuse_scale:
             sig = core.frequency_filter(noise, mags, window_size=noise_p.window_size, raw_scale=noise_p.raw_scale())
@@ -223,6 +231,8 @@ def run(plan, inputs, noise=None, need_stems=True):
         noise_sig.record_stream(cur)
         if nctl is not None:
             nctl['magnitudes'].record_stream(cur)
+        if 'noise' in last_stem:
+            last_stem['noise'].record_stream(cur)
         if rev_state is not None:
             rev_state['ws'].record_stream(cur)
 
@@ -261,7 +271,7 @@ def run(plan, inputs, noise=None, need_stems=True):
             additive_last = core.harmonic_synthesis_fused(lc['f0_hz'], lc['amplitudes'].reshape(B, T),
                                                           lc['harmonic_distribution'], lc['harmonic_shifts'], N,
                                                           additive.sample_rate, additive.inference)
-            noise_last = voice(noise_sig, (N,))
+            noise_last = last_stem['noise'] if noise_vq > 1 else voice(noise_sig, (N,))
             mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}
