@@ -411,11 +411,16 @@ osc_kernel(const OscParams p) {
         const int col = lane & 31, half = lane >> 5;
         // eight 16-byte reads, four running sums (a single chain of 32 dependent adds costs ~5 cycles per add)
         const float4* src = reinterpret_cast<const float4*>(tile + col * TSTRIDE + half * 32);
-        float4 s4 = src[0];
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v tv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const f4v*>(src + i);
+        // all eight reads in flight before the first add (the per-block arrays are dead here, the registers are free)
+        asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+        float4 s4 = make_float4(tv[0].x, tv[0].y, tv[0].z, tv[0].w);
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
-            const float4 v = src[i];
-            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            s4.x += tv[i].x; s4.y += tv[i].y; s4.z += tv[i].z; s4.w += tv[i].w;
         }
         float s = (s4.x + s4.y) + (s4.z + s4.w);
         s += __shfl_xor(s, 32);
