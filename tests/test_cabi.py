@@ -61,3 +61,27 @@ def test_argument_errors_do_not_reach_the_gpu(lib):
         pass
     else:
         raise AssertionError('EINVAL must map to ValueError')
+
+
+def test_argument_errors_of_the_fused_and_split_entry_points(lib):
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(256)
+    # shapes the fused FilteredNoise kernel takes / refuses (host-side geometry, no launch)
+    assert lib.ddspp_frequency_filter_eo_supported(72000, 750, 96, 190, -1) == 1       # 24 kHz, maestro-v2
+    assert lib.ddspp_frequency_filter_eo_supported(48000, 750, 64, 126, -1) == 0       # 16 kHz: 20 frames per window
+    assert lib.ddspp_frequency_filter_eo_supported(72000, 750, 96, 100, -1) == 0       # cropped window
+    assert lib.ddspp_frequency_filter_eo_supported(72001, 750, 96, 190, -1) == 0
+    rc = lib.ddspp_frequency_filter_eo(null, one, one, one, one, one, one, one, 4, 72000, 750, 96, 190, 48, -1, 1,
+                                       -5.0, 10.0, 2.0, 1e-7, 1.0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'null' in lib.ddspp_last_error()
+    rc = lib.ddspp_frequency_filter_eo_voices(one, one, one, one, one, one, one, one, 32, 72000, 750, 96, 190, 48, -1,
+                                              1, -5.0, 10.0, 2.0, 1e-7, 1.0, 16, 3, 0, null)      # 3 does not divide 16
+    assert rc == _lib.DDSPP_EINVAL and b'voices' in lib.ddspp_last_error()
+    rc = lib.ddspp_frequency_filter_eo(one, one, one, one, one, one, one, one, 4, 48000, 750, 64, 126, 32, -1, 1,
+                                       -5.0, 10.0, 2.0, 1e-7, 1.0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'not supported' in lib.ddspp_last_error()
+    assert lib.ddspp_fftconv_transform_ir(null, one, 1, one, 0, null) == _lib.DDSPP_EINVAL
+    assert lib.ddspp_fftconv_execute_prepared(null, one, 10, one, 10, 0, 1, one, 0, null) == _lib.DDSPP_EINVAL
+    rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, one, one, one, 2, 65, 10, 1, 8, 96, 24000.0, 0, 0,
+                                       one, 1 << 30, null)
+    assert rc == _lib.DDSPP_EINVAL and b'exceeds 64' in lib.ddspp_last_error()
