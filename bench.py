@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- DDSP-Piano synthesis hot path on MI355X: audio samples / second, full chain.
 
-One "step" = one pass of the polyphonic ProcessorGroup (get_controls -> inharmonic oscillator bank
--> FilteredNoise -> add chain -> reverb) over one batch of synthetic control envelopes that already
-sit in HBM, plus -- when more than one GPU takes part -- the final RCCL all-gather of the audio.
+One "step" = one pass of the polyphonic ProcessorGroup in the reference's call form
+``processor_group(features, return_outputs_dict=True)`` (ddsp_piano/modules/piano_model.py:160):
+get_controls -> inharmonic oscillator bank -> FilteredNoise -> add chain -> reverb, plus the outputs
+dictionary the reference builds (dry mix, last voice's stems and controls), over one batch of synthetic
+control envelopes that already sit in HBM, plus -- when more than one GPU takes part -- the final RCCL
+all-gather of the audio.
 
 Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments x 3 s, poly=16,
 24 kHz, 250 Hz controls, maestro-v2 dims (H=128 harmonics, K=96 noise bands, S=1), 3 s reverb IR;
 8 GPUs x 64 = the batch=512 of config 4.  The JSON line also carries
-  * roofline     : the operator-boundary cos_oscillator_bank kernel (8 B read per
-                   oscillator-sample + 4 B written per sample) timed with HIP events on materialised
-                   [rows, N, H] envelopes of the same workload, against 8 TB/s;
-  * cpu_baseline : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for
-                   the TF/ddsp reference here) timed on this host on one 3 s, poly=16 segment;
-  * single_stream: the same chain at batch=1 (BASELINE config 2), real-time factor.
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via torch.distributed.run.
+  * roofline       : the operator-boundary cos_oscillator_bank kernel (8 B read per
+                     oscillator-sample + 4 B written per sample) timed with HIP events on materialised
+                     [rows, N, H] envelopes of the same workload, against 8 TB/s;
+  * roofline_step  : the timed step's own dominant call (the compacted oscillator bank, VALU bound): live
+                     HIP-event time against the VALU issue ceiling, instruction counts from profiles/;
+  * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
+                     TF/ddsp reference here) and an op-by-op torch-CPU version on all cores, timed on this host;
+  * step_ms        : per-step HIP-event times (median / min / max) of the headline call;
+  * audio_only_call, dense_worst_case, moving_f0, single_stream, whole_file: other call forms / inputs.
+Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no torchrun environment the script
+starts the N ranks itself (torch.distributed.run, one process per GPU) and fails loudly when the box has fewer
+than N GPUs.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,9 +42,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_BYTES = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMDS = 1024                   # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_WAVE_INST = 2    # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md)
+MAX_CLOCK_HZ = 2.4e9
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -49,28 +62,73 @@ def parse():
     ap.add_argument('--ir-seconds', type=float, default=3.0)
     ap.add_argument('--roofline-rows', type=int, default=0, help='rows (segments x voices) of the '
                     'materialised oscillator-bank measurement; 0 = all rows that fit')
+    ap.add_argument('--call-form', choices=['outputs_dict', 'audio_only'], default='outputs_dict',
+                    help='the call the timed step makes: the reference\'s (piano_model.py:160) or group(features)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-single-stream', action='store_true')
+    ap.add_argument('--no-extras', '--no-single-stream', dest='no_extras', action='store_true',
+                    help='skip the other call forms / workloads reported next to the headline')
     ap.add_argument('--cpu-voices', type=int, default=16)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def make_features(B, P, T, H, K, S, L, device, seed):
+# ----------------------------------------------------------------------------------------------------
+# launching N ranks (the driver uses torch.distributed.run itself; a bare `python bench.py --gpus N` must
+# not silently measure one GPU)
+# ----------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(gpus, env, argv, device_count):
+    """What `python bench.py --gpus N` has to do given the environment.
+
+    Returns None when this process is a rank (or N == 1), the torch.distributed.run command line that
+    starts N ranks of this script otherwise; raises SystemExit when N ranks cannot exist here."""
+    if gpus < 1:
+        raise SystemExit(f'bench.py: --gpus {gpus} is not a GPU count')
+    if 'WORLD_SIZE' in env:
+        world = int(env['WORLD_SIZE'])
+        if world != gpus:
+            raise SystemExit(f'bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; '
+                             'refusing to report a number for a different GPU count')
+        return None
+    if gpus == 1:
+        return None
+    if device_count < gpus:
+        raise SystemExit(f'bench.py: --gpus {gpus} requested but this box has {device_count} GPU(s); '
+                         'not falling back to fewer ranks')
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ----------------------------------------------------------------------------------------------------
+def make_features(B, P, T, H, K, S, L, device, seed, silent_frac=0.25, midi_lo=21, midi_hi=108, vibrato=0.0):
     """Synthetic post-network controls, generated on the GPU; per-voice keys are
-    views of one [B, P, T, C] buffer, which is how a batched control network hands them over."""
+    views of one [B, P, T, C] buffer, which is how a batched control network hands them over.
+
+    vibrato > 0: every voice's f0 (and so every partial's frequency) moves in every frame (a 5 Hz sine of that
+    relative depth plus a slow glide) -- the held-note fast paths of the oscillator bank never apply."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
 
     def randn(*shape):
         return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
 
-    midi = torch.randint(21, 109, (B, P, 1, 1), generator=g, device=device).to(torch.float32)
+    midi = torch.randint(midi_lo, midi_hi + 1, (B, P, 1, 1), generator=g, device=device).to(torch.float32)
     f0 = 440.0 * torch.pow(2.0, (midi - 69.0) / 12.0)
-    silent = torch.rand(B, P, 1, 1, generator=g, device=device) < 0.25
+    silent = torch.rand(B, P, 1, 1, generator=g, device=device) < silent_frac
     f0 = torch.where(silent, torch.zeros_like(f0), f0)
     detune = torch.pow(2.0, 0.3 * torch.arange(S, device=device, dtype=torch.float32) / 1200.0)
     f0 = (f0 * detune.view(1, 1, 1, S)).expand(B, P, T, S).contiguous()
+    if vibrato > 0.0:
+        tt = torch.arange(T, device=device, dtype=torch.float32).view(1, 1, T, 1) / 250.0
+        phi = 6.2831855 * torch.rand(B, P, 1, 1, generator=g, device=device)
+        f0 = (f0 * (1.0 + vibrato * torch.sin(6.2831855 * 5.0 * tt + phi) + 0.1 * vibrato * tt)).contiguous()
     inharm = (torch.exp(-0.105 * midi - 6.87) + torch.exp(0.094 * midi - 13.70)).expand(B, P, T, 1).contiguous()
     decay = torch.exp(-torch.arange(T, device=device, dtype=torch.float32) / (0.4 * T)).view(1, 1, T, 1)
     amps = (randn(B, P, 1, 1) - 1.0) + 3.0 * (decay - 1.0)
@@ -98,6 +156,9 @@ def build_group(dp, P, sr, frame_rate=250):
     return dp.ProcessorGroup(dag)
 
 
+# ----------------------------------------------------------------------------------------------------
+# timing
+# ----------------------------------------------------------------------------------------------------
 def time_steps(fn, steps, warmup, dist=None, drain=None):
     for _ in range(warmup):
         fn()
@@ -115,6 +176,27 @@ def time_steps(fn, steps, warmup, dist=None, drain=None):
     if dist is not None:
         dist.barrier()
     return time.perf_counter() - t0
+
+
+def event_times(fn, reps, warmup=2):
+    """Per-call device times (ms) of fn on torch's current stream (the library launches there), HIP events."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return ts
+
+
+def ms_summary(ts):
+    return {'median': float(np.median(ts)), 'min': float(np.min(ts)), 'max': float(np.max(ts)), 'n': len(ts)}
 
 
 def measure_roofline(dp, base, args, T, U, device):
@@ -144,7 +226,6 @@ def measure_roofline(dp, base, args, T, U, device):
     out = torch.empty((rows, N), dtype=torch.float32, device=device)
     ws, nbytes = core._osc_workspace(rows, N, H, device)
     lib = core._lib_()
-    stream = torch.cuda.current_stream()
 
     def launch():
         rc = lib.ddspp_cos_oscillator_bank(core._ptr(fe), core._ptr(ae), core._ptr(out), rows, N, H,
@@ -152,17 +233,7 @@ def measure_roofline(dp, base, args, T, U, device):
                                            core._stream())
         assert rc == 0, core._lib.last_error()
 
-    launch()
-    torch.cuda.synchronize()
-    reps = 5
-    times = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        launch()
-        e1.record(stream)
-        e1.synchronize()
-        times.append(e0.elapsed_time(e1) * 1e-3)
+    times = [t * 1e-3 for t in event_times(launch, 5, warmup=1)]
     t = float(np.mean(times))
     alg_bytes = rows * (N * H * 8 + N * 4)
     traffic = None
@@ -180,10 +251,49 @@ def measure_roofline(dp, base, args, T, U, device):
             'ms_per_launch': t * 1e3, 'ms_min': float(np.min(times)) * 1e3}
 
 
+def measure_roofline_step(dp, base, args, T, U, device):
+    """The timed step's dominant call, the compacted oscillator bank (ddspp_polyphonic_additive: VALU bound, it
+    moves ~0.7 GB): HIP-event time of the call on the bench inputs against the VALU issue ceiling.  The wave-
+    instruction count of its kernels comes from the committed counter pass (profiles/step_valu.json, written by
+    tools/step_pmc.sh on the same workload); issue fraction = instructions x 2 cycles / (1024 SIMDs x clock x time)."""
+    from ddsp_piano_amd import core
+    B, P = base['f0_hz'].shape[:2]
+    H = base['harmonic_distribution'].shape[-1]
+    S = base['f0_hz'].shape[-1]
+    N = T * U
+    R = B * P
+    additive = dp.MultiInharmonic(sample_rate=args.sample_rate, inference=True)
+    ctl = additive._controls(base['amplitudes'].reshape(R, T, 1), base['harmonic_distribution'].reshape(R, T, H),
+                             base['inharm_coef'].reshape(R, T, 1), base['f0_hz'].reshape(R, T, S), want_counts=True)
+
+    def launch():
+        core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],
+                                 ctl['harmonic_shifts'], B, N, args.sample_rate, voice_major=False,
+                                 audible=ctl['_audible'])
+
+    ts = event_times(launch, 10, warmup=2)
+    t = float(np.median(ts)) * 1e-3
+    out = {'bound': 'valu', 'call': 'ddspp_polyphonic_additive (pre-pass + counts + compacted bank + slot sum)',
+           'ms_per_call': t * 1e3, 'ms_min': float(np.min(ts)), 'unit': 'wave64 VALU instructions/s',
+           'peak': N_SIMDS * MAX_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST,
+           'peak_note': '1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction'}
+    pf = os.path.join(ROOT, 'profiles', 'step_valu.json')
+    if os.path.exists(pf):
+        try:
+            prof = json.load(open(pf))
+            insts = float(prof['valu_wave_instructions_per_call'])
+            out.update({'valu_wave_instructions': insts, 'achieved': insts / t,
+                        'frac': insts / t / out['peak'], 'counters': prof.get('source')})
+        except Exception:  # noqa: BLE001
+            pass
+    return out
+
+
 def measure_cpu_baseline(args, T, U):
     """The oracle (float32-faithful numpy restatement of the TF/ddsp reference -- TF itself cannot be
     installed here) on a bounded sample of the same workload: whole 3 s, poly-16 segments, one
-    thread per voice task, sized for roughly 10-20 s of wall clock on this host."""
+    thread per voice task, sized for roughly 10 s of wall clock on this host; and the op-by-op torch-CPU
+    chain (oracle/torch_cpu_chain.py) with torch's intra-op pool on all cores, the stand-in for TF's."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ddsp_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -222,18 +332,55 @@ def measure_cpu_baseline(args, T, U):
         return time.perf_counter() - t0
 
     t1 = run([make_segment()])                                   # also warms numpy / scipy up
-    n_seg = int(max(1, min(32, round(15.0 / max(t1, 1e-3)))))
+    n_seg = int(max(1, min(32, round(8.0 / max(t1, 1e-3)))))
     segs = [make_segment() for _ in range(n_seg)]
     dt = run(segs)
-    return {'value': n_seg * N / dt, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_seg} segment(s) x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, {sr} Hz, full '
-                      f'chain; numpy oracle, {threads} threads over voice tasks, {dt:.1f} s of wall clock '
-                      f'(host has {os.cpu_count()} logical cores)',
-            'rtf': n_seg * N / dt / sr}
+    numpy_port = {'value': n_seg * N / dt, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
+                  'sample': f'{n_seg} segment(s) x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, {sr} Hz, full '
+                            f'chain; numpy oracle, {threads} threads over voice tasks, {dt:.1f} s of wall clock '
+                            f'(host has {os.cpu_count()} logical cores)',
+                  'rtf': n_seg * N / dt / sr}
+
+    # torch-CPU, all cores: a batch of segments through the vectorised operator sequence
+    from oracle import torch_cpu_chain as TC
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def torch_batch(bt):
+        voices = [{k: torch.as_tensor(v) for k, v in synth_controls(rng, bt, T, H, S=S, K=K).items()} for _ in range(P)]
+        noises = [torch.as_tensor(rng.uniform(-1, 1, [bt, N]).astype(np.float32)) for _ in range(P)]
+        ir = torch.as_tensor(synth_ir(rng, bt, L))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = TC.synthesize(voices, ir, noises, sr)
+        assert tuple(out.shape) == (bt, N)
+        return time.perf_counter() - t0
+
+    t1 = torch_batch(1)
+    bt = int(max(1, min(8, round(8.0 / max(t1, 1e-3)))))       # envelopes are [bt, N, H] x several: keep RAM bounded
+    reps = int(max(1, min(8, round(8.0 / max(t1 * bt, 1e-3)))))
+    dtt = sum(torch_batch(bt) for _ in range(reps))
+    torch_cpu = {'value': reps * bt * N / dtt, 'unit': 'audio samples/s', 'cores': cores, 'kind': 'port',
+                 'sample': f'{reps} batch(es) of {bt} segment(s) x {args.seconds:g} s, poly={P}, H={H}, K={K}, S={S}, '
+                           f'{sr} Hz, full chain; op-by-op torch-CPU chain (materialised envelopes, framed FFT noise, '
+                           f'FFT reverb), intra-op pool = {cores} threads, {dtt:.1f} s of wall clock',
+                 'rtf': reps * bt * N / dtt / sr}
+    best = max((numpy_port, torch_cpu), key=lambda d: d['value'])
+    out = dict(best)
+    out['numpy_oracle'] = numpy_port
+    out['torch_cpu_all_cores'] = torch_cpu
+    out['note'] = 'TensorFlow / ddsp are not installable on this host: both legs are restatements of the reference chain'
+    return out
 
 
 def main():
     args = parse()
+    cmd = launcher_command(args.gpus, os.environ, sys.argv[1:], torch.cuda.device_count())
+    if cmd is not None:
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -250,8 +397,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist_mod.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         dist = dist_mod
-    if args.gpus != world and rank == 0:
-        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+        world = dist.get_world_size()            # the ranks RCCL actually sees
 
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import parallel
@@ -264,6 +410,7 @@ def main():
     L = int(args.ir_seconds * sr)
     feats, base = make_features(B, P, T, H, K, S, L, device, seed=20240 + rank)
     pg = build_group(dp, P, sr)
+    want_dict = args.call_form == 'outputs_dict'
     # the all-gather of step i runs on RCCL's stream while step i + 1 synthesises (two landing buffers)
     gathered = [torch.empty((world * B, N), dtype=torch.float32, device=device) for _ in range(2)] if use_dist else None
     state = {'work': None, 'k': 0}
@@ -273,8 +420,13 @@ def main():
             state['work'].wait()
             state['work'] = None
 
+    def call(group, f):
+        if want_dict:
+            return group(f, return_outputs_dict=True)['signal']        # piano_model.py:160-164
+        return group(f)
+
     def step():
-        audio = pg(feats)
+        audio = call(pg, feats)
         if use_dist:
             drain()
             _, state['work'] = parallel.gather_audio(audio, gathered[state['k'] & 1], async_op=True)
@@ -282,7 +434,7 @@ def main():
         return audio
 
     for _ in range(2):                 # set-up, not a step: rocFFT plans, kernel code objects, allocator pools
-        pg(feats)
+        call(pg, feats)
     torch.cuda.synchronize()
     dt = time_steps(step, args.steps, args.warmup, dist, drain if use_dist else None)
     if use_dist:
@@ -293,30 +445,66 @@ def main():
     value = total_samples / dt
 
     extra = {}
-    if rank == 0 and not args.no_single_stream:
+    if use_dist:
+        # the collective by itself (synchronous), max over ranks: what the overlap has to hide
+        audio = call(pg, feats)
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            parallel.gather_audio(audio, gathered[0])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        tg = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=device)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        extra['allgather'] = {'ms': float(tg.item()) * 1e3, 'bytes_received_per_rank': (world - 1) * B * N * 4,
+                              'note': 'synchronous all_gather_into_tensor alone (median of 5, max over ranks); in the timed '
+                                      'steps it runs on RCCL\'s stream under the next step\'s kernels'}
+    if rank == 0:
+        # per-step device times of the headline call (HIP events on the launch stream; no collective)
+        extra['step_ms'] = ms_summary(event_times(lambda: call(pg, feats), 20, warmup=3))
+    if rank == 0 and not args.no_extras:
+        other = 'audio_only_call' if want_dict else 'outputs_dict_call'
+        fn = (lambda: pg(feats)) if want_dict else (lambda: pg(feats, return_outputs_dict=True))
+        ts = event_times(fn, 20, warmup=3)
+        extra[other] = {'workload': 'the headline batch through ' + ('group(features): audio only' if want_dict else
+                                                                      'group(features, return_outputs_dict=True)'),
+                        'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        # inputs that take none of the data-dependent shortcuts of the oscillator bank: no silent voice, every
+        # partial below Nyquist (low notes), every frequency moving in every frame
+        fd, _ = make_features(B, P, T, H, K, S, L, device, seed=31, silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)
+        pgd = build_group(dp, P, sr)
+        ts = event_times(lambda: call(pgd, fd), 10, warmup=3)
+        extra['dense_worst_case'] = {'workload': f'batch={B}, every voice sounding, notes A0..A1 (all {H} partials below '
+                                                 'Nyquist), f0 moving in every frame (0.4 % vibrato + glide)',
+                                     'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        del fd, pgd
+        fm, _ = make_features(B, P, T, H, K, S, L, device, seed=32, vibrato=0.002)
+        pgm = build_group(dp, P, sr)
+        ts = event_times(lambda: call(pgm, fm), 10, warmup=3)
+        extra['moving_f0'] = {'workload': f'the headline note mix (A0..C8, 25 % silent voices) with every f0 moving in '
+                                          'every frame (0.2 % vibrato + glide)',
+                              'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        del fm, pgm
         f1, _ = make_features(1, P, T, H, K, S, L, device, seed=7)
         pg1 = build_group(dp, P, sr)
-        d1 = min(time_steps(lambda: pg1(f1), 20, 3) for _ in range(3))          # best of three runs of 20
+        d1 = min(time_steps(lambda: call(pg1, f1), 20, 3) for _ in range(3))          # best of three runs of 20
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
-    if rank == 0 and not args.no_single_stream:
-        # PianoModel.call's form (piano_model.py:160): the outputs dict, i.e. the mix plus the last voice's stems
-        dd = min(time_steps(lambda: pg(feats, return_outputs_dict=True), 10, 2) for _ in range(2))
-        extra['outputs_dict_call'] = {'workload': 'the headline batch through group(features, return_outputs_dict=True)',
-                                      'ms_per_step': dd / 10 * 1e3, 'rtf': (B * N * 10 / dd) / sr}
-    if rank == 0 and not args.no_single_stream:
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
         pgw = build_group(dp, P, sr)
-        dw = min(time_steps(lambda: pgw(fw), 5, 2) for _ in range(3))
+        dw = min(time_steps(lambda: call(pgw, fw), 5, 2) for _ in range(3))
         extra['whole_file'] = {'workload': f'B=1 x {Tw / 250:g} s in one segment, poly={P}, 2 s IR',
                                'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
-        del fw, pgw
-    roof = None
+        del fw, pgw, f1, pg1
+    roof = roof_step = None
     if rank == 0 and not args.no_roofline:
         del feats
         torch.cuda.empty_cache()
+        roof_step = measure_roofline_step(dp, base, args, T, U, device)
         roof = measure_roofline(dp, base, args, T, U, device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -337,9 +525,11 @@ def main():
                                    f'poly={P}, {sr} Hz, 250 Hz controls, H={H}, K={K}, S={S}, '
                                    f'{args.ir_seconds:g} s reverb IR (L={L}); global batch {world * B}'
                                    + (' = config 4' if world * B == 512 else ''),
+                       'call_form': 'processor_group(features, return_outputs_dict=True) (piano_model.py:160)'
+                                    if want_dict else 'processor_group(features)',
                        'global_batch': world * B, 'segment_samples': N, 'parallelism': f'batch-shard x{world}'
                                                                                        + (' + RCCL all-gather overlapped with the next step' if world > 1 else '')},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_step': roof_step, 'cpu_baseline': cpu,
         }
         line.update(extra)
     if dist is not None:

@@ -29,6 +29,42 @@ _TWO_PI_F32 = F32(2.0 * np.pi)
 
 
 # ----------------------------------------------------------------------------------------------------
+# Details of the un-vendored ddsp 3.7.0 that are restated from memory (SURVEY.md 8(c) "VERIFY" list; ddsp is not
+# installable next to this package).  Where the LIBRARY decides, the rule is a switch here, mirrored one to one by
+# oracle.ddsp_oracle.RECALLED; the defaults are what this package believes ddsp 3.7.0 does.
+#   auto_delay   crop_and_compensate_delay with delay_compensation < 0: 'ddsp370' (ir_size - 1) // 2 - 1 | 'half'
+#                ir_size // 2.  C-ABI: delay_compensation = DDSPP_DELAY_AUTO (-1) / DDSPP_DELAY_AUTO_HALF (-2).
+#   resize       core.resample(method='linear'): 'legacy' (TF1 bilinear, pos = n * T/N) | 'half_pixel'.
+#                Host tables; the fused oscillator path needs 'legacy' (else the three-operator route runs).
+#   window_crop  apply_window_to_impulse_response, window_size < ir_size: 'ddsp370' | 'centred'.  Host matrix.
+# The other three recalled items are ordinary arguments here (exp_sigmoid's exponent / max_value / threshold,
+# FilteredNoise(initial_bias=)) or oracle-only (the inclusive scan of angular_cumsum is what the kernels implement).
+# ----------------------------------------------------------------------------------------------------
+RECALLED = {'auto_delay': 'ddsp370', 'resize': 'legacy', 'window_crop': 'ddsp370'}
+_RECALLED_CHOICES = {'auto_delay': ('ddsp370', 'half'), 'resize': ('legacy', 'half_pixel'),
+                     'window_crop': ('ddsp370', 'centred')}
+
+
+def set_recalled(**rules):
+    """Select another recollection of a ddsp detail (see RECALLED); returns the previous settings."""
+    for k, v in rules.items():
+        if k not in _RECALLED_CHOICES:
+            raise KeyError(f'unknown recalled detail {k!r}; known: {sorted(_RECALLED_CHOICES)}')
+        if v not in _RECALLED_CHOICES[k]:
+            raise ValueError(f'{k} must be one of {_RECALLED_CHOICES[k]}, got {v!r}')
+    previous = dict(RECALLED)
+    RECALLED.update(rules)
+    return previous
+
+
+def _auto_delay(delay_compensation):
+    """The C-ABI code of a delay_compensation argument: >= 0 as given, < 0 -> the selected automatic rule."""
+    if delay_compensation >= 0:
+        return int(delay_compensation)
+    return -2 if RECALLED['auto_delay'] == 'half' else -1
+
+
+# ----------------------------------------------------------------------------------------------------
 # buffer plumbing
 # ----------------------------------------------------------------------------------------------------
 def default_device():
@@ -169,13 +205,17 @@ def _hann_window_np(n, periodic=True):
 
 
 @functools.lru_cache(maxsize=64)
-def _linear_tables_np(n_frames, n_timesteps):
-    """Legacy bilinear (align_corners=False, no half-pixel centres) source rows and weights."""
+def _linear_tables_np(n_frames, n_timesteps, rule='legacy'):
+    """Bilinear source rows and weights of tf.compat.v1.image.resize(align_corners=False): the TF1 kernel has no
+    half-pixel centres ('legacy', pos = n * T/N); 'half_pixel' is the TF2 scaler, (n + 0.5) * T/N - 0.5."""
     scale = F32(n_frames) / F32(n_timesteps)
-    pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
+    if rule == 'half_pixel':
+        pos = (((np.arange(n_timesteps, dtype=F32) + F32(0.5)).astype(F32) * scale).astype(F32) - F32(0.5)).astype(F32)
+    else:
+        pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
     fl = np.floor(pos)
-    lo = fl.astype(np.int32)
-    hi = np.minimum(np.ceil(pos).astype(np.int32), n_frames - 1).astype(np.int32)
+    lo = np.maximum(fl.astype(np.int32), 0).astype(np.int32)
+    hi = np.minimum(np.maximum(np.ceil(pos).astype(np.int32), 0), n_frames - 1).astype(np.int32)
     w = (pos - fl).astype(F32)
     aligned = False
     if n_timesteps % n_frames == 0:
@@ -199,11 +239,13 @@ def _cached(key, builder):
 
 
 def linear_tables(n_frames, n_timesteps, device):
+    rule = RECALLED['resize']
+
     def build():
-        lo, hi, w, aligned = _linear_tables_np(int(n_frames), int(n_timesteps))
+        lo, hi, w, aligned = _linear_tables_np(int(n_frames), int(n_timesteps), rule)
         return (torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device),
                 torch.from_numpy(w).to(device), aligned)
-    return _cached(('lin', int(n_frames), int(n_timesteps), str(device)), build)
+    return _cached(('lin', int(n_frames), int(n_timesteps), str(device), rule), build)
 
 
 def hann_window(n, device):
@@ -211,23 +253,27 @@ def hann_window(n, device):
                    lambda: torch.from_numpy(_hann_window_np(int(n))).to(device))
 
 
-def _apply_window_rows(ir, window_size):
+def _apply_window_rows(ir, window_size, crop_rule='ddsp370'):
     """ddsp.core.apply_window_to_impulse_response(causal=False) applied along the last axis.
 
     ``ir`` is float64 [..., ir_size] (zero phase); the float32 Hann window is the one TF builds.
+    crop_rule: RECALLED['window_crop'] (only matters when window_size < ir_size).
     """
     ir_size = int(ir.shape[-1])
     if window_size <= 0 or window_size > ir_size:
         window_size = ir_size
     window = _hann_window_np(window_size).astype(np.float64)
     padding = ir_size - window_size
+    centred = crop_rule == 'centred'
     if padding > 0:
-        half_idx = (window_size + 1) // 2
+        half_idx = window_size // 2 if centred else (window_size + 1) // 2
         window = np.concatenate([window[half_idx:], np.zeros([padding]), window[:half_idx]], axis=0)
     else:
         window = np.fft.fftshift(window)
     ir = window * ir
-    if padding > 0:
+    if padding > 0 and centred:
+        ir = np.concatenate([ir[..., ir_size - half_idx:], ir[..., :window_size - half_idx]], axis=-1)
+    elif padding > 0:
         first_half_start = (ir_size - (half_idx - 1)) + 1
         second_half_end = half_idx + 1
         ir = np.concatenate([ir[..., first_half_start:], ir[..., :second_half_end]], axis=-1)
@@ -237,7 +283,7 @@ def _apply_window_rows(ir, window_size):
 
 
 @functools.lru_cache(maxsize=16)
-def _fir_matrix_np(n_bands, window_size):
+def _fir_matrix_np(n_bands, window_size, crop_rule='ddsp370'):
     """M[K, Lw] with frequency_impulse_response(mag) == mag @ M (real inverse DFT x window, shifted)."""
     if n_bands < 2:
         raise ValueError('frequency_impulse_response needs at least 2 frequency bands')
@@ -248,16 +294,16 @@ def _fir_matrix_np(n_bands, window_size):
     coef[0, 0] = 1.0
     coef[-1, 0] = 1.0
     basis = coef * np.cos(2.0 * np.pi * k * j / ir_size) / ir_size       # irfft of unit magnitudes
-    return np.ascontiguousarray(_apply_window_rows(basis, int(window_size)).astype(F32))
+    return np.ascontiguousarray(_apply_window_rows(basis, int(window_size), crop_rule).astype(F32))
 
 
 @functools.lru_cache(maxsize=16)
-def _fir_symmetry_np(n_bands, window_size):
+def _fir_symmetry_np(n_bands, window_size, crop_rule='ddsp370'):
     """(uniq, mirror): taps to evaluate and the tap each one is mirrored onto (-1 = none).
 
     The windowed zero-phase response is even, so the causal FIR satisfies ir[c + m] == ir[c - m]
     about its centre tap c; the pairing is verified numerically on the basis matrix itself."""
-    m = _fir_matrix_np(n_bands, window_size).astype(np.float64)
+    m = _fir_matrix_np(n_bands, window_size, crop_rule).astype(np.float64)
     lw = m.shape[1]
     tol = 1e-6 * float(np.abs(m).max())
     for c in (lw // 2, (lw - 1) // 2):
@@ -333,11 +379,13 @@ def fir_eo_tables(n_bands, window_size, device):
 
 
 def fir_matrix(n_bands, window_size, device):
+    rule = RECALLED['window_crop']
+
     def build():
-        uniq, mirror = _fir_symmetry_np(int(n_bands), int(window_size))
-        return (torch.from_numpy(_fir_matrix_np(int(n_bands), int(window_size))).to(device),
+        uniq, mirror = _fir_symmetry_np(int(n_bands), int(window_size), rule)
+        return (torch.from_numpy(_fir_matrix_np(int(n_bands), int(window_size), rule)).to(device),
                 torch.from_numpy(uniq).to(device), torch.from_numpy(mirror).to(device))
-    return _cached(('firM', int(n_bands), int(window_size), str(device)), build)
+    return _cached(('firM', int(n_bands), int(window_size), str(device), rule), build)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -433,7 +481,7 @@ def fused_synthesis_supported(n_frames, n_samples):
     u = n_samples // n_frames
     if u % 8 != 0 or n_frames + 1 >= n_samples:
         return False
-    return _linear_tables_np(int(n_frames), int(n_samples))[3]
+    return _linear_tables_np(int(n_frames), int(n_samples), RECALLED['resize'])[3]
 
 
 def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_samples,
@@ -657,7 +705,7 @@ def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False,
     ws = torch.empty(nbytes, dtype=torch.uint8, device=audio.device)
     out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
     _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
-                                         int(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
+                                         _auto_delay(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
                                          nbytes, _stream()))
     return out
 
@@ -685,7 +733,7 @@ def fft_convolve_finish(state, audio, padding='same', delay_compensation=-1, add
     out_len = n if padding == 'same' else state['l'] + n - 1
     out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
     _lib.check(_lib_().ddspp_fftconv_execute_prepared(state['plan'], _ptr(audio), n, _ptr(out), out_len,
-                                                      int(delay_compensation), int(add_dry), _ptr(state['ws']),
+                                                      _auto_delay(delay_compensation), int(add_dry), _ptr(state['ws']),
                                                       state['nbytes'], _stream()))
     return out
 
@@ -730,7 +778,7 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
     x = x.contiguous()
     out = torch.empty((batch_size, padded), dtype=torch.float32, device=audio.device)
     _lib.check(_lib_().ddspp_time_varying_fir(_ptr(x), _ptr(ir), _ptr(out), batch_size, padded, n_ir_frames,
-                                              ir_size, int(delay_compensation), _stream()))
+                                              ir_size, _auto_delay(delay_compensation), _stream()))
     return out if padded == audio_size else out[:, :audio_size].contiguous()
 
 
@@ -767,7 +815,8 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, 
         return None
     ce, co, idx, we, wo, nj, lw = eo
     lib = _lib_()
-    if not lib.ddspp_frequency_filter_eo_supported(n, t, k, lw, -1):
+    dcode = _auto_delay(-1)
+    if not lib.ddspp_frequency_filter_eo_supported(n, t, k, lw, dcode):
         return None
     x, mags = x.contiguous(), mags.contiguous()
     if x.data_ptr() % 16 or mags.data_ptr() % 16:
@@ -779,7 +828,7 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, 
     if voices is None:
         out = torch.empty((b, n), dtype=torch.float32, device=x.device)
         _lib.check(lib.ddspp_frequency_filter_eo(_ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo),
-                                                 _ptr(out), b, n, t, k, lw, nj, -1, int(code), float(bias),
+                                                 _ptr(out), b, n, t, k, lw, nj, dcode, int(code), float(bias),
                                                  prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
                                                  _stream()))
         return out
@@ -788,7 +837,7 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, 
         return None
     out = torch.empty((b // vq, n), dtype=torch.float32, device=x.device)
     _lib.check(lib.ddspp_frequency_filter_eo_voices(
-        _ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), b, n, t, k, lw, nj, -1,
+        _ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), b, n, t, k, lw, nj, dcode,
         int(code), float(bias), prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'], n_voices, vq,
         int(vmajor), _stream()))
     return out

@@ -16,6 +16,16 @@
 #define DDSPP_EFFT (-6)
 
 #define DDSPP_CHUNK 1000          // ddsp.core.angular_cumsum(chunk_size=1000)
+
+// ddsp.core.crop_and_compensate_delay: `start` when delay_compensation < 0.  ddsp 3.7.0 is not on disk, the rule is
+// RECALLED: -1 selects `(ir_size - 1) // 2 - 1` (the default; it puts the zero-time tap of the
+// cropped 257-tap window, tap 127, at delay 0), -2 selects the alternative recollection `ir_size // 2`.
+#define DDSPP_DELAY_AUTO (-1)
+#define DDSPP_DELAY_AUTO_HALF (-2)
+static inline int ddspp_auto_delay(int delay_compensation, int ir_size) {
+    if (delay_compensation >= 0) return delay_compensation;
+    return delay_compensation == DDSPP_DELAY_AUTO_HALF ? ir_size / 2 : (ir_size - 1) / 2 - 1;
+}
 #define DDSPP_WAVE 64
 
 extern "C" void ddspp_set_error(const char* fmt, ...);

@@ -786,7 +786,7 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     DDSPP_REQUIRE(R > 0 && N > 0 && T > 0 && Lw > 0, "time_varying_fir: bad dims");
     DDSPP_REQUIRE(N % T == 0, "time_varying_fir: n_samples=%d must be a multiple of n_frames=%d", N, T);
     const int U = N / T;
-    const int delay = delay_compensation < 0 ? (Lw - 1) / 2 - 1 : delay_compensation;
+    const int delay = ddspp_auto_delay(delay_compensation, Lw);
     DDSPP_REQUIRE(delay >= 0, "time_varying_fir: negative delay");
     // Tiled kernel geometry (see tv_fir_kernel).  Tap t of a frame sits at float padl + t of its staged image;
     // padl makes (delay - 3 + padl) a multiple of 4 (aligned 16-byte tap blocks) and puts enough zero blocks in
@@ -881,7 +881,7 @@ struct FusedGeom {
 static bool fused_geometry(int N, int T, int K, int Lw, int delay_compensation, FusedGeom* g) {
     if (N <= 0 || T <= 0 || N % T != 0 || (K != 32 && K != 64 && K != 96) || Lw != 2 * (K - 1)) return false;
     const int U = N / T;
-    const int delay = delay_compensation < 0 ? (Lw - 1) / 2 - 1 : delay_compensation;
+    const int delay = ddspp_auto_delay(delay_compensation, Lw);
     if (delay < 0 || U % 4 != 0 || N % 4 != 0) return false;
     int padl = 18 - (delay + 3) % 4;
     while ((delay - 3 + padl) % 4 != 0) ++padl;

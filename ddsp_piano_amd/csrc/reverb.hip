@@ -200,7 +200,7 @@ int ddspp_fftconv_fft_size(const ddspp_fftconv_plan* pl) { return pl ? pl->nfft 
 
 // out[b, n] = (audio[b] * ir'[b])[n + delay] (+ audio[b, n]),  n < out_len
 //   ir' = ir with ir'[:, 0] = 0 when mask_dry (ddsp.effects.Reverb._mask_dry_ir)
-//   delay < 0 -> (L - 1) // 2 - 1 (ddsp.core.crop_and_compensate_delay)
+//   delay = -1 -> (L - 1) // 2 - 1, -2 -> L // 2 (ddsp.core.crop_and_compensate_delay, see ddspp_auto_delay)
 // audio rows may be strided (audio_stride >= N floats).  Not re-entrant per plan: one execution of a
 // given plan at a time (the rocFFT execution info carries the stream and work buffer).
 // First half of ddspp_fftconv_execute: the (dry-masked) impulse responses -> their spectra, kept in `workspace`.
@@ -239,7 +239,7 @@ int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* pl, const float* audio, i
                   workspace_bytes, pl->total_bytes);
     DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "fftconv_execute: workspace must be 256-byte aligned");
     DDSPP_REQUIRE(audio_stride >= pl->N, "fftconv_execute: audio_stride < n_samples");
-    const int start = delay < 0 ? (pl->L - 1) / 2 - 1 : delay;
+    const int start = ddspp_auto_delay(delay, pl->L);
     DDSPP_REQUIRE(start >= 0 && out_len > 0 && (long long)start + out_len <= pl->nfft,
                   "fftconv_execute: crop [%d, %d) outside the fft frame of %d", start, start + out_len,
                   pl->nfft);

@@ -4,9 +4,11 @@ The reference walks 3*P + 1 DAG nodes one eager processor call at a time
 (ddsp_piano/modules/polyphonic_dag.py:24-40).  When the DAG handed to ProcessorGroup has exactly that
 shape, the voices become a batch dimension: rows = B*P go through ONE get_controls kernel, ONE
 fused oscillator-bank launch, ONE FIR-design + ONE time-varying-FIR launch, one mixer pass and one
-rocFFT reverb.  Results are those of the node-by-node walk (same kernels, same per-row arithmetic;
-the voice sum keeps the DAG's ((add + noise_i) + additive_i) order); tests/test_gpu_group.py checks the
-two routes against each other.
+rocFFT reverb.  Per-row arithmetic is that of the node-by-node walk (same kernels).  The voice sum: with every
+voice's stems (need_stems=True) the mixer keeps the DAG's ((add + noise_i) + additive_i) order; the compacted
+routes (audio only / outputs dict) add the voices in another order -- the oscillators of a segment are summed
+across voices inside the bank -- so their mix differs from the walk's by float32 round-off of the additions
+(~1e-7 relative; tests/test_gpu_group.py checks the routes against each other and against the oracle).
 """
 from __future__ import annotations
 
@@ -118,9 +120,32 @@ def _stack_voices(tensors, voice_major=None):
     return torch.stack(xs, dim=0 if vm else 1).reshape(b * p, t, c), vm
 
 
+def noise_rows(noise, B, P, N, voice_major):
+    """The caller's explicit noise -- [B, P, N], or a sequence of P tensors [B, N] (voice i = the i-th call of the
+    noise processor in the DAG) -- as the [R, N] rows the batched kernels take, in the row order of the controls."""
+    if isinstance(noise, (list, tuple)):
+        if len(noise) != P:
+            raise ValueError(f'noise: expected {P} per-voice tensors, got {len(noise)}')
+        rows = torch.stack([core.tf_float32(z) for z in noise], dim=0 if voice_major else 1)
+    else:
+        rows = core.tf_float32(noise)
+        if rows.dim() == 2 and P == 1:
+            rows = rows[:, None, :]
+        if tuple(rows.shape) != (B, P, N):
+            raise ValueError(f'noise must be [batch, n_synths, n_samples] = {(B, P, N)}, got {tuple(rows.shape)}')
+        if voice_major:
+            rows = rows.transpose(0, 1)
+    if tuple(rows.shape) != ((P, B, N) if voice_major else (B, P, N)):
+        raise ValueError(f'noise: every per-voice tensor must be {(B, N)}')
+    return rows.contiguous().reshape(B * P, N)
+
+
 def run(plan, inputs, noise=None, need_stems=True):
     """Execute the polyphonic DAG with voices batched.  Returns the ddsp-style outputs dict, or None
     when the inputs do not fit the batched kernels (caller then walks the DAG node by node).
+
+    noise: the uniform(-1, 1) draws of the noise processor given explicitly ([B, P, N] or P tensors [B, N]; the
+    reference draws them unseeded, filtered_noise_synth.py:39-40); None = the processor's own Philox draw.
 
     need_stems=False (a plain ``group(features)`` call that only wants the audio): the additive branch runs through
     the compacted kernel, which forms the per-segment mix directly -- the `additive` / `noise` / `voices` entries
@@ -173,12 +198,9 @@ def run(plan, inputs, noise=None, need_stems=True):
     def noise_branch(noise):
         nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
         if noise is None:
-            override = getattr(noise_p, 'noise_override', None)
-            if override:
-                noise = torch.stack([core.tf_float32(override.pop(0)) for _ in range(P)], dim=0 if vm else 1)
-        if noise is None:
             noise = noise_p.draw_noise(R, N, dev)
-        noise = core.tf_float32(noise).reshape(R, N)
+        else:
+            noise = noise_rows(noise, B, P, N, vm)
         if voice_sums > 1:
             # audio only: the filtered noise of four voices leaves the kernel as one row (a quarter of the round trip)
             sig = core.frequency_filter_voice_sums(noise, mags if fuse_scale else nctl['magnitudes'],

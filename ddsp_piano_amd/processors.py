@@ -104,27 +104,40 @@ class ProcessorGroup:
             return dict(signal=signal, controls=outputs)
         return signal
 
-    def get_controls(self, inputs, **kwargs):
-        """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag).  kwargs (noise=,
-        need_stems=) only concern the batched polyphonic route."""
+    def get_controls(self, inputs, noise=None, need_stems=True):
+        """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag).
+
+        noise: explicit uniform(-1, 1) draws for the noise synthesiser instead of its own generator -- [B, P, N] or a
+        sequence of P tensors [B, N], voice i = the i-th FilteredNoise node of the DAG (the reference draws them
+        unseeded, filtered_noise_synth.py:39-40; parity tests and reproducible renders pass them in).
+        need_stems only concerns the batched polyphonic route (polyphonic.run)."""
         if self.fast_path:
             from . import polyphonic
             if self._plan is None:
                 self._plan = polyphonic.recognise(self.dag) or False
             if self._plan:
-                outputs = polyphonic.run(self._plan, inputs, **kwargs)
+                outputs = polyphonic.run(self._plan, inputs, noise=noise, need_stems=need_stems)
                 if outputs is not None:
                     return outputs
-        return self._run_dag(inputs)
+        return self._run_dag(inputs, noise=noise)
 
-    def _run_dag(self, inputs):
+    def _run_dag(self, inputs, noise=None):
+        from .synths import FilteredNoise
         outputs = {'inputs': inputs}
         outputs.update(inputs)
         module_outputs = None
+        noise_calls = 0
         for node in self.dag:
             processor, input_keys = node[0], node[1]
             args = [_nested_lookup(k, outputs) for k in input_keys]
-            module_outputs = processor(*args, return_outputs_dict=True)
+            if noise is not None and isinstance(processor, FilteredNoise):
+                z = noise[noise_calls] if isinstance(noise, (list, tuple)) else \
+                    (noise[:, noise_calls] if noise.dim() == 3 else noise)
+                noise_calls += 1
+                controls = processor.get_controls(*[core.tf_float32(a) for a in args])
+                module_outputs = dict(signal=processor.get_signal(**controls, noise=z), controls=controls)
+            else:
+                module_outputs = processor(*args, return_outputs_dict=True)
             outputs[processor.name] = module_outputs
         outputs['out'] = module_outputs
         return outputs

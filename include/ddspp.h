@@ -157,7 +157,10 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
 
 /* ddsp.core.fft_convolve(audio[R,N], impulse_response[R,T,Lw], padding='same', delay_compensation)
  * in the framed case (frame = hop = N / T); reached from filtered_noise_synth.py:41-42 through
- * ddsp.core.frequency_filter.  delay_compensation < 0 -> (Lw - 1) // 2 - 1. */
+ * ddsp.core.frequency_filter.  delay_compensation >= 0: that many leading samples are cropped;
+ * DDSPP_DELAY_AUTO (-1): crop_and_compensate_delay's automatic start as recalled from ddsp 3.7.0,
+ * (Lw - 1) // 2 - 1; DDSPP_DELAY_AUTO_HALF (-2): the alternative recollection Lw // 2 (DESIGN.md section 2 --
+ * ddsp is not on disk, so the rule is a documented switch; every entry point that takes a delay accepts both). */
 int ddspp_time_varying_fir(const float* audio, const float* impulse_response, float* out, int R, int N,
                            int T, int Lw, int delay_compensation, hipStream_t stream);
 
@@ -194,6 +197,8 @@ typedef struct FftConvPlan ddspp_fftconv_plan;
 
 /* ddsp.core.get_fft_size(N, L, power_of_2=True) */
 int ddspp_fft_size(int N, int L);
+#define DDSPP_DELAY_AUTO (-1)
+#define DDSPP_DELAY_AUTO_HALF (-2)
 
 /* ddsp.core.fft_convolve, single IR frame (ddsp.effects.Reverb.get_signal; fdn_reverb.py:407-410).
  * B_ir is B or 1 (a batch-1 IR is shared by all rows). */

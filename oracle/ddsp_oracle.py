@@ -36,6 +36,64 @@ import scipy.fft as sfft
 F32 = np.float32
 TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2.0 * pi`
 
+# ----------------------------------------------------------------------------------------------
+# The six details of ddsp 3.7.0 that are RECALLED, not read (SURVEY.md 8(c) "VERIFY" list).  Each is ONE
+# switchable entry here; every function below reads it at call time.  The defaults are the builder's
+# recollection of ddsp 3.7.0; the alternatives are what a different recollection would give.  A host with
+# TensorFlow + ddsp settles them: tests/golden/make_golden.py (DDSP_GOLDEN_BACKEND=tf) regenerates the
+# golden vectors from the real library and tests/test_golden_backend.py reports which setting they match.
+#   auto_delay      crop_and_compensate_delay, delay_compensation < 0:
+#                     'ddsp370'  start = (ir_size - 1) // 2 - 1        'half'  start = ir_size // 2
+#   window_crop     apply_window_to_impulse_response when window_size < ir_size:
+#                     'ddsp370'  half_idx = (W + 1) // 2, crop [ir_size - half_idx + 2:] ++ [:half_idx + 1]
+#                     'centred'  half_idx = W // 2,       crop [ir_size - half_idx:]     ++ [:W - half_idx]
+#   resize          core.resample(method='linear') -> tf.compat.v1.image.resize(BILINEAR, align_corners=False):
+#                     'legacy'      pos = float32(n) * float32(T / N)                (TF1 kernel, no half-pixel centres)
+#                     'half_pixel'  pos = (float32(n) + 0.5) * float32(T / N) - 0.5  (TF2 tf.image.resize)
+#   angular_cumsum  core.angular_cumsum:
+#                     'ddsp370'    inclusive cumsum in the chunk, chunk offsets shifted right by one chunk
+#                     'exclusive'  exclusive cumsum in the chunk (first sample has phase 0)
+#   exp_sigmoid     defaults (exponent, max_value, threshold) of core.exp_sigmoid
+#   initial_bias    default of synths.FilteredNoise(initial_bias=)
+# ----------------------------------------------------------------------------------------------
+RECALLED_DEFAULTS = {
+    'auto_delay': 'ddsp370',
+    'window_crop': 'ddsp370',
+    'resize': 'legacy',
+    'angular_cumsum': 'ddsp370',
+    'exp_sigmoid': (10.0, 2.0, 1e-7),
+    'initial_bias': -5.0,
+}
+RECALLED_CHOICES = {
+    'auto_delay': ('ddsp370', 'half'),
+    'window_crop': ('ddsp370', 'centred'),
+    'resize': ('legacy', 'half_pixel'),
+    'angular_cumsum': ('ddsp370', 'exclusive'),
+}
+RECALLED = dict(RECALLED_DEFAULTS)
+
+
+class recalled:
+    """``with recalled(auto_delay='half'): ...`` -- evaluate the oracle under another recollection."""
+
+    def __init__(self, **overrides):
+        for k, v in overrides.items():
+            if k not in RECALLED_DEFAULTS:
+                raise KeyError(f'unknown recalled detail {k!r}')
+            if k in RECALLED_CHOICES and v not in RECALLED_CHOICES[k]:
+                raise ValueError(f'{k} must be one of {RECALLED_CHOICES[k]}, got {v!r}')
+        self.overrides = overrides
+
+    def __enter__(self):
+        self.saved = dict(RECALLED)
+        RECALLED.update(self.overrides)
+        return RECALLED
+
+    def __exit__(self, *exc):
+        RECALLED.clear()
+        RECALLED.update(self.saved)
+        return False
+
 
 def tf_float32(x):
     """ddsp.core.tf_float32: cast/convert to float32."""
@@ -58,11 +116,16 @@ def _sigmoid_f32(x):
     return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
 
 
-def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
+def exp_sigmoid(x, exponent=None, max_value=None, threshold=None):
     """ddsp.core.exp_sigmoid: ``max_value * sigmoid(x) ** log(exponent) + threshold``.
 
-    Default scale_fn of InHarmonic (inharm_synth.py:149) and FilteredNoise.
+    Default scale_fn of InHarmonic (inharm_synth.py:149) and FilteredNoise.  The default constants
+    (10.0, 2.0, 1e-7) are RECALLED['exp_sigmoid'].
     """
+    d = RECALLED['exp_sigmoid']
+    exponent = d[0] if exponent is None else exponent
+    max_value = d[1] if max_value is None else max_value
+    threshold = d[2] if threshold is None else threshold
     x = tf_float32(x)
     p = F32(np.log(F32(exponent)))
     return (F32(max_value) * np.power(_sigmoid_f32(x), p, dtype=F32) + F32(threshold)).astype(F32)
@@ -135,10 +198,13 @@ def linear_resample_positions(n_frames, n_timesteps):
     reached through ddsp.core.resample -> tf.compat.v1.image.resize).
     """
     scale = F32(n_frames) / F32(n_timesteps)
-    pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
+    if RECALLED['resize'] == 'half_pixel':         # TF2 HalfPixelScaler: (out + 0.5) * scale - 0.5
+        pos = (((np.arange(n_timesteps, dtype=F32) + F32(0.5)).astype(F32) * scale).astype(F32) - F32(0.5)).astype(F32)
+    else:                                          # TF1 LegacyScaler: out * scale
+        pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
     fl = np.floor(pos).astype(F32)
-    lo = fl.astype(np.int64)
-    hi = np.minimum(np.ceil(pos).astype(np.int64), n_frames - 1)
+    lo = np.maximum(fl.astype(np.int64), 0)
+    hi = np.minimum(np.maximum(np.ceil(pos).astype(np.int64), 0), n_frames - 1)
     w = (pos - fl).astype(F32)
     return lo, hi, w
 
@@ -230,7 +296,10 @@ def angular_cumsum(angular_frequency, chunk_size=1000):
     n_chunks = length_p // chunk_size
     chunks = x.reshape((n_batch, n_chunks, chunk_size) + rest)
     phase = np.cumsum(chunks, axis=2, dtype=F32)                       # sequential float32 scan
-    offsets = np.mod(phase[:, :, -1:, ...], TWO_PI_F32).astype(F32)
+    last = phase[:, :, -1:, ...]
+    if RECALLED['angular_cumsum'] == 'exclusive':                      # tf.cumsum(exclusive=True): phase[0] = 0
+        phase = np.concatenate([np.zeros_like(phase[:, :, :1]), phase[:, :, :-1]], axis=2)
+    offsets = np.mod(last, TWO_PI_F32).astype(F32)
     offsets = np.concatenate([np.zeros_like(offsets[:, :1]), offsets[:, :-1]], axis=1)
     offsets = np.mod(np.cumsum(offsets, axis=1, dtype=F32), TWO_PI_F32).astype(F32)
     phase = (phase + offsets).astype(F32)
@@ -434,15 +503,20 @@ def apply_window_to_impulse_response(impulse_response, window_size=0, causal=Fal
         window_size = ir_size
     window = hann_window(window_size)
     padding = ir_size - window_size
+    centred = RECALLED['window_crop'] == 'centred'
     if padding > 0:
-        half_idx = (window_size + 1) // 2
+        half_idx = window_size // 2 if centred else (window_size + 1) // 2
         window = np.concatenate([window[half_idx:], np.zeros([padding], F32), window[:half_idx]], axis=0)
     else:
         window = np.fft.fftshift(window, axes=-1)
     ir = (window * ir).astype(F32)
     if padding > 0:
-        first_half_start = (ir_size - (half_idx - 1)) + 1
-        second_half_end = half_idx + 1
+        if centred:
+            first_half_start = ir_size - half_idx
+            second_half_end = window_size - half_idx
+        else:
+            first_half_start = (ir_size - (half_idx - 1)) + 1
+            second_half_end = half_idx + 1
         ir = np.concatenate([ir[..., first_half_start:], ir[..., :second_half_end]], axis=-1)
     else:
         ir = np.fft.fftshift(ir, axes=-1)
@@ -466,7 +540,10 @@ def crop_and_compensate_delay(audio, audio_size, ir_size, padding, delay_compens
         raise ValueError('Padding must be \'valid\' or \'same\', instead of {}.'.format(padding))
     total_size = int(audio.shape[-1])
     crop = total_size - crop_size
-    start = (ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation
+    if delay_compensation < 0:
+        start = ir_size // 2 if RECALLED['auto_delay'] == 'half' else (ir_size - 1) // 2 - 1
+    else:
+        start = delay_compensation
     end = crop - start
     return audio[:, start:total_size - end] if end != 0 else audio[:, start:0]
 
@@ -519,13 +596,13 @@ class FilteredNoise(Processor):
     """
 
     def __init__(self, frame_rate=250, sample_rate=16000, window_size=257, scale_fn=exp_sigmoid,
-                 initial_bias=-5.0, name='filtered_noise'):
+                 initial_bias=None, name='filtered_noise'):
         super().__init__(name=name)
         self.frame_rate = frame_rate
         self.sample_rate = sample_rate
         self.window_size = window_size
         self.scale_fn = scale_fn
-        self.initial_bias = initial_bias
+        self.initial_bias = RECALLED['initial_bias'] if initial_bias is None else initial_bias
 
     @property
     def upsampling(self):

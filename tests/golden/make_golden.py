@@ -11,9 +11,19 @@ Writes (all small, float32 .npz):
   c1_mono.npz            BASELINE config 1: 1 s monophonic note, poly=1, 64 harmonics, 24 kHz, dry.
   c2_small.npz           down-sized config 2: B=1, P=2, T=50, H=96, K=64, S=2, 16 kHz, full chain with
                          the real dafx22 IR (first 6000 taps of row 0).
-The expected outputs are "restatement goldens": they come from oracle/ddsp_oracle.py because
-TensorFlow / ddsp cannot be imported here.  If a TF + ddsp host ever exists,
-run this same script there with DDSP_GOLDEN_BACKEND=tf to upgrade them to TF goldens (hook below).
+  recalled_details.npz   one tiny single-operator case per recalled ddsp detail (oracle.RECALLED): flat-spectrum
+                         frequency_filter through the full and the cropped window, a resampled ramp, the angular
+                         cumsum of a constant, exp_sigmoid and the FilteredNoise bias.
+Every file carries a `backend` field.  "restatement": the expected outputs come from oracle/ddsp_oracle.py,
+because TensorFlow / ddsp cannot be imported in the build container.  On a host with
+TensorFlow + ddsp 3.7.0 + a checkout of the reference,
+
+    DDSP_GOLDEN_BACKEND=tf [DDSP_PIANO_REFERENCE=/path/to/ddsp-piano] python tests/golden/make_golden.py
+
+runs the SAME inputs through the real library (tests/golden/tf_backend.py), rewrites the files with
+backend = "tf", and prints, per recalled detail, which oracle setting the real outputs match.  From then on
+tests/test_golden_backend.py (CPU) holds the oracle, and the -m gpu golden tests hold the HIP path, to reference
+outputs: parity is pinned.
 """
 import os
 import sys
@@ -33,10 +43,60 @@ IR_OFFSET, IR_ROWS, IR_LEN = 308892, 10, 24000
 
 
 def backend():
+    """(module-like object with the oracle's constructors, backend name, version string)."""
     if os.environ.get('DDSP_GOLDEN_BACKEND') == 'tf':
-        raise SystemExit('TF backend hook: import ddsp / ddsp_piano here and build the same processors '
-                         '(MultiInharmonic, DynamicSizeFilteredNoise, effects.Reverb) with the same inputs.')
-    return O
+        sys.path.insert(0, HERE)
+        from tf_backend import TFBackend
+        b = TFBackend()
+        return b, 'tf', ', '.join(f'{k} {v}' for k, v in b.versions.items())
+    return O, 'restatement', f'numpy {np.__version__}'
+
+
+def recalled_cases(B_):
+    """Inputs and the backend's outputs for the single-operator cases that decide each recalled detail."""
+    rng = np.random.default_rng(77)
+    noise = rng.uniform(-1, 1, [1, 960]).astype(np.float32)
+    ramp = np.arange(12, dtype=np.float32)[None, :, None]
+    omega = np.full([1, 2500, 1], 0.01, np.float32)
+    x = np.linspace(-6, 6, 25).astype(np.float32)
+    raw_mag = rng.normal(0, 1, [1, 4, 8]).astype(np.float32)
+    out = dict(noise=noise, ramp=ramp, omega=omega, x=x, raw_mag=raw_mag)
+    out['flat_full'] = B_.frequency_filter(noise, np.ones([1, 10, 96], np.float32), 257)      # auto_delay
+    out['flat_crop'] = B_.frequency_filter(noise, np.ones([1, 10, 200], np.float32), 257)     # window_crop + auto_delay
+    out['ramp_linear'] = B_.resample(ramp, 12 * 96)                                            # resize
+    out['ramp_window'] = B_.resample(ramp, 12 * 96, method='window')
+    out['phase'] = B_.angular_cumsum(omega)                                                    # angular_cumsum
+    out['exp_sigmoid'] = B_.exp_sigmoid(x)                                                     # exp_sigmoid constants
+    out['noise_controls'] = B_.FilteredNoise(frame_rate=250, sample_rate=24000).get_controls(raw_mag)['magnitudes']
+    return {k: np.asarray(v, np.float32) for k, v in out.items()}
+
+
+def report_recalled(cases):
+    """Which oracle setting reproduces the backend's outputs (meaningful when the backend is the real library)."""
+    def err(a, b):
+        return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+    ones96, ones200 = np.ones([1, 10, 96], np.float32), np.ones([1, 10, 200], np.float32)
+    rows = []
+    for rule in O.RECALLED_CHOICES['auto_delay']:
+        with O.recalled(auto_delay=rule):
+            rows.append(('auto_delay', rule, err(O.frequency_filter(cases['noise'], ones96, 257), cases['flat_full'])))
+    for crop in O.RECALLED_CHOICES['window_crop']:
+        for rule in O.RECALLED_CHOICES['auto_delay']:
+            with O.recalled(window_crop=crop, auto_delay=rule):
+                rows.append((f'window_crop (auto_delay={rule})', crop,
+                             err(O.frequency_filter(cases['noise'], ones200, 257), cases['flat_crop'])))
+    for rule in O.RECALLED_CHOICES['resize']:
+        with O.recalled(resize=rule):
+            rows.append(('resize', rule, err(O.resample(cases['ramp'], 12 * 96), cases['ramp_linear'])))
+    for rule in O.RECALLED_CHOICES['angular_cumsum']:
+        with O.recalled(angular_cumsum=rule):
+            rows.append(('angular_cumsum', rule, err(O.angular_cumsum(cases['omega']), cases['phase'])))
+    rows.append(('exp_sigmoid', str(O.RECALLED['exp_sigmoid']), err(O.exp_sigmoid(cases['x']), cases['exp_sigmoid'])))
+    rows.append(('initial_bias', str(O.RECALLED['initial_bias']),
+                 err(O.FilteredNoise().get_controls(cases['raw_mag'])['magnitudes'], cases['noise_controls'])))
+    print('recalled detail                      oracle setting        rms error vs backend output')
+    for name, rule, e in rows:
+        print(f'{name:36s} {rule:20s} {e:.3e}' + ('   <-- matches' if e < 1e-5 else ''))
 
 
 def dafx22_ir():
@@ -48,9 +108,17 @@ def dafx22_ir():
 
 
 def main():
-    B_ = backend()
-    ir = dafx22_ir()
-    np.savez_compressed(os.path.join(HERE, 'dafx22_reverb_ir.npz'), ir=ir, rows=np.array([0, 9]))
+    B_, bname, bver = backend()
+    tag = dict(backend=np.array(bname), backend_versions=np.array(bver))
+    if os.path.exists(REF_CKPT):
+        ir = dafx22_ir()
+        np.savez_compressed(os.path.join(HERE, 'dafx22_reverb_ir.npz'), ir=ir, rows=np.array([0, 9]),
+                            backend=np.array('reference-data'), backend_versions=np.array('dafx22/ckpt-0'))
+    else:                      # a TF host without the checkpoint blob: the committed rows are the same data
+        ir = np.load(os.path.join(HERE, 'dafx22_reverb_ir.npz'))['ir']
+    cases = recalled_cases(B_)
+    np.savez_compressed(os.path.join(HERE, 'recalled_details.npz'), **cases, **tag)
+    report_recalled(cases)
 
     # ---- C1: 1 s mono note, 64 harmonics, 24 kHz, dry -----------------------------------------
     rng = np.random.default_rng(1234)
@@ -61,7 +129,7 @@ def main():
     audio = synth.get_signal(**ctl)
     np.savez_compressed(os.path.join(HERE, 'c1_mono.npz'), sample_rate=sr, frame_rate=250,
                         **{f'raw_{k}': v for k, v in raw.items()}, **{f'ctl_{k}': v for k, v in ctl.items()},
-                        audio=audio.astype(np.float32))
+                        audio=audio.astype(np.float32), **tag)
 
     # ---- down-sized C2: B=1, P=2, T=50, dafx22 dims, full chain --------------------------------
     rng = np.random.default_rng(1234)
@@ -83,7 +151,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'c2_small.npz'), sample_rate=sr, frame_rate=250, n_synths=P,
                         noises=noises, audio=out['signal'].astype(np.float32),
                         dry=out['controls']['add']['signal'].astype(np.float32),
-                        **{f'in_{k}': v for k, v in feats.items()})
+                        **{f'in_{k}': v for k, v in feats.items()}, **tag)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

@@ -1,0 +1,93 @@
+"""CPU: the committed golden vectors, their provenance, and the oracle against them.
+
+Every fixture made by tests/golden/make_golden.py carries a `backend` field: "restatement" (expected outputs
+computed by oracle/ddsp_oracle.py -- all that is possible without TensorFlow) or "tf" (the same inputs through the
+real TensorFlow + ddsp 3.7.0 + ddsp_piano modules, tests/golden/tf_backend.py).  The day the generator has run on a
+TF host these tests pin the ORACLE to reference outputs (and, per recalled ddsp detail, say which switch is wrong if
+one is); the -m gpu golden tests pin the HIP path to the same files.  A half-upgraded fixture set is an error."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from util import O, rms, rms_err
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SYNTH_FIXTURES = ('c1_mono', 'c2_small', 'recalled_details')
+KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
+            noise_controls=['magnitudes'], reverb_controls=['reverb_ir'])
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name + '.npz'))
+
+
+def _backends():
+    return {n: str(_load(n)['backend']) for n in SYNTH_FIXTURES}
+
+
+def test_every_fixture_names_its_backend_and_the_set_is_consistent():
+    for path in glob.glob(os.path.join(GOLD, '*.npz')):
+        g = np.load(path)
+        if os.path.basename(path) == 'midi_conditioning.npz':
+            continue                                   # outputs of the reference class itself (make_golden_midi.py)
+        assert 'backend' in g.files, f'{path} has no backend field: regenerate with tests/golden/make_golden.py'
+    kinds = set(_backends().values())
+    assert kinds <= {'restatement', 'tf'}
+    assert len(kinds) == 1, (f'mixed fixture set {_backends()}: a TF golden exists next to restatement goldens -- '
+                             'rerun DDSP_GOLDEN_BACKEND=tf python tests/golden/make_golden.py for all of them')
+
+
+def _tol():
+    # restatement goldens ARE the oracle's outputs (bit for bit up to numpy's libm); TF goldens are the parity bar
+    return 1e-4 if set(_backends().values()) == {'tf'} else 1e-6
+
+
+def test_oracle_reproduces_config1():
+    g = _load('c1_mono')
+    syn = O.MultiInharmonic(frame_rate=int(g['frame_rate']), sample_rate=int(g['sample_rate']), inference=True)
+    ctl = syn.get_controls(g['raw_amplitudes'], g['raw_harmonic_distribution'], g['raw_inharm_coef'], g['raw_f0_hz'])
+    for k in ('amplitudes', 'harmonic_distribution', 'harmonic_shifts', 'f0_hz'):
+        np.testing.assert_allclose(ctl[k], g[f'ctl_{k}'], rtol=2e-5, atol=1e-8)
+    audio = syn.get_signal(**ctl)
+    assert rms_err(audio, g['audio']) < _tol(), 'oracle vs golden C1: see test_recalled_details_match for the culprit'
+
+
+def test_oracle_reproduces_small_config2():
+    g = _load('c2_small')
+    P, sr = int(g['n_synths']), int(g['sample_rate'])
+    feats = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+    additive = O.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True)
+    noise = O.FilteredNoise(name='noise', frame_rate=250, sample_rate=sr)
+    dag = O.polyphonic_dag(additive, noise, O.Reverb(name='reverb'), n_synths=P, **KEYS)
+    out = O.ProcessorGroup(dag)(feats, return_outputs_dict=True,
+                                extra_kwargs={'noise': [{'noise': z} for z in g['noises']]})
+    assert rms_err(out['controls']['add']['signal'], g['dry']) < _tol()
+    assert rms_err(out['signal'], g['audio']) < _tol() * max(1.0, rms(g['audio']))
+
+
+@pytest.mark.parametrize('detail', ['auto_delay', 'window_crop', 'resize', 'angular_cumsum', 'exp_sigmoid',
+                                    'initial_bias'])
+def test_recalled_details_match(detail):
+    """One single-operator case per recalled ddsp detail: with TF goldens a failure here names the detail whose
+    default in oracle.RECALLED (and ddsp_piano_amd.core.RECALLED) is the wrong recollection."""
+    g = _load('recalled_details')
+    tol = 1e-5 if _tol() > 1e-5 else 1e-6
+    if detail == 'auto_delay':
+        got, want = O.frequency_filter(g['noise'], np.ones([1, 10, 96], np.float32), 257), g['flat_full']
+    elif detail == 'window_crop':
+        got, want = O.frequency_filter(g['noise'], np.ones([1, 10, 200], np.float32), 257), g['flat_crop']
+    elif detail == 'resize':
+        got, want = O.resample(g['ramp'], 12 * 96), g['ramp_linear']
+        assert rms_err(O.resample(g['ramp'], 12 * 96, method='window'), g['ramp_window']) < tol
+    elif detail == 'angular_cumsum':
+        got, want = O.angular_cumsum(g['omega']), g['phase']
+        d = np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - want.astype(np.float64)))))
+        assert d.max() < 1e-3                     # float32 scans of 2500 terms agree to ~1e-4 rad, never to 0.01
+        return
+    elif detail == 'exp_sigmoid':
+        got, want = O.exp_sigmoid(g['x']), g['exp_sigmoid']
+    else:
+        got, want = O.FilteredNoise().get_controls(g['raw_mag'])['magnitudes'], g['noise_controls']
+    assert rms_err(got, want) < tol, f'recalled detail {detail!r}: oracle default disagrees with the {_backends()} golden'

@@ -1,0 +1,119 @@
+"""GPU parity at the FULL sizes of the BASELINE configs, through the routes the benchmark times.
+
+  C3  batch 64 x 3 s, poly 16, 24 kHz, H=128, K=96, 3 s IR  -- bench.py's headline inputs (same generator, same seed):
+      group(features) and group(features, return_outputs_dict=True) on the compacted / side-stream / voice-sum
+      route, all 64 rows against the every-stem route, two segments against the oracle.
+  C2  one 3 s poly-16 segment, full chain, H=96/K=64 and H=128/K=96, against the oracle.
+  C5  the per-GPU share of config 5: batch 32, 48 kHz, poly 32, H=128, 3 s, 10 s IR (2^20-point FFT): all rows
+      against the every-stem route, one segment against the oracle.
+The oracle legs are a few tens of seconds of numpy each (one thread per voice)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_segments, rms, rms_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5                      # observed ~1e-7; BASELINE.json's bar is 1e-4 RMS
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _np_rows(feats, rows):
+    return {k: v[rows].cpu().numpy() if k != 'reverb_ir' else v[rows].cpu().numpy() for k, v in feats.items()}
+
+
+def _check_against_oracle(out, feats, noise, segments, P, sr, what):
+    rows = torch.as_tensor(segments, device='cuda')
+    fnp = _np_rows(feats, rows)
+    ref = oracle_segments(fnp, noise[rows].cpu().numpy(), P, sr, list(range(len(segments))))
+    for j, b in enumerate(segments):
+        r = ref[j]
+        sig = out['signal'][b:b + 1].cpu().numpy()
+        e = rms_err(sig, r['signal'])
+        assert e < TOL * max(1.0, rms(r['signal'])), f'{what}: segment {b}: {e:.3e} vs rms {rms(r["signal"]):.3e}'
+        ctl = out.get('controls')
+        if ctl is not None:
+            assert rms_err(ctl['add']['signal'][b:b + 1].cpu().numpy(), r['dry']) < TOL * max(1.0, rms(r['dry'])), what
+            assert rms_err(ctl['additive']['signal'][b:b + 1].cpu().numpy(), r['additive_last']) < TOL, what
+            assert rms_err(ctl['noise']['signal'][b:b + 1].cpu().numpy(), r['noise_last']) < TOL, what
+
+
+def test_config3_batch64_headline_routes():
+    bench = _bench()
+    import ddsp_piano_amd as dp
+    B, P, T, H, K, S, sr, L = 64, 16, 750, 128, 96, 1, 24000, 72000
+    N = T * 96
+    dev = torch.device('cuda', 0)
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=20240)       # bench.py's rank-0 inputs
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_group(dp, P, sr)
+    audio = pg(feats, noise=noise)                                              # audio-only form
+    full = pg(feats, return_outputs_dict=True, noise=noise)                     # the reference's call form (timed)
+    stems = pg(feats, return_outputs_dict=True, need_stems=True, noise=noise)   # every voice's stems: per-voice kernels
+    torch.cuda.synchronize()
+    assert audio.shape == (B, N) and torch.isfinite(audio).all()
+    scale = max(1.0, float(stems['signal'].abs().max()))
+    # all 64 rows: the compacted routes against the per-voice route (summation order of the voices differs)
+    assert (audio - stems['signal']).abs().max().item() < 2e-5 * scale
+    assert (full['signal'] - stems['signal']).abs().max().item() < 2e-5 * scale
+    assert (full['controls']['add']['signal'] - stems['controls']['add']['signal']).abs().max().item() < 2e-5 * scale
+    for name in ('additive', 'noise'):
+        a, b = full['controls'][name]['signal'], stems['controls'][name]['signal']
+        assert (a - b).abs().max().item() < 2e-6 * max(1.0, float(b.abs().max())), name
+    rng = np.random.default_rng(3)
+    segments = sorted(int(x) for x in rng.choice(B, 2, replace=False))
+    _check_against_oracle(full, feats, noise, segments, P, sr, 'C3 outputs dict')
+    _check_against_oracle({'signal': audio}, feats, noise, segments, P, sr, 'C3 audio only')
+
+
+@pytest.mark.parametrize('H,K', [(96, 64), (128, 96)])
+def test_config2_one_3s_poly16_segment(H, K):
+    bench = _bench()
+    import ddsp_piano_amd as dp
+    B, P, T, S, sr, L = 1, 16, 750, 1, 24000, 72000
+    N = T * 96
+    dev = torch.device('cuda', 0)
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=7, silent_frac=0.1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_group(dp, P, sr)
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    audio = pg(feats, noise=noise)
+    _check_against_oracle(full, feats, noise, [0], P, sr, f'C2 H={H} K={K} outputs dict')
+    _check_against_oracle({'signal': audio}, feats, noise, [0], P, sr, f'C2 H={H} K={K} audio only')
+
+
+def test_config5_per_gpu_share_48k_poly32():
+    bench = _bench()
+    import ddsp_piano_amd as dp
+    B, P, T, H, K, S, sr, L = 32, 32, 750, 128, 96, 1, 48000, 480000
+    N = T * 192
+    dev = torch.device('cuda', 0)
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=5)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_group(dp, P, sr)
+    assert pg.additive.upsampling == 192
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    stems = pg(feats, return_outputs_dict=True, need_stems=True, noise=noise)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(stems['signal'].abs().max()))
+    assert full['signal'].shape == (B, N) and torch.isfinite(full['signal']).all()
+    assert (full['signal'] - stems['signal']).abs().max().item() < 3e-5 * scale
+    assert (full['controls']['add']['signal'] - stems['controls']['add']['signal']).abs().max().item() < 3e-5 * scale
+    del stems
+    _check_against_oracle(full, feats, noise, [int(np.random.default_rng(9).integers(B))], P, sr, 'C5')

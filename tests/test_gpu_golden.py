@@ -45,14 +45,36 @@ def test_config2_small_full_chain_with_real_dafx22_ir():
     feats = {k[3:]: _dev(g[k]) for k in g.files if k.startswith('in_')}
     additive = dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True)
     noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr)
-    noise.noise_override = [_dev(z) for z in g['noises']]
     dag = dp.polyphonic_dag(additive, noise, dp.Reverb(name='reverb'),
                             additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
                             noise_controls=['magnitudes'], reverb_controls=['reverb_ir'], n_synths=P)
-    out = dp.ProcessorGroup(dag)(feats, return_outputs_dict=True)
+    out = dp.ProcessorGroup(dag)(feats, return_outputs_dict=True, noise=[_dev(z) for z in g['noises']])
     err = rms_err(out['signal'].cpu().numpy(), g['audio'])
     assert err < TOL * max(1.0, rms(g['audio'])), f'{err:.3e} vs rms {rms(g["audio"]):.3e}'
     assert rms_err(out['controls']['add']['signal'].cpu().numpy(), g['dry']) < TOL
+
+
+def test_recalled_detail_cases():
+    """The single-operator cases that decide the recalled ddsp details (tests/golden/recalled_details.npz), through the
+    HIP path.  With TF-made goldens this is where a wrong default of ddsp_piano_amd.core.RECALLED shows, by name."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    g = np.load(os.path.join(GOLD, 'recalled_details.npz'))
+    noise = _dev(g['noise'])
+    flat = core.frequency_filter(noise, torch.ones(1, 10, 96, device='cuda'), 257).cpu().numpy()
+    assert rms_err(flat, g['flat_full']) < 1e-5, 'auto_delay'
+    crop = core.frequency_filter(noise, torch.ones(1, 10, 200, device='cuda'), 257).cpu().numpy()
+    assert rms_err(crop, g['flat_crop']) < 1e-5, 'window_crop / auto_delay'
+    assert rms_err(core.resample(_dev(g['ramp']), 12 * 96).cpu().numpy(), g['ramp_linear']) < 1e-6, 'resize'
+    assert rms_err(core.resample(_dev(g['ramp']), 12 * 96, method='window').cpu().numpy(), g['ramp_window']) < 1e-6
+    np.testing.assert_allclose(core.exp_sigmoid(_dev(g['x'])).cpu().numpy(), g['exp_sigmoid'], rtol=2e-5, atol=1e-9)
+    ctl = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=24000).get_controls(_dev(g['raw_mag']))['magnitudes']
+    np.testing.assert_allclose(ctl.cpu().numpy(), g['noise_controls'], rtol=2e-5, atol=1e-9)
+    # angular cumsum of a constant omega = a single sinusoid of constant frequency through the oscillator bank
+    om = float(g['omega'][0, 0, 0])
+    fe = torch.full((1, 2500 + 4, 1), om * 24000.0 / 6.2831855, device='cuda')          # omega = fe * 2 pi / sr
+    got = core.cos_oscillator_bank(fe, torch.ones_like(fe), 24000, True, True).cpu().numpy()[0, :2500]
+    assert np.abs(got - np.cos(g['phase'][0, :, 0].astype(np.float64))).max() < 2e-3, 'angular_cumsum'
 
 
 def test_full_size_properties_config3_shape():

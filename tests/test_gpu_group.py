@@ -55,12 +55,8 @@ def test_processor_group_matches_oracle(B, P, T, H, K, S, sr, L):
 
     for fast in (True, False):
         gdag, gnoise = _build(dp, P, sr)
-        gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
-        if not fast:       # node-by-node route: feed the same noise through get_signal
-            orig = gnoise.get_signal
-            gnoise.get_signal = lambda magnitudes, _o=orig, _n=gnoise: _o(magnitudes, noise=_n.noise_override.pop(0))
         pg = dp.ProcessorGroup(gdag, fast_path=fast)
-        out = pg(gfeats, return_outputs_dict=True)
+        out = pg(gfeats, return_outputs_dict=True, noise=[torch.as_tensor(z, device='cuda') for z in noises])
         sig = out['signal'].cpu().numpy()
         ref = oref['signal']
         assert sig.shape == ref.shape == (B, N)
@@ -99,12 +95,9 @@ def test_fast_path_zero_copy_views_and_no_reverb(voice_major, stems):
     dagb, _ = _build(dp, P, sr, with_reverb=False)
     b = dp.ProcessorGroup(dagb, fast_path=False)
     noise = torch.as_tensor(rng.uniform(-1, 1, [P, B, T * 64]).astype(np.float32), device='cuda')
-    a.noise.noise_override = [noise[i] for i in range(P)]
-    b.noise.noise_override = [noise[i] for i in range(P)]
-    orig = b.noise.get_signal
-    b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
+    nz = [noise[i] for i in range(P)]
     if stems:
-        oa, ob = a(feats, return_outputs_dict=True, need_stems=True), b(feats, return_outputs_dict=True)
+        oa, ob = a(feats, return_outputs_dict=True, need_stems=True, noise=nz), b(feats, return_outputs_dict=True, noise=nz)
         ya, yb = oa['signal'], ob['signal']
         for name in ('additive', 'noise'):             # the last voice's stems, as the node-by-node walk leaves them
             assert (oa['controls'][name]['signal'] - ob['controls'][name]['signal']).abs().max().item() < 2e-6
@@ -112,7 +105,7 @@ def test_fast_path_zero_copy_views_and_no_reverb(voice_major, stems):
         assert voices.shape == (B, P, T * 64)
         assert torch.equal(voices[:, P - 1], oa['controls']['additive']['signal'])
     else:
-        ya, yb = a(feats), b(feats)
+        ya, yb = a(feats, noise=nz), b(feats, noise=noise.transpose(0, 1))      # list of P [B, N] == tensor [B, P, N]
     assert ya.shape == (B, T * 64)
     assert (ya - yb).abs().max().item() < 2e-6
 
@@ -162,8 +155,8 @@ def test_long_segment_whole_file_mode():
     odag, _ = _build(O, P, sr)
     ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': z} for z in noises]})
     gdag, gnoise = _build(dp, P, sr)
-    gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
-    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}).cpu().numpy()
+    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()},
+                                  noise=[torch.as_tensor(z, device='cuda') for z in noises]).cpu().numpy()
     assert got.shape == ref.shape == (B, N)
     err = rms_err(got, ref)
     assert err < TOL * max(1.0, rms(ref)), f'{err:.3e} vs rms {rms(ref):.3e}'
@@ -196,11 +189,9 @@ def test_default_model_dag_shape():
     odag, _ = _default_model_dag(O, P, sr)
     ref = O.ProcessorGroup(odag)(feats, return_outputs_dict=True, extra_kwargs={'noise': [{'noise': z} for z in noises]})
     gdag, gnoise = _default_model_dag(dp, P, sr)
-    gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
-    orig = gnoise.get_signal
-    gnoise.get_signal = lambda magnitudes: orig(magnitudes, noise=gnoise.noise_override.pop(0))
     pg = dp.ProcessorGroup(gdag)
-    out = pg({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}, return_outputs_dict=True)
+    out = pg({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}, return_outputs_dict=True,
+             noise=[torch.as_tensor(z, device='cuda') for z in noises])
     assert rms_err(out['signal'].cpu().numpy(), ref['signal']) < TOL * max(1.0, rms(ref['signal']))
     for k in ('add_0', f'add_{P - 1}', f'sub_add_{P - 1}'):
         assert rms_err(out['controls'][k]['signal'].cpu().numpy(), ref['controls'][k]['signal']) < TOL
@@ -233,11 +224,7 @@ def test_config5_shape_48k_poly32_long_ir():
     daga, _ = _build(dp, P, sr, with_reverb=False)
     dagb, _ = _build(dp, P, sr, with_reverb=False)
     a, b = dp.ProcessorGroup(daga, fast_path=True), dp.ProcessorGroup(dagb, fast_path=False)
-    a.noise.noise_override = [noise[:, i] for i in range(P)]
-    b.noise.noise_override = [noise[:, i] for i in range(P)]
-    orig = b.noise.get_signal
-    b.noise.get_signal = lambda magnitudes: orig(magnitudes, noise=b.noise.noise_override.pop(0))
-    assert (a(feats) - b(feats)).abs().max().item() < 5e-6
+    assert (a(feats, noise=noise) - b(feats, noise=noise)).abs().max().item() < 5e-6
 
 
 def test_monophonic_group_and_config1_dry():
@@ -251,11 +238,8 @@ def test_monophonic_group_and_config1_dry():
     ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': noise}]})
     for fast in (True, False):
         gdag, gnoise = _build(dp, P, sr, with_reverb=False)
-        gnoise.noise_override = [torch.as_tensor(noise, device='cuda')]
-        if not fast:
-            orig = gnoise.get_signal
-            gnoise.get_signal = lambda magnitudes, _o=orig, _n=gnoise: _o(magnitudes, noise=_n.noise_override.pop(0))
-        got = dp.ProcessorGroup(gdag, fast_path=fast)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()})
+        got = dp.ProcessorGroup(gdag, fast_path=fast)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()},
+                                                      noise=[torch.as_tensor(noise, device='cuda')])
         assert got.shape == (B, 24000) and rms_err(got.cpu().numpy(), ref) < TOL
 
 
@@ -345,10 +329,9 @@ def test_outputs_dict_routes_agree():
     outs = {}
     for mode in ('last', True, False):
         dag, gnoise = _build(dp, P, sr)
-        gnoise.noise_override = list(noises)
         pg = dp.ProcessorGroup(dag)
-        outs[mode] = pg(feats, return_outputs_dict=True, need_stems=mode) if mode is not False else \
-            {'signal': pg(feats), 'controls': None}
+        outs[mode] = pg(feats, return_outputs_dict=True, need_stems=mode, noise=list(noises)) if mode is not False else \
+            {'signal': pg(feats, noise=list(noises)), 'controls': None}
     last, full, audio = outs['last'], outs[True], outs[False]
     # same kernels as the audio-only call (which adds the noise of four voices at a time inside the noise kernel)
     assert (last['signal'] - audio['signal']).abs().max().item() < 5e-6
@@ -410,8 +393,8 @@ def test_odd_shapes_match_the_oracle(B, P, T, H, K, L):
     odag, _ = _build(O, P, sr)
     ref = O.ProcessorGroup(odag)(feats, extra_kwargs={'noise': [{'noise': z} for z in noises]})
     gdag, gnoise = _build(dp, P, sr)
-    gnoise.noise_override = [torch.as_tensor(z, device='cuda') for z in noises]
-    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}).cpu().numpy()
+    got = dp.ProcessorGroup(gdag)({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()},
+                                  noise=[torch.as_tensor(z, device='cuda') for z in noises]).cpu().numpy()
     assert got.shape == ref.shape == (B, N)
     assert rms_err(got, ref) < TOL * max(1.0, rms(ref))
 

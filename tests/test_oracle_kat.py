@@ -171,3 +171,81 @@ def test_goldens_have_not_drifted():
     assert audio.shape == (1, 24000) and rms_err(audio, g['audio']) < 1e-6
     ir = np.load(os.path.join(GOLD, 'dafx22_reverb_ir.npz'))['ir']
     assert ir.shape == (2, 24000) and abs(ir[0, 1] - 3.18) < 0.05
+
+
+# ----------------------------------------------------------------------------------------------------
+# The recalled ddsp details as switches (oracle.RECALLED): every alternative has its own known answer, so the
+# day real ddsp outputs exist the matching setting is identified by data, not by recollection.
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rule,delay_full,shift_crop', [('ddsp370', 2, 0), ('half', 0, -1)])
+def test_auto_delay_rule_known_answers(rule, delay_full, shift_crop):
+    """Flat magnitudes = a unit tap at the FIR's zero-time index: tap K - 1 for the full-length window
+    (2 (K - 1) <= 257), tap 127 for the 257-tap crop.  'ddsp370' crops (L - 1) // 2 - 1 samples: 2-sample
+    delay / exact alignment.  'half' crops L // 2: exact alignment / one sample early."""
+    rng = np.random.default_rng(0)
+    noise = rng.uniform(-1, 1, [1, 960]).astype(np.float32)
+    with O.recalled(auto_delay=rule):
+        y = O.frequency_filter(noise, np.ones([1, 10, 96], np.float32), 257)
+        yc = O.frequency_filter(noise, np.ones([1, 10, 200], np.float32), 257)
+    d = delay_full
+    assert np.abs(y[0, d:] - noise[0, :960 - d]).max() < 1e-6
+    # cropped window: the unit tap sits one sample before the window's peak and carries the weight hann257[127]
+    g = O.hann_window(257)[127]
+    if shift_crop == 0:
+        assert np.abs(yc[0] - g * noise[0]).max() < 2e-6
+    else:
+        assert np.abs(yc[0, :-1] - g * noise[0, 1:]).max() < 2e-6
+    assert O.RECALLED['auto_delay'] == 'ddsp370'           # the context manager restores the default
+
+
+@pytest.mark.parametrize('rule,peak', [('ddsp370', 127), ('centred', 128)])
+def test_window_crop_known_answers(rule, peak):
+    with O.recalled(window_crop=rule):
+        ir = O.frequency_impulse_response(np.ones([1, 1, 200], np.float32), 257)
+    assert ir.shape[-1] == 257 and int(np.argmax(ir[0, 0])) == peak
+    if rule == 'centred':           # symmetric about the peak, which carries the full window weight
+        assert abs(ir[0, 0, peak] - 1.0) < 1e-6
+        assert np.abs(ir[0, 0, peak + 1:] - ir[0, 0, peak - 1::-1][:128]).max() < 1e-6
+
+
+@pytest.mark.parametrize('rule', ['legacy', 'half_pixel'])
+def test_resize_rule_known_answers(rule):
+    """A ramp stays a ramp: legacy -> y[n] = n / U with the last frame held; half-pixel -> shifted by half an
+    output pixel, (n + 0.5) / U - 0.5, clamped to the first / last frame at the ends."""
+    T, U = 12, 96
+    x = np.arange(T, dtype=np.float32)[None, :, None]
+    with O.recalled(resize=rule):
+        y = O.resample(x, T * U)[0, :, 0]
+    n = np.arange(T * U)
+    if rule == 'legacy':
+        want = np.minimum(n / U, T - 1)
+    else:
+        want = np.clip((n + 0.5) / U - 0.5, 0, T - 1)
+    assert np.abs(y - want).max() < 1e-5
+
+
+@pytest.mark.parametrize('rule', ['ddsp370', 'exclusive'])
+def test_angular_cumsum_rule_known_answers(rule):
+    """Constant omega: phase[n] = (n + 1) omega (inclusive: the first sample is cos(omega)) or n omega (exclusive:
+    the first sample is 1), wrapped; both continue across the 1000-sample chunk boundary."""
+    om = np.float32(0.01)
+    with O.recalled(angular_cumsum=rule):
+        ph = O.angular_cumsum(np.full([1, 2500, 1], om, np.float32))[0, :, 0]
+    k = np.arange(2500) + (1 if rule == 'ddsp370' else 0)
+    want = np.mod(k.astype(np.float64) * float(om), 2 * np.pi)
+    err = np.abs(np.angle(np.exp(1j * (ph - want))))
+    assert err.max() < 5e-4 and (ph[0] == (om if rule == 'ddsp370' else 0.0))
+
+
+def test_scale_constants_are_switchable():
+    x = np.float32(0.3)
+    base = O.exp_sigmoid(x)
+    with O.recalled(exp_sigmoid=(10.0, 1.0, 1e-7)):
+        assert abs(O.exp_sigmoid(x) - (base - 1e-7) / 2 - 1e-7) < 1e-6
+    with O.recalled(initial_bias=0.0):
+        assert O.FilteredNoise().initial_bias == 0.0
+    assert O.FilteredNoise().initial_bias == -5.0
+    with pytest.raises(ValueError):
+        O.recalled(auto_delay='nope')
+    with pytest.raises(KeyError):
+        O.recalled(unknown=1)

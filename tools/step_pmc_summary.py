@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Joins the passes of tools/step_pmc.sh: per kernel, launches, average duration, SQ counters per launch, and the
+VALU issue fraction  = SQ_INSTS_VALU (wave instructions) * 2 cycles / (1024 SIMDs * clock * duration)   [clock from
+GRBM_GUI_ACTIVE / duration], HBM bytes (FETCH_SIZE KiB x 2 on gfx950, WRITE_SIZE KiB)."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+SIMDS = 1024
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    name = re.sub(r'\(.*$', '', name)
+    return name.replace('ddspp::', '')
+
+
+def pmc(path):
+    agg = defaultdict(lambda: defaultdict(list))
+    for fn in glob.glob(os.path.join(path, '**', '*counter_collection.csv'), recursive=True):
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                agg[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
+    return agg
+
+
+def main(out):
+    dur, calls = {}, {}
+    for fn in glob.glob(os.path.join(out, 'kt', '**', '*kernel_stats.csv'), recursive=True):
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                k = short(row['Name'])
+                dur[k] = dur.get(k, 0.0) + float(row['TotalDurationNs'])
+                calls[k] = calls.get(k, 0) + int(row['Calls'])
+    ctr = defaultdict(dict)
+    for sub in ('a', 'b', 'f', 'w'):
+        for k, cs in pmc(os.path.join(out, sub)).items():
+            for c, v in cs.items():
+                ctr[k][c] = sum(v) / len(v)
+    for k in sorted(dur, key=lambda k: -dur[k]):
+        c = ctr.get(k)
+        if not c:
+            continue
+        ms = dur[k] / calls[k] / 1e6
+        print(f'{k[:96]}\n    launches {calls[k]}  avg {ms:.4f} ms')
+        gui = c.get('GRBM_GUI_ACTIVE')
+        clk = gui / (ms * 1e-3) if gui else None
+        for name in sorted(c):
+            print(f'    {name:30s} {c[name]:18.1f}')
+        if clk and 'SQ_INSTS_VALU' in c:
+            # kernel time under the counter pass differs slightly from the trace pass: use the pass's own GRBM cycles
+            frac = c['SQ_INSTS_VALU'] * 2.0 / (SIMDS * gui)
+            print(f'    -> clock {clk / 1e9:.3f} GHz; VALU issue fraction (2 cycles per wave64 instruction) = {frac:.3f}')
+        if 'SQ_ACTIVE_INST_VALU' in c and 'SQ_BUSY_CYCLES' in c and gui:
+            print(f'    -> SQ_ACTIVE_INST_VALU / (4 * 1024 SIMD-cycles) = {c["SQ_ACTIVE_INST_VALU"] / (4.0 * SIMDS * gui):.3f}'
+                  f'   [counter is in quad-cycles per SIMD]')
+        if 'FETCH_SIZE' in c or 'WRITE_SIZE' in c:
+            rd = 2.0 * c.get('FETCH_SIZE', 0.0) * 1024 / 1e9
+            wr = c.get('WRITE_SIZE', 0.0) * 1024 / 1e9
+            print(f'    -> HBM read {rd:.3f} GB, written {wr:.3f} GB per launch = {(rd + wr) / (ms * 1e-3) / 1e3:.2f} TB/s')
+
+
+    # wave-instruction count of one ddspp_polyphonic_additive call (bench.py roofline_step reads it from profiles/)
+    add_kernels = [k for k in ctr if k.startswith(('osc_prepass', 'osc_count', 'osc_partial_sum', 'osc_offset_scan')) or
+                   re.match(r'osc_kernel<\d, true, 0, true, true>', k)]
+    tot = sum(ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels)
+    if tot:
+        import json
+        json.dump({'valu_wave_instructions_per_call': tot,
+                   'kernels': {k: ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels},
+                   'source': 'rocprofv3 --pmc SQ_INSTS_VALU over bench.py --steps 3 --warmup 1 (tools/step_pmc.sh), '
+                             'per-launch averages of the kernels of ddspp_polyphonic_additive at BASELINE config 3'},
+                  open(os.path.join(out, 'step_valu.json'), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
