@@ -17,12 +17,14 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'oscillator.hip', 'resample.hip', 'controls.hip', 'noise.hip',
-           'reverb.hip', 'fdn.hip']
+SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
+           'noise.hip', 'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
+HEADERS = ['ddspp_common.h', 'osc_common.h']
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
-PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize']}
+PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'],
+                  'bank_compact.hip': ['-fno-slp-vectorize']}
 
 DDSPP_OK = 0
 DDSPP_EINVAL = -22
@@ -39,7 +41,7 @@ def _needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, 'ddspp_common.h')]
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -57,7 +59,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
         srcp = os.path.join(_CSRC, src)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, 'ddspp_common.h'))):
+                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, h)) for h in HEADERS)):
             return obj
         extra = PER_FILE_FLAGS.get(src, [])
         cmd = [hipcc] + flags + extra + ['-x', 'hip', '-c', srcp, '-o', obj]
@@ -95,15 +97,17 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
-    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                           c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     'ddspp_scale_bias': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_float, c_float,
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_mix_last_voice': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_void_p]),
     'ddspp_fir_from_magnitudes': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                           c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes_eo': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -111,7 +115,7 @@ SIGNATURES = {
                                              c_float, c_float, c_void_p]),
     'ddspp_frequency_filter_eo_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'ddspp_frequency_filter_eo': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 + [c_void_p]),
-    'ddspp_frequency_filter_eo_voices': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 + [c_int] * 3 + [c_void_p]),
+    'ddspp_frequency_filter_eo_voices': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float] * 5 + [c_int] * 3 + [c_void_p]),
     'ddspp_time_varying_fir': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     'ddspp_uniform_noise': (c_int, [c_void_p, c_size_t, c_uint64, c_uint64, c_void_p]),

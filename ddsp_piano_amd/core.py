@@ -505,13 +505,15 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
-                        sample_rate, spans=0, voice_major=False, audible=None):
+                        sample_rate, spans=0, voice_major=False, audible=None, split_last=False):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
     The per-voice stems are never formed; lanes go only to oscillators that are audible somewhere in a
     span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only.  audible: the int32 [R, T]
-    per-frame counts of InHarmonic._controls(want_counts=True) (saves a scan of the [R, T, H] controls)."""
+    per-frame counts of InHarmonic._controls(want_counts=True) (saves a scan of the [R, T, H] controls).
+    split_last=True returns (sum of voices 0 .. P-2, the last voice's stem): what the outputs dictionary of the
+    reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37)."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
@@ -524,6 +526,7 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     nbytes = int(lib.ddspp_polyphonic_additive_workspace_bytes(b, p, t, s, h, u))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     out = torch.empty((b, n_samples), dtype=torch.float32, device=dev)
+    last = torch.empty((b, n_samples), dtype=torch.float32, device=dev) if split_last else None
     null = ctypes.c_void_p(0)
     if audible is not None and (audible.dtype != torch.int32 or audible.numel() != r * t or not audible.is_contiguous()):
         raise ValueError('audible must be a contiguous int32 tensor of R * T frame counts')
@@ -531,9 +534,9 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
         _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
         _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
         ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(wlin), _ptr(whann),
-        _ptr(out), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
+        _ptr(out), _ptr(last), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
         _stream()))
-    return out
+    return (out, last) if split_last else out
 
 
 def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_distribution=None,
@@ -782,11 +785,13 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
     return out if padded == audio_size else out[:, :audio_size].contiguous()
 
 
-def frequency_filter_voice_sums(audio, magnitudes, window_size, raw_scale, n_voices, voices_per_row, voice_major):
+def frequency_filter_voice_sums(audio, magnitudes, window_size, raw_scale, n_voices, voices_per_row, voice_major,
+                                split_last=False):
     """frequency_filter over the rows of a polyphonic group with `voices_per_row` consecutive voices of a segment
-    summed into one output row ([R / voices_per_row, N], segment major); None when the fused kernel does not apply."""
+    summed into one output row ([R / voices_per_row, N], segment major); None when the fused kernel does not apply.
+    split_last=True: returns (sums, last) -- every segment's last voice [B, N] stays out of its row's sum."""
     return _frequency_filter_fused(audio, magnitudes, window_size, 'same', raw_scale,
-                                   voices=(int(n_voices), int(voices_per_row), bool(voice_major)))
+                                   voices=(int(n_voices), int(voices_per_row), bool(voice_major), bool(split_last)))
 
 
 def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale=None):
@@ -832,15 +837,16 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, 
                                                  prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
                                                  _stream()))
         return out
-    n_voices, vq, vmajor = voices
-    if n_voices % vq or b % n_voices:
+    n_voices, vq, vmajor, split_last = voices
+    if n_voices % vq or b % n_voices or (split_last and vq < 2):
         return None
     out = torch.empty((b // vq, n), dtype=torch.float32, device=x.device)
+    last = torch.empty((b // n_voices, n), dtype=torch.float32, device=x.device) if split_last else None
     _lib.check(lib.ddspp_frequency_filter_eo_voices(
-        _ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), b, n, t, k, lw, nj, dcode,
-        int(code), float(bias), prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'], n_voices, vq,
+        _ptr(x), _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), _ptr(last), b, n, t, k, lw, nj,
+        dcode, int(code), float(bias), prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'], n_voices, vq,
         int(vmajor), _stream()))
-    return out
+    return (out, last) if split_last else out
 
 
 def uniform_noise(shape, seed=0, offset=0, device=None):

@@ -1,0 +1,437 @@
+// Compacted polyphonic oscillator bank for gfx950 (CDNA4): the additive branch of a whole segment --
+// sum over the P voices of MultiInharmonic.get_signal (ddsp_piano/modules/inharm_synth.py:272-293 ->
+// harmonic_synthesis :87-127 -> cos_oscillator_bank :49-84 with ddsp.core.angular_cumsum) -- straight from the
+// frame-rate controls, with lanes only for oscillators that are audible somewhere in the span.
+//
+// This is the kernel the timed step spends most of its time in; it is VALU bound.  What the
+// code below is built around, all measured on the MI355X (tools/ubench, profiles/):
+//   * a wave64 VALU instruction issues in ~2.3 cycles when its neighbours are independent, ~4.4 when each depends on
+//     its predecessor -- other wavefronts of the SIMD do not fill the gap (valu_latency).  So every stage of a block
+//     works on all 8 samples x VPL oscillators at once: sixteen independent chains, never one after the other;
+//   * a quarter-rate v_cos_f32 costs 8.1 cycles back to back but ~4 cycles extra at every switch between plain and
+//     transcendental instructions (trans_overlap): the sixteen cosines of a block are issued as one run;
+//   * scheduling barriers between the stages keep the compiler from re-serialising the chains to save registers (the
+//     all-purpose osc_kernel template ends up with one chain through two temporaries at the 128-VGPR cap).
+// Arithmetic is that of osc_kernel (ddspp_common.h): per (oscillator, sample) the float32 phase scan
+// `ph += omega` in the reference's order, `s = ph + off`, an EXACT reduction r = s - rint(s / P) P (one FMA, P =
+// float32(2 pi), the reference's modulus), v_cos_f32 on r / P; amplitudes through the Hann cross-fade FMA.
+#include <type_traits>
+
+#include "osc_common.h"
+
+namespace ddspp {
+
+namespace {
+
+constexpr float INV_P = 0x1.45f306p-3f;      // RN(1 / (2 pi))
+
+// One wavefront per workgroup: slots past the audible set exit at once and give their place to the next workgroup.
+template <int VPL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bank_compact_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
+    float* tile = lds_dyn;                                   // [TILE][TSTRIDE]
+    const int lane = threadIdx.x & 63;
+    // workgroup index = slot major, (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so
+    // every XCD gets the same mix of busy (low slots) and idle workgroups and the busy ones are dispatched first
+    const int nbs = p.R * p.spans;
+    const int cw_all = blockIdx.x / nbs;
+    const int bs = blockIdx.x - cw_all * nbs;
+    const int row = bs / p.spans;                            // segment b
+    const int span = bs - row * p.spans;
+    const int c0 = span * p.cps, c1 = min(c0 + p.cps, p.nchunks);
+    const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S;
+    typedef const __attribute__((address_space(4))) float* cfloat_p;     // wave-uniform tables -> scalar loads
+    const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
+    const cfloat_p whann_c = (cfloat_p)(uintptr_t)p.whann;
+    const int n_begin = c0 * DDSPP_CHUNK, n_end = min(c1 * DDSPP_CHUNK, N);
+    const float nyq = p.nyq, sr = p.sr, rsr = p.rsr;
+
+    // ---- which oscillators this slot carries ------------------------------------------------------------------
+    // The audible oscillators of the segment's (voice, sub-string) rows are packed back to back: sub-row q
+    // contributes its first nk harmonics.  Region A = voices [0, P - split_last), region B = the last voice.
+    const int Q = p.P * S, Qa = (p.P - p.split_last) * S;
+    const bool in_b = cw_all >= p.wmax_a;
+    const int cw = in_b ? cw_all - p.wmax_a : cw_all;
+    const int len = lane < Q ? p.nk[((size_t)row * p.spans + span) * p.P + lane / S] : 0;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int total_a = Qa > 0 ? __shfl(incl, Qa - 1) : 0;
+    const int total_b = __shfl(incl, 63) - total_a;
+    if (cw_all == 0 && lane == 0) {
+        int* wc = p.wcount + ((size_t)row * p.spans + span) * 2;
+        wc[0] = (total_a + 64 * VPL - 1) / (64 * VPL);
+        wc[1] = (total_b + 64 * VPL - 1) / (64 * VPL);
+    }
+    const int total = in_b ? total_b : total_a;
+    if (64 * VPL * cw >= total) return;                      // nothing audible left for this slot
+    const int qlo = in_b ? Qa : 0, qhi = in_b ? Q : Qa, base = in_b ? total_a : 0;
+    int* offs = reinterpret_cast<int*>(tile);                // exclusive offsets of the sub-rows, via LDS
+    offs[lane] = incl - len - base;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int vk[VPL], vs[VPL], lrow[VPL], vidx[VPL];
+    bool valid[VPL];
+    float kmul[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int g = 64 * VPL * cw + lane + 64 * j;
+        const int gc = min(g, total - 1);
+        int q = qlo;                                         // last sub-row of the region whose offset is <= gc
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (q + step < qhi && offs[q + step] <= gc) q += step;
+        const int k = gc - offs[q];
+        lrow[j] = p.vmajor ? (q / S) * p.R + row : row * p.P + q / S;
+        vs[j] = q - (q / S) * S;
+        vk[j] = k;
+        vidx[j] = vs[j] * H + k;
+        valid[j] = g < total;
+        kmul[j] = (float)(k + 1);                            // linspace(1, H, H)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- running state ---------------------------------------------------------------------------------------
+    float ph[VPL], asum[VPL], off[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        ph[j] = 0.0f;
+        asum[j] = 0.0f;
+        off[j] = 0.0f;
+    }
+    if (p.spans > 1) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            asum[j] = p.astart[((size_t)lrow[j] * p.spans + span) * p.VP + vidx[j]];
+            off[j] = mod_2pi(asum[j]);
+        }
+    }
+
+    // ---- frame controls: x0/a0 = frame t, x1/a1 = frame min(t + 1, T - 1); the raw values of the frame after that
+    // are requested one whole frame early (q_*), so their latency hides behind U samples of arithmetic.
+    //   hf(t, v) = (f0[t, s] * k) * (1 + shift[t, k])     inharm_synth.py:106-108
+    //   ha(t, v) = amp[t] * hd[t, k]                      inharm_synth.py:112
+    float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
+    float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
+    const bool has_shifts = p.shifts != nullptr;
+    auto frame_request = [&](int tt) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const size_t fr = (size_t)lrow[j] * T + tt;
+            q_amp[j] = p.amp[fr];
+            q_f0[j] = p.f0[fr * S + vs[j]];
+            q_sh[j] = has_shifts ? p.shifts[fr * H + vk[j]] : 0.0f;
+            q_hd[j] = p.hd[fr * H + vk[j]];
+        }
+    };
+    auto frame_finish = [&](float* xf, float* xa) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            float f = q_f0[j] * kmul[j];
+            if (has_shifts) f = f * (1.0f + q_sh[j]);
+            const float a = q_amp[j] * q_hd[j];
+            xf[j] = valid[j] ? f : 0.0f;
+            xa[j] = valid[j] ? a : 0.0f;
+        }
+    };
+    // per-frame classification (wave-uniform):
+    //   fast       every frequency of the frame pair is >= 0, either 0 or comfortably normal, and small enough that a
+    //              chunk's phase stays below 2^22 * 2 pi  -> the exact constant division (div_const) and the one-FMA
+    //              2 pi reduction are valid (ddspp_common.h)
+    //   const_freq x0 == x1 in every lane (a held note): fe == x0 exactly, omega is the per-frame constant om_c
+    //   need_mask  some oscillator crosses Nyquist inside the frame pair -> per-sample remove_above_nyquist
+    bool fast = false, const_freq = false, need_mask = true;
+    float om_c[VPL], da[VPL], am0[VPL];    // am0 / da: the frame pair's amplitudes as the blocks use them
+    const float f_big = 3900.0f * sr;              // 1008 samples of omega(f_big) stay below 2.6e7 rad
+    auto classify_frame = [&]() {
+        bool ok = true, msk = false, cst = true;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
+            ok = ok && (lo > 1e-28f || (lo == 0.0f && (hi == 0.0f || hi > 1e-24f))) && (hi < f_big);
+            // above Nyquist for the whole frame pair: masked once, here (a0 / a1 themselves stay as they are: the
+            // next pair starts from the unmasked a1)
+            const bool gone = lo >= nyq;
+            am0[j] = gone ? 0.0f : a0[j];
+            da[j] = gone ? 0.0f : a1[j] - a0[j];
+            msk = msk || (lo < nyq && hi >= nyq);
+            cst = cst && (x0[j] == x1[j]);
+            om_c[j] = omega_of<false>(x0[j], sr, rsr);
+        }
+        fast = __all(ok) && p.fastdiv;
+        need_mask = __any(msk);
+        const_freq = __all(cst);
+    };
+
+    int t = n_begin / U, r = n_begin - t * U;
+    frame_request(t);
+    frame_finish(x0, a0);
+    frame_request(min(t + 1, T - 1));
+    frame_finish(x1, a1);
+    frame_request(min(t + 2, T - 1));
+    classify_frame();
+
+    float* out_row = p.out + ((size_t)row * p.wmax + cw_all) * N;
+    int cpos = 0, tpos = 0, tile_n0 = n_begin;
+
+    const int abl = p.dbg_noflags >> 8;
+    auto flush_tile = [&](int nt0, int count) {
+        if (abl & 1) return;
+        // column sums: lane (col, half) adds 32 of the 64 lane partials of sample `col`
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int col = lane & 31, half = lane >> 5;
+        const float4* src = reinterpret_cast<const float4*>(tile + col * TSTRIDE + half * 32);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v tv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const f4v*>(src + i);
+        asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+        float4 s4 = make_float4(tv[0].x, tv[0].y, tv[0].z, tv[0].w);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            s4.x += tv[i].x; s4.y += tv[i].y; s4.z += tv[i].z; s4.w += tv[i].w;
+        }
+        float s = (s4.x + s4.y) + (s4.z + s4.w);
+        s += __shfl_xor(s, 32);
+        if (lane < count) out_row[nt0 + lane] = s;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // stages 2-4 of a block whose phases pv[i][j] (before the chunk offset) are known; MASK: per-sample Nyquist mask
+    auto finish_block = [&](float (*pv)[VPL], const float (*fe)[VPL], const float* w1, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stage 2: s = phase + offsets (the reference's float32 add), then s - q P with ONE multiple q of the
+        // reference's modulus P = float32(2 pi) per oscillator and block: q = rint(s_first / P).  The phase advances by
+        // less than pi per sample, so r = s - q P lies in [-pi, pi + 7 omega]; the FMA forms it from the exact
+        // product: no rounding while |r| < 16 (both terms are multiples of 2^-21), at most 2^-20 rad for the few
+        // partials near Nyquist late in a block.  v_cos_f32 takes revolutions and folds whole turns exactly, so
+        // cos(r / 2 pi) is cos(floormod(s, P)) to ~1e-6 rad -- two instructions per sample less than a per-sample q.
+        float q0[VPL];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) pv[i][j] = pv[i][j] + off[j];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) q0[j] = -__builtin_rintf(pv[0][j] * INV_P);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) pv[i][j] = __builtin_fmaf(q0[j], DDSPP_TWO_PI_F32, pv[i][j]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) pv[i][j] = pv[i][j] * INV_P;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stage 3: the cosines of the block in one run -------------------------------------------------------
+        if (!(abl & 4)) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) pv[i][j] = __builtin_amdgcn_cosf(pv[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stage 4: Hann cross-fade of the amplitudes (core.upsample_with_windows: a0 w[U + r] + a1 w[r] with
+        // w[U + r] + w[r] = 1 to an ulp = a0 + (a1 - a0) w[r]), Nyquist mask, harmonic sum over the lane's own -------
+        float acc[BLK];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+            float a = __builtin_fmaf(da[0], w1[i], am0[0]);
+            if (MASK) a = (fe[i][0] >= nyq) ? 0.0f : a;                    // remove_above_nyquist
+            acc[i] = a * pv[i][0];
+        }
+#pragma unroll
+        for (int j = 1; j < VPL; ++j)
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) {
+                float a = __builtin_fmaf(da[j], w1[i], am0[j]);
+                if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
+                acc[i] = __builtin_fmaf(a, pv[i][j], acc[i]);
+            }
+        if (abl & 2) {
+            float z = 0.f;
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) z += acc[i];
+            if (z == 12345.678f) tile[lane] = z;
+        } else {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) tile[(tpos + i) * TSTRIDE + lane] = acc[i];
+        }
+    };
+
+    // Hann cross-fade weights w[r + i] and bilinear weights wlin[n0 + i] of the block: scalar loads issued one block
+    // ahead (wave-uniform addresses -> s_load_dwordx8)
+    float w1[BLK], wl[BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) {
+        w1[i] = whann_c[r + i];
+        wl[i] = wlin_c[n_begin + i];
+    }
+
+    // Two loops: the outer one walks frames, the inner one the blocks of a frame.  The controls of frame t + 2 are
+    // requested when frame t starts and only touched when it ends: inside the inner loop nothing depends on them, so
+    // no wait for them (and no register shuffling of loop-carried copies) sits between two blocks.
+    for (int n0 = n_begin; n0 < n_end;) {
+    const int nf_end = min(n0 + (U - r), n_end);
+    for (; n0 < nf_end; n0 += BLK) {
+        float wnext[BLK], wlnext[BLK];
+        {
+            const int rn = (r + BLK == U) ? 0 : r + BLK;
+            const int nn = min(n0 + BLK, N - BLK);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) {
+                wnext[i] = whann_c[rn + i];
+                wlnext[i] = wlin_c[nn + i];
+            }
+        }
+        if (fast && const_freq) {
+            // ---- stage 1: the float32 phase scan (VPL sequential chains, interleaved) ---------------------------
+            float pv[BLK][VPL];
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    ph[j] = ph[j] + om_c[j];
+                    pv[i][j] = ph[j];
+                }
+            finish_block(pv, pv, w1, std::false_type{});
+        } else if (fast) {
+            float pv[BLK][VPL], fe[BLK][VPL], om[BLK][VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const float dx = x1[j] - x0[j];
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) fe[i][j] = x0[j] + dx * wl[i];          // legacy bilinear (core.resample)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) om[i][j] = omega_of<true>(fe[i][j], sr, rsr);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    ph[j] = ph[j] + om[i][j];
+                    pv[i][j] = ph[j];
+                }
+            if (need_mask) finish_block(pv, fe, w1, std::true_type{});
+            else finish_block(pv, fe, w1, std::false_type{});
+        } else {
+            // generic path (negative / denormal / huge frequencies, unchecked sample rates): IEEE division, fmod
+            // based floormod, one sample at a time -- correctness only
+#pragma unroll 1
+            for (int i = 0; i < BLK; ++i) {
+                const float wli = wlin_c[n0 + i], whi = whann_c[r + i];
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const float f = x0[j] + (x1[j] - x0[j]) * wli;
+                    ph[j] = ph[j] + omega_of<false>(f, sr, rsr);
+                    const float a = (f >= nyq) ? 0.0f : __builtin_fmaf(da[j], whi, am0[j]);
+                    acc = __builtin_fmaf(a, cos_reduced(mod_2pi(ph[j] + off[j])), acc);
+                }
+                tile[(tpos + i) * TSTRIDE + lane] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+            w1[i] = wnext[i];
+            wl[i] = wlnext[i];
+        }
+        // ---- tile bookkeeping ---------------------------------------------------------------------------------
+        tpos += BLK;
+        if (tpos == TILE || n0 + BLK >= n_end) {
+            flush_tile(tile_n0, tpos);
+            tile_n0 += tpos;
+            tpos = 0;
+        }
+        // ---- chunk boundary (ddsp.core.angular_cumsum) ---------------------------------------------------------
+        cpos += BLK;
+        if (cpos == DDSPP_CHUNK) {
+            cpos = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const float e = mod_2pi(ph[j]);      // phase[:, :, -1] % 2pi
+                asum[j] = asum[j] + e;               // cumsum over chunks (float32, sequential)
+                off[j] = mod_2pi(asum[j]);           // % 2pi
+                ph[j] = 0.0f;
+            }
+        }
+        r += BLK;
+    }
+    // ---- frame boundary ----------------------------------------------------------------------------------------
+    if (r == U) {
+        r = 0;
+        ++t;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            x0[j] = x1[j];
+            a0[j] = a1[j];
+        }
+        frame_finish(x1, a1);                        // raw values requested one frame ago
+        frame_request(min(t + 2, T - 1));
+        classify_frame();
+    }
+    }
+}
+
+// audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic); with split_last the last
+// voice's slots go to audio_last and the others' to audio
+__global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restrict__ partial, const int* __restrict__ wcount,
+                                                          float* __restrict__ out, float* __restrict__ out_last, int B,
+                                                          int N, int wmax, int wmax_a, int spans, int cps) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)B * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
+        const int span = min((4 * i) / (cps * DDSPP_CHUNK), spans - 1);
+        const int wa = wcount[((size_t)b * spans + span) * 2], wb = wcount[((size_t)b * spans + span) * 2 + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accb = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < wa; ++w) {
+            const float4 v = reinterpret_cast<const float4*>(partial + ((size_t)b * wmax + w) * N)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        for (int w = 0; w < wb; ++w) {
+            const float4 v = reinterpret_cast<const float4*>(partial + ((size_t)b * wmax + wmax_a + w) * N)[i];
+            accb.x += v.x; accb.y += v.y; accb.z += v.z; accb.w += v.w;
+        }
+        if (out_last) {
+            reinterpret_cast<float4*>(out_last + (size_t)b * N)[i] = accb;
+        } else {
+            acc.x += accb.x; acc.y += accb.y; acc.z += accb.z; acc.w += accb.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)b * N)[i] = acc;
+    }
+}
+
+}  // namespace
+
+void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
+    const size_t lds = (size_t)(TILE * TSTRIDE) * sizeof(float);
+    const dim3 grid((unsigned)((size_t)p.R * p.spans * p.wmax)), blk(64);
+    if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1>), grid, blk, lds, stream, p);
+    else hipLaunchKernelGGL((bank_compact_kernel<2>), grid, blk, lds, stream, p);
+}
+
+void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, hipStream_t stream) {
+    size_t blocks = ((size_t)p.R * (p.N / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bank_slot_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.out, p.wcount, audio, audio_last,
+                       p.R, p.N, p.wmax, p.wmax_a, p.spans, p.cps);
+}
+
+}  // namespace ddspp

@@ -168,13 +168,16 @@ __global__ void __launch_bounds__(256) add_signals_kernel(const float* const* __
 __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __restrict__ additive,
                                                            const float* __restrict__ noise,
                                                            float* __restrict__ out, int B, int P,
-                                                           int N, int out_stride, int voice_major) {
+                                                           int N, int out_stride, int voice_major,
+                                                           float* __restrict__ out_prev) {
     const int n4 = N / 4;
     const size_t total = (size_t)B * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int v = 0; v < P; ++v) {
+            // the running mix the last `add` node receives as its first operand (its controls' signal_0)
+            if (out_prev && v == P - 1) reinterpret_cast<float4*>(out_prev + (size_t)b * N)[i] = acc;
             const size_t off = (voice_major ? (size_t)v * B + b : (size_t)b * P + v) * n4 + i;
             if (noise) {
                 const float4 z = reinterpret_cast<const float4*>(noise)[off];
@@ -191,10 +194,13 @@ __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __rest
 
 // out[b, n] = sum_v a[b, v, n] (PA rows) + sum_v z[b, v, n] (PZ rows): the add chain when one operand is
 // already a per-segment mix
+// tail_z / tail_a / out_prev (all or none): out_prev = the sum above, out = (out_prev + tail_z) + tail_a -- the last step
+// of the add chain of polyphonic_dag.py:34-37 with its three operands kept apart
 __global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict__ a, int PA,
                                                        const float* __restrict__ z, int PZ,
                                                        float* __restrict__ out, int B, int N, int out_stride,
-                                                       int voice_major) {
+                                                       int voice_major, const float* __restrict__ tail_z,
+                                                       const float* __restrict__ tail_a, float* __restrict__ out_prev) {
     const int n4 = N / 4;
     const size_t total = (size_t)B * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
@@ -207,6 +213,13 @@ __global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict
         for (int v = 0; v < PA; ++v) {
             const float4 t = reinterpret_cast<const float4*>(a)[(voice_major ? (size_t)v * B + b : (size_t)b * PA + v) * n4 + i];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (out_prev) {
+            reinterpret_cast<float4*>(out_prev + (size_t)b * N)[i] = acc;
+            const float4 tz = reinterpret_cast<const float4*>(tail_z + (size_t)b * N)[i];
+            const float4 ta = reinterpret_cast<const float4*>(tail_a + (size_t)b * N)[i];
+            acc.x = (acc.x + tz.x) + ta.x; acc.y = (acc.y + tz.y) + ta.y;
+            acc.z = (acc.z + tz.z) + ta.z; acc.w = (acc.w + tz.w) + ta.w;
         }
         reinterpret_cast<float4*>(out + (size_t)b * out_stride)[i] = acc;
     }
@@ -294,13 +307,13 @@ int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, 
 // [B, P, N] (voice_major = 0) or [P, B, N] (voice_major = 1, the layout the reference's Parallelizer
 // leaves the merged controls in, sub_modules.py:573-592); out rows are written with a stride (so the
 // dry mix can land in a zero-padded FFT buffer of the reverb).  noise may be null (dry additive only).
-int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
+int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, float* out_prev, int B, int P, int N,
                          int out_stride, int voice_major, hipStream_t stream) {
     DDSPP_REQUIRE(additive && out, "polyphonic_mix: null buffer");
     DDSPP_REQUIRE(B > 0 && P > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N,
                   "polyphonic_mix: bad dims");
     hipLaunchKernelGGL(polyphonic_mix_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
-                       additive, noise, out, B, P, N, out_stride, voice_major);
+                       additive, noise, out, B, P, N, out_stride, voice_major, out_prev);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
@@ -312,7 +325,22 @@ int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out,
                   "mix_voices: bad arguments");
     DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N, "mix_voices: bad dims");
     hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
-                       out, B, N, out_stride, voice_major);
+                       out, B, N, out_stride, voice_major, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The end of the add chain with the last voice kept apart (what the reference's outputs dictionary holds for the
+// re-used processors, polyphonic_dag.py:34-37): prev[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] (the other
+// voices), dry[b] = (prev[b] + noise_last[b]) + additive_last[b].  All outputs [B, N].
+int ddspp_mix_last_voice(const float* a, int PA, const float* z, int PZ, const float* noise_last,
+                         const float* additive_last, float* prev, float* dry, int B, int N, int voice_major,
+                         hipStream_t stream) {
+    DDSPP_REQUIRE(prev && dry && noise_last && additive_last && (a || PA == 0) && (z || PZ == 0) && PA >= 0 && PZ >= 0,
+                  "mix_last_voice: bad arguments");
+    DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0, "mix_last_voice: bad dims");
+    hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
+                       dry, B, N, N, voice_major, noise_last, additive_last, prev);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -474,6 +474,7 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                        const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
                        const float* __restrict__ tap_wo,     // [NJ, 4]
                        float* __restrict__ out,              // [R / vq, N]
+                       float* __restrict__ out_last,         // [R / n_voices, N] the last voice of every segment on its own (vq > 1), or null
                        int R, int N, int T, int U, int Lw, int NJ, int delay, int windows_per_row, int padl,
                        int nb, int seglen, int dc, float bias, ScaleFn scale, int vq, int n_voices, int vmajor) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -664,9 +665,16 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                 quad[k] = keep + __shfl_xor(send, 4);
             }
             const int n = np0 + FIR_OPL * a + 4 * sg;
+            // out_last: the segment's last voice (the last unit of its last output row) leaves on its own and stays out
+            // of the sum -- the outputs dictionary of the reference's DAG holds that voice's noise next to the mix
+            const int orow = task / windows_per_row;
+            const bool lastv = out_last != nullptr && iv == vq - 1 && (orow % pq) == pq - 1;
             if (iv == 0) vsum = make_float4(quad[0], quad[1], quad[2], quad[3]);
-            else { vsum.x += quad[0]; vsum.y += quad[1]; vsum.z += quad[2]; vsum.w += quad[3]; }
-            if (iv == vq - 1 && n < N) *reinterpret_cast<float4*>(out + (size_t)(task / windows_per_row) * N + n) = vsum;
+            else if (!lastv) { vsum.x += quad[0]; vsum.y += quad[1]; vsum.z += quad[2]; vsum.w += quad[3]; }
+            if (iv == vq - 1 && n < N) {
+                *reinterpret_cast<float4*>(out + (size_t)orow * N + n) = vsum;
+                if (lastv) *reinterpret_cast<float4*>(out_last + (size_t)(orow / pq) * N + n) = make_float4(quad[0], quad[1], quad[2], quad[3]);
+            }
         }
         __syncthreads();                 // LDS is rewritten by the next window
     }
@@ -904,7 +912,8 @@ int ddspp_frequency_filter_eo_supported(int N, int T, int K, int Lw, int delay_c
 }
 
 static int launch_fused_noise(const float* audio, const float* magnitudes, const float* CE, const float* CO,
-                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, int R, int N,
+                              const int* tap_idx, const float* tap_we, const float* tap_wo, float* out, float* out_last,
+                              int R, int N,
                               int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind, float bias,
                               float exponent, float max_value, float threshold, float gain, int vq, int n_voices,
                               int voice_major, hipStream_t stream) {
@@ -914,6 +923,8 @@ static int launch_fused_noise(const float* audio, const float* magnitudes, const
     DDSPP_REQUIRE(scale_kind >= -1 && scale_kind <= 2, "frequency_filter_eo: unknown scale_fn %d", scale_kind);
     DDSPP_REQUIRE(vq >= 1 && n_voices >= 1 && n_voices % vq == 0 && R % n_voices == 0,
                   "frequency_filter_eo: %d voices per output row do not divide %d voices / %d rows", vq, n_voices, R);
+    DDSPP_REQUIRE(!out_last || (vq > 1 && (uintptr_t)out_last % 16 == 0),
+                  "frequency_filter_eo: out_last needs voices_per_row > 1 and a 16-byte aligned buffer");
     FusedGeom g;
     DDSPP_REQUIRE(fused_geometry(N, T, K, Lw, delay_compensation, &g) && NJ == K / 2,
                   "frequency_filter_eo: shape not supported (N=%d T=%d K=%d Lw=%d)", N, T, K, Lw);
@@ -929,7 +940,7 @@ static int launch_fused_noise(const float* audio, const float* magnitudes, const
     const ScaleFn sf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
 #define DDSPP_FUSED_LAUNCH(KH, JT)                                                                              \
     hipLaunchKernelGGL((noise_fir_fused_kernel<KH, JT>), grid, block, lds, stream, audio, magnitudes, CE, CO,    \
-                       tap_idx, tap_we, tap_wo, out, R, N, T, g.U, Lw, NJ, g.delay, g.wpr, g.padl, g.nb,         \
+                       tap_idx, tap_we, tap_wo, out, out_last, R, N, T, g.U, Lw, NJ, g.delay, g.wpr, g.padl, g.nb, \
                        g.seglen, g.dc, bias, sf, vq, n_voices, voice_major)
     if (K == 32) DDSPP_FUSED_LAUNCH(16, 1);
     else if (K == 64) DDSPP_FUSED_LAUNCH(32, 2);
@@ -946,7 +957,7 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
                               int N, int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind,
                               float bias, float exponent, float max_value, float threshold, float gain,
                               hipStream_t stream) {
-    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, R, N, T, K, Lw, NJ,
+    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, nullptr, R, N, T, K, Lw, NJ,
                               delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain, 1, 1, 0,
                               stream);
 }
@@ -954,13 +965,15 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
 // The same for the rows of a polyphonic group (rows = n_segments x n_voices, segment major or voice major), with the
 // filtered noise of `voices_per_row` consecutive voices summed into one output row: out[R / voices_per_row, N],
 // out[b, q] = sum_i filtered(voice q * voices_per_row + i of segment b).  Feeds ddspp_mix_voices.
+// out_last (may be null) [R / n_voices, N]: the last voice of every segment goes there instead of into its row's sum.
 int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes, const float* CE, const float* CO,
                                      const int* tap_idx, const float* tap_we, const float* tap_wo, float* out,
+                                     float* out_last,
                                      int R, int N, int T, int K, int Lw, int NJ, int delay_compensation,
                                      int scale_kind, float bias, float exponent, float max_value, float threshold,
                                      float gain, int n_voices, int voices_per_row, int voice_major,
                                      hipStream_t stream) {
-    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, R, N, T, K, Lw, NJ,
+    return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, K, Lw, NJ,
                               delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain,
                               voices_per_row, n_voices, voice_major, stream);
 }

@@ -1,0 +1,59 @@
+// Shared by the oscillator-bank translation units (oscillator.hip, bank_compact.hip).
+#pragma once
+#include "ddspp_common.h"
+
+namespace ddspp {
+
+struct OscParams {
+    // materialised source: cos_oscillator_bank(frequency_envelopes, amplitude_envelopes)
+    const float* __restrict__ fe;      // [R, N, H]
+    const float* __restrict__ ae;      // [R, N, H]
+    // fused source: frame-rate controls of harmonic_synthesis / MultiInharmonic.get_signal
+    const float* __restrict__ f0;      // [R, T, S]
+    const float* __restrict__ amp;     // [R, T]
+    const float* __restrict__ hd;      // [R, T, H]
+    const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts)
+    const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
+    int dbg_noflags;                   // DDSPP_OSC_NO_FLAGS=1: ignore bit 16 of audible, stream the controls instead (A/B switch)
+    const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
+    const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)
+    float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
+    float* __restrict__ ework;         // [R, npre, VP]  chunk end phase mod 2pi
+    const float* __restrict__ astart;  // [R, spans, VP] running offset sum at span start
+    float* __restrict__ partial;       // [R, groups, N] per-group audio when groups > 1
+    int R, N, T, U, H, S, V, VP;
+    int groups, vgrp;                  // oscillators of a row are split over `groups` wavefronts
+    int spans, cps, nchunks, npre;
+    float sr, rsr, nyq;
+    int fastdiv;                       // sample rate is in the exhaustively checked list
+    // compacted polyphonic mode (osc_kernel<1, true, MODE_MAIN, true, true>): R = segments, each with
+    // P voices; only oscillators with a non-zero amplitude somewhere in the span are given a lane
+    const int* __restrict__ nk;        // [B, spans, P] audible harmonics per voice and span
+    int* __restrict__ wcount;          // [B, spans]    wavefronts that actually produced a partial row
+    int P, wmax, nslots;               // voices per segment, partial rows per segment, workgroups per (segment, span)
+    int vmajor;                        // compact mode: rows are [P, B] (voice major) instead of [B, P]
+    // compacted bank (bank_compact.hip): slots [0, wmax_a) carry the audible oscillators of voices [0, P - split_last),
+    // slots [wmax_a, wmax) those of the last voice (split_last = 1: the caller wants that voice's stem on its own)
+    int split_last, wmax_a;
+    float* __restrict__ out_last;      // [B, N] the last voice's stem (split_last = 1), `out` then holds the other voices' sum
+};
+
+enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
+
+constexpr int BLK = 8;        // samples per unrolled block; divides U and the 1000-sample chunk
+constexpr int TILE = 32;      // samples per LDS reduction tile
+constexpr int TSTRIDE = 68;   // words per tile row: 16-byte aligned rows, 17 quads apart -> ds_read_b128 conflict free
+
+template <bool FAST>
+__device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
+    float om = fe * DDSPP_TWO_PI_F32;             // inharm_synth.py:69
+    if (FAST) return div_const(om, sr, rsr);      // inharm_synth.py:70, exact (see ddspp_common.h)
+    return om / sr;
+}
+
+
+// compacted polyphonic bank: launches of bank_compact.hip (p.out = partial rows, see ddspp_polyphonic_additive)
+void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream);
+void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, hipStream_t stream);
+
+}  // namespace ddspp

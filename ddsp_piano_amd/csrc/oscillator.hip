@@ -23,52 +23,9 @@
 //   read exactly once) is the HBM-roofline configuration.
 #include <type_traits>
 
-#include "ddspp_common.h"
+#include "osc_common.h"
 
 namespace ddspp {
-
-struct OscParams {
-    // materialised source: cos_oscillator_bank(frequency_envelopes, amplitude_envelopes)
-    const float* __restrict__ fe;      // [R, N, H]
-    const float* __restrict__ ae;      // [R, N, H]
-    // fused source: frame-rate controls of harmonic_synthesis / MultiInharmonic.get_signal
-    const float* __restrict__ f0;      // [R, T, S]
-    const float* __restrict__ amp;     // [R, T]
-    const float* __restrict__ hd;      // [R, T, H]
-    const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts)
-    const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
-    int dbg_noflags;                   // DDSPP_OSC_NO_FLAGS=1: ignore bit 16 of audible, stream the controls instead (A/B switch)
-    const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
-    const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)
-    float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
-    float* __restrict__ ework;         // [R, npre, VP]  chunk end phase mod 2pi
-    const float* __restrict__ astart;  // [R, spans, VP] running offset sum at span start
-    float* __restrict__ partial;       // [R, groups, N] per-group audio when groups > 1
-    int R, N, T, U, H, S, V, VP;
-    int groups, vgrp;                  // oscillators of a row are split over `groups` wavefronts
-    int spans, cps, nchunks, npre;
-    float sr, rsr, nyq;
-    int fastdiv;                       // sample rate is in the exhaustively checked list
-    // compacted polyphonic mode (osc_kernel<1, true, MODE_MAIN, true, true>): R = segments, each with
-    // P voices; only oscillators with a non-zero amplitude somewhere in the span are given a lane
-    const int* __restrict__ nk;        // [B, spans, P] audible harmonics per voice and span
-    int* __restrict__ wcount;          // [B, spans]    wavefronts that actually produced a partial row
-    int P, wmax, nslots;               // voices per segment, partial rows per segment, workgroups per (segment, span)
-    int vmajor;                        // compact mode: rows are [P, B] (voice major) instead of [B, P]
-};
-
-enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
-
-constexpr int BLK = 8;        // samples per unrolled block; divides U and the 1000-sample chunk
-constexpr int TILE = 32;      // samples per LDS reduction tile
-constexpr int TSTRIDE = 68;   // words per tile row: 16-byte aligned rows, 17 quads apart -> ds_read_b128 conflict free
-
-template <bool FAST>
-__device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
-    float om = fe * DDSPP_TWO_PI_F32;             // inharm_synth.py:69
-    if (FAST) return div_const(om, sr, rsr);      // inharm_synth.py:70, exact (see ddspp_common.h)
-    return om / sr;
-}
 
 template <int VPL, bool FUSED, int MODE, bool SUM, bool COMPACT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? 4 : 1, COMPACT ? 4 : 8)))
@@ -215,6 +172,7 @@ osc_kernel(const OscParams p) {
     // x0/a0 = frame t, x1/a1 = frame min(t + 1, T - 1); the raw values of the frame after that are
     // requested one whole frame early (q_*), so their HBM/L2 latency hides behind 96 samples of work.
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
+    float a1_raw[VPL];                 // frame t + 1's amplitude before classify_frame's whole-pair Nyquist mask: the NEXT pair starts from it
     float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
     int t = 0, r = 0;
     auto frame_request = [&](int tt) {
@@ -281,6 +239,8 @@ osc_kernel(const OscParams p) {
         frame_finish(x0, a0);
         frame_request(min(t + 1, T - 1));
         frame_finish(x1, a1);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) a1_raw[j] = a1[j];
         frame_request(min(t + 2, T - 1));
         classify_frame();
     }
@@ -529,9 +489,11 @@ osc_kernel(const OscParams p) {
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     x0[j] = x1[j];
-                    a0[j] = a1[j];
+                    a0[j] = a1_raw[j];
                 }
                 frame_finish(x1, a1);                       // raw values requested one frame ago
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) a1_raw[j] = a1[j];
                 frame_request(min(t + 2, T - 1));
                 classify_frame();
             }
@@ -566,11 +528,19 @@ osc_kernel(const OscParams p) {
 // re-used for every later chunk with the same frequencies; only chunks with moving frequencies are
 // scanned sample by sample.  Output: astart[row, span, v] = e[0] + ... + e[c0(span) - 1] accumulated
 // sequentially in float32 -- exactly what the pre-pass + offset-scan kernels produce.
-template <int VPL>
+//
+// PARTS > 1: the PARTS wavefronts of a workgroup share one (row, group); each walks a contiguous run of the chunks (its
+// own memo, its own change detector started at its first frame), leaves the end phases e[c] in LDS, and wavefront 0
+// adds them up in chunk order -- the same float32 sums in the same order.  A row whose frequencies move in every
+// frame (vibrato, glides) costs 72 sample-by-sample chunk scans: one wavefront took 10 ms for them at batch 64, four
+// at twice the occupancy take 0.3 ms; rows of held notes cost what they did (one memoised scan per wavefront).
+template <int VPL, int PARTS>
 __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
     const int lane = threadIdx.x & 63;
-    const int task = wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (task >= p.R * p.groups) return;
+    const int part = wave_uniform(threadIdx.x >> 6);
+    const int task = PARTS > 1 ? (int)blockIdx.x : wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (PARTS == 1 && task >= p.R * p.groups) return;
     const int row = task / p.groups, grp = task - row * p.groups;
     const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
     const int vbase = grp * p.vgrp, vlast = min(vbase + p.vgrp, p.V) - 1;
@@ -660,7 +630,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         t_checked = max(t_checked, t_need);
     };
     auto check_upto = [&](int t_need) {
-        if (p.audible && !p.dbg_noflags) {
+        if (p.audible && !(p.dbg_noflags & 1)) {
             flagged_upto(t_need);
             return;
         }
@@ -692,7 +662,19 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         e_memo[j] = 0.0f;
     }
     int memo_t = -1;                   // first frame of the chunk the memo was taken from (-1: none)
-    for (int c = 0; c <= p.npre; ++c) {
+    // this wavefront's run of chunks
+    const int per_part = (p.npre + PARTS - 1) / PARTS;
+    const int c_begin = PARTS > 1 ? min(part * per_part, p.npre) : 0;
+    const int c_end = PARTS > 1 ? min(c_begin + per_part, p.npre) : p.npre;
+    if (PARTS > 1 && c_begin > 0) {    // the change detector starts at this run's first frame
+        const int t0 = (c_begin * DDSPP_CHUNK) / U;
+        t_checked = t0;
+        last_change = t0;
+        fl_base = t0 + 1;
+        fl_before = t0;
+        hf_of(t0, x_prev);
+    }
+    auto emit_start = [&](int c) {     // astart of the span that begins at chunk c (if one does)
         if (c % p.cps == 0) {
             const int span = c / p.cps;
             if (span < p.spans) {
@@ -701,7 +683,10 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                     p.ework[((size_t)row * p.spans + span) * p.VP + vidx[j]] = asum[j];   // = astart
             }
         }
-        if (c == p.npre) break;
+    };
+    for (int c = c_begin; c <= c_end; ++c) {
+        if (PARTS == 1) emit_start(c);
+        if (c == c_end) break;
         const int n_lo = c * DDSPP_CHUNK, n_hi = min(n_lo + DDSPP_CHUNK, N);
         const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
         check_upto(t_hi);
@@ -719,9 +704,11 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                 om[j] = omega_of<false>(xa[j], p.sr, p.rsr);
                 ph[j] = 0.0f;
             }
-            for (int n = n_lo; n < n_hi; ++n) {
+            for (int n = n_lo; n < n_hi; n += BLK) {          // chunk lengths are multiples of BLK (U and 1000 are)
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) ph[j] = ph[j] + om[j];
+                for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) ph[j] = ph[j] + om[j];
             }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
@@ -730,32 +717,83 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
             }
             memo_t = (n_hi - n_lo == DDSPP_CHUNK) ? t_lo : -1;     // a short last chunk is no memo
         } else {
-            float ph[VPL], x0[VPL], x1[VPL];
+            // moving frequencies: sample by sample, BLK samples per step (one scalar load of their interpolation
+            // weights, requested a step ahead; a step never straddles a frame: U % BLK == 0), the raw controls of the
+            // frame after next requested a frame ahead, and the exact constant division when every frequency of the
+            // frame pair is in its checked range (same test as the main kernel's classify_frame)
+            float ph[VPL], x0[VPL], x1[VPL], qf[VPL], qs[VPL];
 #pragma unroll
             for (int j = 0; j < VPL; ++j) ph[j] = 0.0f;
             int tt = t_lo, r = n_lo - t_lo * U;
             hf_of(tt, x0);
             hf_of(min(tt + 1, T - 1), x1);
-            for (int n = n_lo; n < n_hi; ++n) {
-                const float wl = wlin_c[n];
+            hf_raw(min(tt + 2, T - 1), qf, qs);
+            auto pair_ok = [&]() {
+                bool ok = true;
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
-                    const float fe = x0[j] + (x1[j] - x0[j]) * wl;
-                    ph[j] = ph[j] + omega_of<false>(fe, p.sr, p.rsr);
+                    const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
+                    ok = ok && (lo > 1e-28f || (lo == 0.0f && (hi == 0.0f || hi > 1e-24f))) && (hi < 3.0e38f);
                 }
-                if (++r == U) {
+                return p.fastdiv && __all(ok);
+            };
+            bool fast = pair_ok();
+            float wl[BLK], wn[BLK];
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n_lo + i];
+            for (int n = n_lo; n < n_hi; n += BLK) {
+                const int nn = min(n + BLK, N - BLK);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) wn[i] = wlin_c[nn + i];
+                if (fast) {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const float dx = x1[j] - x0[j];
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) ph[j] = ph[j] + omega_of<true>(x0[j] + dx * wl[i], p.sr, p.rsr);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const float dx = x1[j] - x0[j];
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) ph[j] = ph[j] + omega_of<false>(x0[j] + dx * wl[i], p.sr, p.rsr);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
+                r += BLK;
+                if (r == U) {
                     r = 0;
                     ++tt;
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) x0[j] = x1[j];
-                    hf_of(min(tt + 1, T - 1), x1);
+                    hf_calc(qf, qs, x1);
+                    hf_raw(min(tt + 2, T - 1), qf, qs);
+                    fast = pair_ok();
                 }
             }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) e[j] = mod_2pi(ph[j]);
         }
+        if (PARTS == 1) {
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + e[j];
+            for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + e[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) lds_dyn[((size_t)c * VPL + j) * 64 + lane] = e[j];
+        }
+    }
+    if (PARTS > 1) {
+        __syncthreads();
+        if (part == 0) {
+            for (int c = 0; c <= p.npre; ++c) {
+                emit_start(c);
+                if (c == p.npre) break;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + lds_dyn[((size_t)c * VPL + j) * 64 + lane];
+            }
+        }
     }
 }
 
@@ -1021,26 +1059,6 @@ __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __rest
     nk[((size_t)b * spans + span) * P + v] = best;
 }
 
-// audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic)
-__global__ void __launch_bounds__(256) osc_partial_sum_kernel(const float* __restrict__ partial,
-                                                            const int* __restrict__ wcount,
-                                                            float* __restrict__ out, int B, int N, int wmax,
-                                                            int spans, int cps) {
-    const int n4 = N / 4;
-    const size_t total = (size_t)B * n4;
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
-        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
-        const int span = min((4 * i) / (cps * DDSPP_CHUNK), spans - 1);
-        const int wc = wcount[(size_t)b * spans + span];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int w = 0; w < wc; ++w) {
-            const float4 v = reinterpret_cast<const float4*>(partial + ((size_t)b * wmax + w) * N)[i];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        reinterpret_cast<float4*>(out + (size_t)b * N)[i] = acc;
-    }
-}
-
 static bool sample_rate_is_checked(float sr) {
     // rates for which div_const == IEEE division was verified for every float32 input with
     // |x| >= 1e-28 (tests/test_exact_arith.py builds and runs the checker)
@@ -1133,6 +1151,27 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
     return pl;
 }
 
+// Launch of the memoised pre-pass: `tasks` (row, group) pairs.  Four wavefronts per pair (PARTS = 4) whenever the
+// chunk end phases of a row fit in LDS; one wavefront per pair otherwise (very long rows).
+static void launch_memo_prepass(int vpl, const OscParams& q, int tasks, hipStream_t stream) {
+    const size_t lds4 = (size_t)q.npre * vpl * 64 * sizeof(float);
+    const bool parts4 = vpl <= 2 && q.npre >= 8 && lds4 <= 64 * 1024 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
+    if (parts4) {
+        if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks), dim3(256), lds4, stream, q);
+        else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks), dim3(256), lds4, stream, q);
+        return;
+    }
+    const dim3 grid((tasks + 3) / 4), blk(256);
+    switch (vpl) {
+        case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 1>), grid, blk, 0, stream, q); break;
+        case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 1>), grid, blk, 0, stream, q); break;
+        case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3, 1>), grid, blk, 0, stream, q); break;
+        case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4, 1>), grid, blk, 0, stream, q); break;
+        case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6, 1>), grid, blk, 0, stream, q); break;
+        default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8, 1>), grid, blk, 0, stream, q); break;
+    }
+}
+
 template <int VPL, bool FUSED>
 static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t stream) {
     const int nblk_main = p.R * p.spans;
@@ -1147,8 +1186,7 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
         if (p.spans > 1 && memo) {
             OscParams q = p;
             q.ework = const_cast<float*>(p.astart);      // the memo pre-pass writes astart directly
-            const int tasks = p.R * p.groups;
-            hipLaunchKernelGGL((osc_prepass_fused_kernel<VPL>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q);
+            launch_memo_prepass(VPL, q, p.R * p.groups, stream);
         } else if (p.spans > 1) {
             const int nblk_pre = p.R * p.npre;
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), blk, lds,
@@ -1296,15 +1334,15 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
     const size_t N = (size_t)T * U;
     const size_t nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     const size_t V = (size_t)S * H, VP = (V + 63) / 64 * 64 + 64;
-    const size_t wmax = (P * V + 63) / 64;
+    const size_t wmax = (P * V + 63) / 64 + 1;        /* + 1: the last voice's slots start on a slot boundary */
     return (2 * (size_t)B * P * nchunks * VP      /* astart + chunk end phases (worst case: one span per chunk) */
-            + (size_t)B * nchunks * (P + 1)       /* nk + wcount */
+            + (size_t)B * nchunks * (P + 2)       /* nk + wcount */
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const int* audible, const float* wlin,
-                              const float* whann, float* audio,
+                              const float* whann, float* audio, float* audio_last,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
@@ -1330,19 +1368,22 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     // A wavefront slot carries 128 audible oscillators (2 per lane); when that leaves the chip short of wavefronts
     // (single segments: B * spans * slots < ~2 per SIMD) it carries 64, twice the wavefronts at half the length.
     const int vpl_c = ((long long)B * sp * ((P * V + 127) / 128) < env_int("DDSPP_OSC_COMPACT_VPL1_BELOW", 2048)) ? 1 : 2;
-    const int wmax = (P * V + 64 * vpl_c - 1) / (64 * vpl_c);      // partial rows (wavefront slots) per segment
+    // partial rows (wavefront slots) per segment: with audio_last the last voice's oscillators get slots of their own
+    const int split_last = (audio_last && P > 1) ? 1 : 0;
+    const int wmax_a = ((P - split_last) * V + 64 * vpl_c - 1) / (64 * vpl_c);
+    const int wmax = wmax_a + (split_last ? (V + 64 * vpl_c - 1) / (64 * vpl_c) : 0);
 
     float* astart = (float*)workspace;
     float* ework = astart + (size_t)R * sp * VP;           // chunk end phases (chunk-parallel pre-pass only)
     int* nk = (int*)(ework + (size_t)R * nchunks * VP);
     int* wcount = nk + (size_t)B * sp * P;
-    float* partial = (float*)(wcount + (size_t)B * sp);
+    float* partial = (float*)(wcount + (size_t)B * sp * 2);
     partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
 
     OscParams p{};
     p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
     p.audible = audible;
-    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
+    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0) | (env_int("DDSPP_BANK_ABLATE", 0) << 8);
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
     p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;
@@ -1366,14 +1407,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
                 q.groups = V / 64;
                 q.vgrp = 64;
             }
-            switch (split ? 1 : vpl_pre) {
-                case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-                case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-                case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-                case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-                case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-                default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8>), dim3((tasks + 3) / 4), dim3(256), 0, stream, q); break;
-            }
+            launch_memo_prepass(split ? 1 : vpl_pre, q, tasks, stream);
         } else {
             q.ework = ework;
             const bool chunk_kernel = vpl_pre <= 2 && DDSPP_CHUNK / U + 3 <= PRE_FR && !env_int("DDSPP_OSC_OLD_CHUNK_PREPASS", 0);
@@ -1403,30 +1437,20 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     else
         hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
                            harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
-    // 3. the compacted oscillator bank: one wavefront per (segment, span, slot of 64 audible oscillators)
-    // wavefront slots launched per (segment, span): slot cw takes the cw-th block of 128 audible oscillators (and
-    // cw + nslots, ... when fewer slots than wmax are launched); a piano has about a third of its P * H partials
-    // below Nyquist, the slots past the audible set exit at once (cheap: slot-group-major workgroup order)
-    int nslots = env_int("DDSPP_OSC_COMPACT_SLOTS", wmax);
-    // wavefront slots per workgroup: slots past the audible set exit at once, but their workgroup keeps its LDS until
-    // its busy slots are done, which left ~5 of 16 wavefront places per CU idle with four-slot workgroups
-    // (batch 64: 2.51 ms per step with 4, 2.41 with 2, 2.36-2.41 with 1)
-    int wpw = env_int("DDSPP_OSC_COMPACT_WPW", 1);
-    if (wpw != 1 && wpw != 2 && wpw != 4) wpw = 1;
-    nslots = (nslots + wpw - 1) / wpw * wpw;
-    if (nslots < wpw) nslots = wpw;
-    p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = nslots; p.vmajor = voice_major ? 1 : 0;
+    // 3. the compacted oscillator bank (bank_compact.hip): one wavefront per (segment, span, slot of 64 * vpl audible
+    //    oscillators); a piano has about a third of its P * H partials below Nyquist, the slots past the audible set
+    //    exit at once (cheap: slot-major workgroup order)
+    p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = wmax; p.vmajor = voice_major ? 1 : 0;
+    p.split_last = split_last; p.wmax_a = wmax_a;
     p.nk = nk; p.wcount = wcount; p.out = partial;
-    const size_t lds = ((size_t)wpw * (TILE * TSTRIDE) + 2 * 32) * sizeof(float);
-    if (vpl_c == 1)
-        hipLaunchKernelGGL((osc_kernel<1, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / wpw))), dim3(64 * wpw),
-                           lds, stream, p);
-    else
-        hipLaunchKernelGGL((osc_kernel<2, true, MODE_MAIN, true, true>), dim3((unsigned)(B * sp * (nslots / wpw))), dim3(64 * wpw),
-                           lds, stream, p);
-    // 4. slots -> audio
-    hipLaunchKernelGGL(osc_partial_sum_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
-                       partial, wcount, audio, B, N, wmax, sp, cps);
+    launch_bank_compact(p, vpl_c, stream);
+    // 4. slots -> audio (with audio_last: voices [0, P - 1) -> audio, the last voice -> audio_last)
+    if (audio_last && !split_last) {           // P == 1: the only voice is the last one
+        launch_bank_slot_sum(p, audio_last, nullptr, stream);
+        DDSPP_HIP_CHECK(hipMemsetAsync(audio, 0, (size_t)B * N * sizeof(float), stream));
+    } else {
+        launch_bank_slot_sum(p, audio, split_last ? audio_last : nullptr, stream);
+    }
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

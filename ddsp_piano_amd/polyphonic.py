@@ -201,23 +201,18 @@ def run(plan, inputs, noise=None, need_stems=True):
             noise = noise_p.draw_noise(R, N, dev)
         else:
             noise = noise_rows(noise, B, P, N, vm)
+        m_src = mags if fuse_scale else nctl['magnitudes']
+        rs = noise_p.raw_scale() if fuse_scale else None
         if voice_sums > 1:
-            # audio only: the filtered noise of four voices leaves the kernel as one row (a quarter of the round trip)
-            sig = core.frequency_filter_voice_sums(noise, mags if fuse_scale else nctl['magnitudes'],
-                                                   noise_p.window_size, noise_p.raw_scale() if fuse_scale else None,
-                                                   P, voice_sums, vm)
-            if sig is not None:
-                if want_last:          # the last voice's own stem: one more B-row pass over the same noise rows
-                    rows_last = (noise.reshape(P, B, N)[P - 1] if vm else noise.reshape(B, P, N)[:, P - 1]).contiguous()
-                    m_src = mags if fuse_scale else nctl['magnitudes']
-                    m_last = (m_src.reshape(P, B, T, K)[P - 1] if vm else m_src.reshape(B, P, T, K)[:, P - 1]).contiguous()
-                    last_stem['noise'] = core.frequency_filter(rows_last, m_last, window_size=noise_p.window_size,
-                                                               raw_scale=noise_p.raw_scale() if fuse_scale else None)
-                return nctl, sig, voice_sums
-        if fuse_scale:
-            sig = core.frequency_filter(noise, mags, window_size=noise_p.window_size, raw_scale=noise_p.raw_scale())
-        else:
-            sig = core.frequency_filter(noise, nctl['magnitudes'], window_size=noise_p.window_size)
+            # the filtered noise of several voices leaves the kernel as one row (an eighth of the round trip); for the
+            # outputs dictionary the last voice stays out of its row's sum and leaves on its own
+            res = core.frequency_filter_voice_sums(noise, m_src, noise_p.window_size, rs, P, voice_sums, vm,
+                                                   split_last=want_last)
+            if res is not None:
+                if want_last:
+                    res, last_stem['noise'] = res
+                return nctl, res, voice_sums
+        sig = core.frequency_filter(noise, m_src, window_size=noise_p.window_size, raw_scale=rs)
         return nctl, sig, 1
 
     # The noise branch does not depend on the additive one until the mix: it is enqueued on a side stream first, so
@@ -239,10 +234,14 @@ def run(plan, inputs, noise=None, need_stems=True):
         nctl, noise_sig, noise_vq = noise_branch(noise)
     # --- additive branch ------------------------------------------------------------------------
     ctl = additive._controls(amp, hd, inh, f0, want_counts=compact)
+    additive_last = None
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                 ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N,
-                                                additive.sample_rate, voice_major=vm, audible=ctl['_audible'])
+                                                additive.sample_rate, voice_major=vm, audible=ctl['_audible'],
+                                                split_last=want_last)
+        if want_last:               # (voices 0 .. P-2 summed, the last voice's stem): one launch, no oscillator twice
+            additive_mix, additive_last = additive_mix
         additive_sig = None
     else:
         additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
@@ -275,31 +274,40 @@ def run(plan, inputs, noise=None, need_stems=True):
     # --- add chain ------------------------------------------------------------------------------
     dry = torch.empty((B, N), dtype=torch.float32, device=dev)
     if compact:
-        if noise_vq > 1:           # noise rows are [B, P / noise_vq] sums, segment major
-            _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), P // noise_vq, _ptr(dry), B, N, N,
-                                                0, _stream()))
-        else:
-            _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), P, _ptr(dry), B, N, N,
-                                                vmi, _stream()))
         outputs = {'inputs': inputs}
         outputs.update(inputs)
         add_controls = {}
+        pz = P // noise_vq if noise_vq > 1 else P          # noise rows per segment ([B, P / noise_vq] sums are segment major)
+        zvm = 0 if noise_vq > 1 else vmi
         if want_last:
-            # what the node-by-node walk leaves behind: the three re-used processors hold the LAST voice's stems and
-            # controls (polyphonic_dag.py re-uses the objects).  Its additive stem is one more B-row launch; its
-            # noise stem is already a row block of noise_sig.
-            lc = {k: voice(ctl[k], sh).contiguous() for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
-                                                                   ('harmonic_shifts', (T, H)), ('f0_hz', (T, S)))}
-            additive_last = core.harmonic_synthesis_fused(lc['f0_hz'], lc['amplitudes'].reshape(B, T),
-                                                          lc['harmonic_distribution'], lc['harmonic_shifts'], N,
-                                                          additive.sample_rate, additive.inference)
-            noise_last = last_stem['noise'] if noise_vq > 1 else voice(noise_sig, (N,))
+            # What the node-by-node walk leaves behind: the three re-used processors hold the LAST voice's stems and
+            # controls (polyphonic_dag.py re-uses the objects), and the last `add` call's operands are (the mix of
+            # the voices before it, its noise, its additive signal).  The bank and the noise kernel kept the last
+            # voice apart, so the chain's last step is evaluated as the DAG writes it: (prev + noise) + additive.
+            noise_last = last_stem.get('noise')
+            if noise_last is None:                          # per-voice noise rows: the last voice is a row block
+                noise_last = voice(noise_sig, (N,)).contiguous()
+                z_rows, z_n = per_voice(noise_sig, (N,))[:, :last].contiguous(), P - 1
+                zvm = 0
+            else:
+                z_rows, z_n = noise_sig, pz
+            prev = torch.empty((B, N), dtype=torch.float32, device=dev)
+            if P > 1:
+                _lib.check(_lib_().ddspp_mix_last_voice(_ptr(additive_mix), 1, _ptr(z_rows), z_n, _ptr(noise_last),
+                                                        _ptr(additive_last), _ptr(prev), _ptr(dry), B, N, zvm, _stream()))
+            else:
+                dry = core.add_signals([noise_last, additive_last])
+            lc = {k: voice(ctl[k], sh) for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
+                                                     ('harmonic_shifts', (T, H)), ('f0_hz', (T, S)))}
             mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}
             outputs[noise_p.name] = {'signal': noise_last, 'controls': {'magnitudes': mags_last}}
-            add_controls = {'signal_1': noise_last, 'signal_2': additive_last} if P > 1 else \
+            add_controls = {'signal_0': prev, 'signal_1': noise_last, 'signal_2': additive_last} if P > 1 else \
                 {'signal_0': noise_last, 'signal_1': additive_last}
+        else:
+            _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), pz, _ptr(dry), B, N, N, zvm,
+                                                _stream()))
         outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
         module_outputs = outputs[plan.add.name]
         if plan.reverb is not None:
@@ -307,7 +315,8 @@ def run(plan, inputs, noise=None, need_stems=True):
             outputs[plan.reverb.name] = module_outputs
         outputs['out'] = module_outputs
         return outputs
-    _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), B, P, N, N,
+    prev = torch.empty((B, N), dtype=torch.float32, device=dev) if P > 1 else None
+    _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), _ptr(prev), B, P, N, N,
                                             vmi, _stream()))
 
     additive_sig = per_voice(additive_sig, (N,))
@@ -323,7 +332,7 @@ def run(plan, inputs, noise=None, need_stems=True):
                      'f0_hz': voice(ctl['f0_hz'], (T, S))}}
     outputs[noise_p.name] = {'signal': noise_sig[:, last],
                              'controls': {'magnitudes': voice(nctl['magnitudes'], (T, K))}}
-    add_controls = {'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
+    add_controls = {'signal_0': prev, 'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
         {'signal_0': noise_sig[:, last], 'signal_1': additive_sig[:, last]}
     outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
     module_outputs = outputs[plan.add.name]

@@ -90,11 +90,14 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
  * reference's Parallelizer.unparallelize leaves the merged controls in (sub_modules.py:573-592), so the per-voice
  * keys `<name>_<i>` can be handed over without a copy.  Only oscillators with a non-zero amplitude somewhere in a
  * span are given a lane, so the work follows the number of partials below Nyquist instead of P * H.
- * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics. */
+ * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.
+ * audio_last[B, T*U] (may be NULL): when given, the LAST voice's stem goes there and `audio` holds the sum of voices
+ * 0 .. P-2 -- the reference's DAG re-uses one additive processor for all voices, so its outputs dictionary keeps the
+ * last voice's signal next to the mix (polyphonic_dag.py:28-37, piano_model.py:160-164). */
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const int* audible, const float* wlin,
-                              const float* whann, float* audio,
+                              const float* whann, float* audio, float* audio_last,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
@@ -126,8 +129,9 @@ int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_k
 int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, hipStream_t stream);
 
 /* the whole `add` chain of polyphonic_dag.py:28-37: additive/noise [B,P,N] (voice_major = 0) or [P,B,N]
- * (voice_major = 1) -> out rows of out_stride floats (noise may be NULL). */
-int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, int B, int P, int N,
+ * (voice_major = 1) -> out rows of out_stride floats (noise may be NULL).  out_prev (may be NULL) [B,N]: the running
+ * mix before the last voice, i.e. the first operand of the last `add` node. */
+int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, float* out_prev, int B, int P, int N,
                          int out_stride, int voice_major, hipStream_t stream);
 
 /* out[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] ([B,PA,N], [B,PZ,N], or [PA,B,N], [PZ,B,N] when
@@ -135,6 +139,14 @@ int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, 
  * per-segment mix of ddspp_polyphonic_additive. */
 int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out, int B, int N, int out_stride,
                      int voice_major, hipStream_t stream);
+
+/* The end of the add chain with the last voice kept apart -- what the reference's outputs dictionary holds for the
+ * re-used processors (polyphonic_dag.py:34-37, piano_model.py:160-164): prev[b] = sum of the PA rows a[b, :] + the PZ
+ * rows z[b, :] (voices 0 .. P-2), dry[b] = (prev[b] + noise_last[b]) + additive_last[b].  prev, dry, noise_last,
+ * additive_last: [B, N]. */
+int ddspp_mix_last_voice(const float* a, int PA, const float* z, int PZ, const float* noise_last,
+                         const float* additive_last, float* prev, float* dry, int B, int N, int voice_major,
+                         hipStream_t stream);
 
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
@@ -179,9 +191,13 @@ int ddspp_frequency_filter_eo(const float* audio, const float* magnitudes, const
 /* The same for the R = n_segments * n_voices rows of a polyphonic group (segment major, or voice major as
  * ddspp_polyphonic_additive), with the filtered noise of `voices_per_row` consecutive voices of a segment summed in
  * registers into ONE output row: out[R / voices_per_row, N] -- the noise half of the `add` chain of
- * polyphonic_dag.py:28-37 without a [R, N] round trip; ddspp_mix_voices adds the rows to the additive mix. */
+ * polyphonic_dag.py:28-37 without a [R, N] round trip; ddspp_mix_voices adds the rows to the additive mix.
+ * out_last (may be NULL; needs voices_per_row > 1) [R / n_voices, N]: every segment's LAST voice goes there instead
+ * of into its row's sum (the reference's outputs dictionary keeps the re-used noise processor's last signal);
+ * ddspp_mix_last_voice then finishes the chain. */
 int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes, const float* CE, const float* CO,
                                      const int* tap_idx, const float* tap_we, const float* tap_wo, float* out,
+                                     float* out_last,
                                      int R, int N, int T, int K, int Lw, int NJ, int delay_compensation,
                                      int scale_kind, float bias, float exponent, float max_value, float threshold,
                                      float gain, int n_voices, int voices_per_row, int voice_major,

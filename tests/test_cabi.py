@@ -74,7 +74,7 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     rc = lib.ddspp_frequency_filter_eo(null, one, one, one, one, one, one, one, 4, 72000, 750, 96, 190, 48, -1, 1,
                                        -5.0, 10.0, 2.0, 1e-7, 1.0, null)
     assert rc == _lib.DDSPP_EINVAL and b'null' in lib.ddspp_last_error()
-    rc = lib.ddspp_frequency_filter_eo_voices(one, one, one, one, one, one, one, one, 32, 72000, 750, 96, 190, 48, -1,
+    rc = lib.ddspp_frequency_filter_eo_voices(one, one, one, one, one, one, one, one, null, 32, 72000, 750, 96, 190, 48, -1,
                                               1, -5.0, 10.0, 2.0, 1e-7, 1.0, 16, 3, 0, null)      # 3 does not divide 16
     assert rc == _lib.DDSPP_EINVAL and b'voices' in lib.ddspp_last_error()
     rc = lib.ddspp_frequency_filter_eo(one, one, one, one, one, one, one, one, 4, 48000, 750, 64, 126, 32, -1, 1,
@@ -82,6 +82,6 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     assert rc == _lib.DDSPP_EINVAL and b'not supported' in lib.ddspp_last_error()
     assert lib.ddspp_fftconv_transform_ir(null, one, 1, one, 0, null) == _lib.DDSPP_EINVAL
     assert lib.ddspp_fftconv_execute_prepared(null, one, 10, one, 10, 0, 1, one, 0, null) == _lib.DDSPP_EINVAL
-    rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, one, one, one, 2, 65, 10, 1, 8, 96, 24000.0, 0, 0,
+    rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, one, one, one, null, 2, 65, 10, 1, 8, 96, 24000.0, 0, 0,
                                        one, 1 << 30, null)
     assert rc == _lib.DDSPP_EINVAL and b'exceeds 64' in lib.ddspp_last_error()

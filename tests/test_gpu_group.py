@@ -284,11 +284,59 @@ def test_compacted_additive_equals_voice_stems():
             mix_cnt = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'],
                                                B, N, sr, spans=spans, audible=cnt)
             assert torch.equal(mix_cnt, mix), (B, P, H, S, spans)
+            # the last voice kept apart (what the outputs dictionary of the reference's DAG holds): its oscillators get
+            # wavefront slots of their own, every oscillator still runs exactly once
+            rest, last_v = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'],
+                                                    B, N, sr, spans=spans, audible=cnt, split_last=True)
+            assert (last_v - stems[:, P - 1]).abs().max().item() < 3e-6, (B, P, H, S, spans)
+            assert (rest - stems[:, :P - 1].sum(dim=1)).abs().max().item() < 3e-6, (B, P, H, S, spans)
+            rest_vm, last_vm = core.polyphonic_additive(*vm, B, N, sr, spans=spans, voice_major=True, split_last=True)
+            assert torch.equal(rest_vm, rest) and torch.equal(last_vm, last_v)
     # all voices silent: zeros
     z = torch.zeros(4, 20, 8, device='cuda')
     out = core.polyphonic_additive(torch.full((4, 20, 1), 100.0, device='cuda'), torch.zeros(4, 20, device='cuda'), z, z,
                                    2, 20 * 96, 24000)
     assert out.shape == (2, 1920) and (out == 0).all()
+
+
+def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
+    """Every frame's frequencies move (vibrato + glide, some partials gliding through Nyquist): the memoised pre-pass
+    scans every chunk sample by sample, four wavefronts per (row, 64 oscillators) sharing the chunks.  Same start
+    phases bit for bit as one wavefront walking the whole row, and the audio matches the oracle -- also with
+    normalize_below_nyquist=False, where a partial above Nyquist keeps its amplitude in the controls and only the
+    sample-rate mask of cos_oscillator_bank (inharm_synth.py:65-67) silences it."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(41)
+    B, P, T, H, sr = 5, 4, 120, 128, 24000            # R * 2 groups >= ... the batch form needs R >= 256 rows for the memo
+    B = 64                                            # 256 rows: the memoised pre-pass is the one that runs
+    N = T * 96
+    R = B * P
+    raw = synth_controls(rng, R, T, H, S=1, silent_frac=0.1, midi_lo=60, midi_hi=100)
+    tt = np.arange(T, dtype=np.float32)[None, :, None]
+    raw['f0_hz'] = (raw['f0_hz'] * (1 + 0.004 * np.sin(0.13 * tt + rng.uniform(0, 6, [R, 1, 1])) - 0.0015 * tt)
+                    ).astype(np.float32)              # downward glide: high partials come back below Nyquist
+    for nbn in (True, False):
+        syn = dp.MultiInharmonic(sample_rate=sr, inference=True, normalize_below_nyquist=nbn)
+        osyn = O.MultiInharmonic(sample_rate=sr, inference=True, normalize_below_nyquist=nbn)
+        dev = [torch.as_tensor(raw[k], device='cuda') for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]
+        ctl = syn._controls(*dev, want_counts=True)
+        amp = ctl['amplitudes'].reshape(R, T).contiguous()
+        args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
+        mix = core.polyphonic_additive(*args, audible=ctl['_audible'])
+        monkeypatch.setenv('DDSPP_OSC_PREPASS_ONE_WAVE', '1')
+        one = core.polyphonic_additive(*args, audible=ctl['_audible'])
+        monkeypatch.delenv('DDSPP_OSC_PREPASS_ONE_WAVE')
+        assert torch.equal(mix, one), nbn
+        stems = core.harmonic_synthesis_fused(*args[:4], N, sr, True).reshape(B, P, N)
+        assert (mix - stems.sum(dim=1)).abs().max().item() < 5e-6, nbn
+        rows = [0, 7, R - 1]                          # the oracle on a few voice rows
+        ref = osyn(*[raw[k][rows] for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')])
+        got = stems.reshape(R, N)[rows].cpu().numpy()
+        assert rms_err(got, ref) < TOL, nbn
+        one_seg = core.polyphonic_additive(*[a[:P].contiguous() for a in args[:4]], 1, N, sr)     # compact kernel, 1 segment
+        ref_seg = osyn(*[raw[k][:P] for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]).sum(0)
+        assert rms_err(one_seg.cpu().numpy()[0], ref_seg) < TOL, nbn
 
 
 def test_parallelizer_views_feed_the_group_without_copies():
@@ -339,10 +387,16 @@ def test_outputs_dict_routes_agree():
     cl, cf = last['controls'], full['controls']
     assert 'voices' not in cl and cf['voices']['additive'].shape == (B, P, N)
     for name in ('additive', 'noise'):
-        assert torch.equal(cl[name]['signal'], cf[name]['signal']), name     # the last voice's stems: same kernels
+        # the last voice's stems: slots of its own in the compacted bank / a row of its own out of the voice-summing
+        # noise kernel, against the per-voice kernels (same per-oscillator arithmetic, another summation order)
+        assert (cl[name]['signal'] - cf[name]['signal']).abs().max().item() < 3e-6, name
         for k in cf[name]['controls']:
             assert torch.equal(cl[name]['controls'][k], cf[name]['controls'][k]), (name, k)
-    assert set(cl['add']['controls']) == set(cf['add']['controls'])
+    assert set(cl['add']['controls']) == set(cf['add']['controls']) == {'signal_0', 'signal_1', 'signal_2'}
+    for k in ('signal_0', 'signal_1', 'signal_2'):       # the last add node's operands: running mix, noise, additive
+        assert (cl['add']['controls'][k] - cf['add']['controls'][k]).abs().max().item() < 5e-6, k
+    last_step = (cl['add']['controls']['signal_0'] + cl['add']['controls']['signal_1']) + cl['add']['controls']['signal_2']
+    assert torch.equal(last_step, cl['add']['signal'])    # the chain's last step is evaluated as the DAG writes it
     assert (cl['add']['signal'] - cf['add']['signal']).abs().max().item() < 5e-6
     assert cl['out'] is cl['reverb'] and 'reverb_ir' in cl and 'amplitudes_0' in cl
 

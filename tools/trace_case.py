@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Run one bench input case a few times (for rocprofv3 --kernel-trace --stats).
+usage: python tools/trace_case.py [headline|moving|dense] [audio|dict] [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import ddsp_piano_amd as dp  # noqa: E402
+
+case = sys.argv[1] if len(sys.argv) > 1 else 'headline'
+form = sys.argv[2] if len(sys.argv) > 2 else 'dict'
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device('cuda', 0)
+B, P, T, H, K, S, L, sr = 64, 16, 750, 128, 96, 1, 72000, 24000
+kw = {'headline': {}, 'moving': dict(vibrato=0.002),
+      'dense': dict(silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)}[case]
+feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
+pg = bench.build_group(dp, P, sr)
+fn = (lambda: pg(feats, return_outputs_dict=True)) if form == 'dict' else (lambda: pg(feats))
+ts = bench.event_times(fn, reps, warmup=2)
+print(case, form, 'ms per step:', bench.ms_summary(ts))
