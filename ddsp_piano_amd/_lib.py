@@ -97,10 +97,12 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
-    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_additive': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                           c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
+    'ddspp_inharmonic_controls_group': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_float, c_int, c_float, c_float, c_float,
+                                                c_float, c_int, c_int, c_void_p]),
     'ddspp_scale_bias': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_float, c_float,
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -505,7 +505,7 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
-                        sample_rate, spans=0, voice_major=False, audible=None, split_last=False):
+                        sample_rate, spans=0, voice_major=False, audible=None, split_last=False, inharm_coef=None):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
@@ -513,7 +513,8 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     span (ddspp_polyphonic_additive).  Inference (angular cumsum) path only.  audible: the int32 [R, T]
     per-frame counts of InHarmonic._controls(want_counts=True) (saves a scan of the [R, T, H] controls).
     split_last=True returns (sum of voices 0 .. P-2, the last voice's stem): what the outputs dictionary of the
-    reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37)."""
+    reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37).
+    harmonic_shifts=None with inharm_coef [R, T] (raw): the kernels form the shifts themselves (get_inharmonic_freq)."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
@@ -533,6 +534,7 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     _lib.check(lib.ddspp_polyphonic_additive(
         _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
         _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
+        _ptr(inharm_coef) if (inharm_coef is not None and harmonic_shifts is None) else null,
         ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(wlin), _ptr(whann),
         _ptr(out), _ptr(last), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
         _stream()))

@@ -120,14 +120,14 @@ bank_compact_kernel(const OscParams p) {
     //   ha(t, v) = amp[t] * hd[t, k]                      inharm_synth.py:112
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
     float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
-    const bool has_shifts = p.shifts != nullptr;
+    const bool has_shifts = p.shifts != nullptr, from_inh = !has_shifts && p.inh != nullptr;
     auto frame_request = [&](int tt) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const size_t fr = (size_t)lrow[j] * T + tt;
             q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
-            q_sh[j] = has_shifts ? p.shifts[fr * H + vk[j]] : 0.0f;
+            q_sh[j] = has_shifts ? p.shifts[fr * H + vk[j]] : (from_inh ? p.inh[fr] : 0.0f);
             q_hd[j] = p.hd[fr * H + vk[j]];
         }
     };
@@ -136,6 +136,7 @@ bank_compact_kernel(const OscParams p) {
         for (int j = 0; j < VPL; ++j) {
             float f = q_f0[j] * kmul[j];
             if (has_shifts) f = f * (1.0f + q_sh[j]);
+            else if (from_inh) f = f * (1.0f + shift_from_inharm(q_sh[j], kmul[j]));     // get_inharmonic_freq, per lane and frame
             const float a = q_amp[j] * q_hd[j];
             xf[j] = valid[j] ? f : 0.0f;
             xa[j] = valid[j] ? a : 0.0f;

@@ -25,6 +25,8 @@ struct InharmParams {
     float* __restrict__ hd_out;                       // [R, T, H]
     float* __restrict__ shifts_out;                   // [R, T, H]
     int* __restrict__ count_out;                      // [R, T] audible leading harmonics per frame (+ bit 16: frequencies moved), or null
+    float* __restrict__ shifts_last;                  // [R / P, T, H] harmonic_shifts of every segment's LAST voice only, or null
+    int P, vmajor;                                    // rows are [B, P] (or [P, B] with vmajor) when shifts_last is given
     int R, T, H, S;
     float nyquist, min_frequency, n_substrings;
     int normalize_after_nyquist_cut, normalize_below_nyquist;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
                 g = g * inharm + 1.0f;                 //                                        :38
                 g = sqrtf(g);                          //                                        :39
                 freq[j] = (f0 * m) * g;                // f0_hz * int_multiplier * inharm_factor :42
-                shift[j] = g - 1.0f;                   //                                        :44
+                shift[j] = g - 1.0f;                   //                                        :44  (= osc_common.h shift_from_inharm)
                 sum += hd[j];
             }
         }
@@ -109,7 +111,18 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             const int k = lane + 64 * j;
             if (k < H) {
                 p.hd_out[frame * H + k] = hd[j];
-                p.shifts_out[frame * H + k] = shift[j];
+                if (p.shifts_out) p.shifts_out[frame * H + k] = shift[j];    // null: the oscillator kernels form them from inharm_coef
+            }
+        }
+        if (p.shifts_last) {       // what the outputs dictionary of the reference's DAG keeps: the last voice's controls
+            const int row = (int)(frame / p.T), tt = (int)(frame - (size_t)row * p.T), nb = p.R / p.P;
+            const int v = p.vmajor ? row / nb : row % p.P, b = p.vmajor ? row % nb : row / p.P;
+            if (v == p.P - 1) {
+#pragma unroll
+                for (int j = 0; j < HPL; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < H) p.shifts_last[((size_t)b * p.T + tt) * H + k] = shift[j];
+                }
             }
         }
         if (lane == 0) p.amp_out[frame] = amp;
@@ -242,15 +255,16 @@ extern "C" {
 // InHarmonic.get_controls / MultiInharmonic.get_controls  -- inharm_synth.py:167-219, :254-270.
 // scale_kind: 0 none, 1 core.exp_sigmoid, 2 exp_tanh; (exponent, max_value, threshold, gain) are the
 // keyword defaults of those functions unless the caller overrides them.
-int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
+static int inharmonic_controls_impl(const float* amplitudes, const float* harmonic_distribution,
                               const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
                               float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
                               int R, int T, int H, int S, float sample_rate, float min_frequency, int scale_kind,
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
+                              float* shifts_last_out, int n_voices, int voice_major,
                               hipStream_t stream) {
     DDSPP_REQUIRE(amplitudes && harmonic_distribution && inharm_coef && f0_hz && amplitudes_out &&
-                      harmonic_distribution_out && harmonic_shifts_out,
+                      harmonic_distribution_out,
                   "inharmonic_controls: null buffer");
     DDSPP_REQUIRE(R > 0 && T > 0 && H > 0 && S > 0, "inharmonic_controls: bad dims");
     DDSPP_REQUIRE(H <= 512, "inharmonic_controls: n_harmonics=%d exceeds 512", H);
@@ -260,6 +274,9 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
     p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
     p.amp_out = amplitudes_out; p.hd_out = harmonic_distribution_out; p.shifts_out = harmonic_shifts_out;
     p.count_out = audible_out;
+    DDSPP_REQUIRE(!shifts_last_out || (n_voices >= 1 && R % n_voices == 0),
+                  "inharmonic_controls: %d rows are not a whole number of %d-voice segments", R, n_voices);
+    p.shifts_last = shifts_last_out; p.P = n_voices; p.vmajor = voice_major;
     p.R = R; p.T = T; p.H = H; p.S = S;
     p.nyquist = sample_rate / 2.0f; p.min_frequency = min_frequency; p.n_substrings = (float)S;
     p.normalize_after_nyquist_cut = normalize_after_nyquist_cut;
@@ -277,6 +294,36 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
                            audible_out, R, T, S);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
+}
+
+int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
+                              const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                              float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
+                              int R, int T, int H, int S, float sample_rate, float min_frequency, int scale_kind,
+                              float exponent, float max_value, float threshold, float gain,
+                              int normalize_after_nyquist_cut, int normalize_below_nyquist,
+                              hipStream_t stream) {
+    return inharmonic_controls_impl(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amplitudes_out,
+                                    harmonic_distribution_out, harmonic_shifts_out, audible_out, R, T, H, S, sample_rate,
+                                    min_frequency, scale_kind, exponent, max_value, threshold, gain,
+                                    normalize_after_nyquist_cut, normalize_below_nyquist, nullptr, 1, 0, stream);
+}
+
+// The same over the R = n_segments * n_voices rows of a polyphonic group (segment major, or voice major), writing
+// harmonic_shifts only for every segment's LAST voice (shifts_last_out [R / n_voices, T, H]): the compacted oscillator
+// bank forms the shifts of all voices itself, the outputs dictionary of the reference's DAG keeps the last voice's.
+int ddspp_inharmonic_controls_group(const float* amplitudes, const float* harmonic_distribution,
+                                    const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                                    float* harmonic_distribution_out, float* shifts_last_out, int* audible_out,
+                                    int R, int T, int H, int S, int n_voices, int voice_major, float sample_rate,
+                                    float min_frequency, int scale_kind, float exponent, float max_value,
+                                    float threshold, float gain, int normalize_after_nyquist_cut,
+                                    int normalize_below_nyquist, hipStream_t stream) {
+    return inharmonic_controls_impl(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amplitudes_out,
+                                    harmonic_distribution_out, nullptr, audible_out, R, T, H, S, sample_rate,
+                                    min_frequency, scale_kind, exponent, max_value, threshold, gain,
+                                    normalize_after_nyquist_cut, normalize_below_nyquist, shifts_last_out, n_voices,
+                                    voice_major, stream);
 }
 
 // ddsp.synths.FilteredNoise.get_controls: magnitudes = scale_fn(magnitudes + initial_bias)

@@ -12,7 +12,8 @@ struct OscParams {
     const float* __restrict__ f0;      // [R, T, S]
     const float* __restrict__ amp;     // [R, T]
     const float* __restrict__ hd;      // [R, T, H]
-    const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts)
+    const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts, or shifts from `inh`)
+    const float* __restrict__ inh;     // [R, T] raw inharm_coef: with shifts == null the kernels form harmonic_shifts themselves
     const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
     int dbg_noflags;                   // DDSPP_OSC_NO_FLAGS=1: ignore bit 16 of audible, stream the controls instead (A/B switch)
     const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
@@ -43,6 +44,18 @@ enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
 constexpr int BLK = 8;        // samples per unrolled block; divides U and the 1000-sample chunk
 constexpr int TILE = 32;      // samples per LDS reduction tile
 constexpr int TSTRIDE = 68;   // words per tile row: 16-byte aligned rows, 17 quads apart -> ds_read_b128 conflict free
+
+// harmonic_shifts[t, k] of get_inharmonic_freq (inharm_synth.py:37-44) for harmonic number m = k + 1, from the raw
+// inharm_coef (clamped as InHarmonic.get_controls does, :183).  Every op separately rounded, the square root correctly
+// rounded: bit for bit what ddspp_inharmonic_controls writes into harmonic_shifts_out, so a kernel may form the shifts
+// itself (per lane and frame) instead of reading a [R, T, H] tensor back.
+__device__ __forceinline__ float shift_from_inharm(float inharm_raw, float m) {
+    const float inharm = fmaxf(inharm_raw, 0.0f);
+    float g = m * m;                               // tf.math.pow(int_multiplier, 2)        :37
+    g = g * inharm + 1.0f;                         //                                        :38
+    g = sqrtf(g);                                  //                                        :39
+    return g - 1.0f;                               //                                        :44
+}
 
 template <bool FAST>
 __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {

@@ -181,7 +181,7 @@ osc_kernel(const OscParams p) {
             const size_t fr = (size_t)lrow[j] * T + tt;
             q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
-            q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : 0.0f;
+            q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : (p.inh ? p.inh[fr] : 0.0f);
             q_hd[j] = (MODE != MODE_PREPASS) ? p.hd[fr * H + vk[j]] : 0.0f;
         }
     };
@@ -190,6 +190,7 @@ osc_kernel(const OscParams p) {
         for (int j = 0; j < VPL; ++j) {
             float f = q_f0[j] * kmul[j];
             if (p.shifts) f = f * (1.0f + q_sh[j]);
+            else if (p.inh) f = f * (1.0f + shift_from_inharm(q_sh[j], kmul[j]));
             const float a = q_amp[j] * q_hd[j];
             xf[j] = valid[j] ? f : 0.0f;
             xa[j] = (valid[j] && MODE != MODE_PREPASS) ? a : 0.0f;
@@ -576,24 +577,29 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     }
     // raw loads and arithmetic are kept apart (and free of branches) so that a batch of frames is
     // fetched with all its loads in flight at once
-    const float* shp = p.shifts ? p.shifts : p.hd;          // no shifts: any finite [R, T, H] buffer ...
-    const float sh_on = p.shifts ? 1.0f : 0.0f;             // ... times 0
+    // shifts: read from the [R, T, H] tensor, or formed from the row's inharm_coef (p.shifts == null, p.inh given);
+    // neither: any finite buffer, ignored
+    const bool from_inh = !p.shifts && p.inh;
+    const float* shp = p.shifts ? p.shifts : (from_inh ? p.inh : p.hd);
+    const int sh_stride = from_inh ? 0 : H;                  // inharm_coef is one value per frame
     auto hf_raw = [&](int tt, float* rf, float* rs) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const size_t fr = (size_t)row * T + (need[j] ? tt : 0);
             rf[j] = p.f0[fr * S + vs[j]];
-            rs[j] = shp[fr * H + vk[j]];
+            rs[j] = from_inh ? shp[fr] : shp[fr * H + vk[j]];
         }
     };
     auto hf_calc = [&](const float* rf, const float* rs, float* xf) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             float f = rf[j] * kmul[j];
-            if (p.shifts) f = f * (1.0f + rs[j] * sh_on);
+            if (p.shifts) f = f * (1.0f + rs[j]);
+            else if (from_inh) f = f * (1.0f + shift_from_inharm(rs[j], kmul[j]));
             xf[j] = valid[j] ? f : 0.0f;
         }
     };
+    (void)sh_stride;
     auto hf_of = [&](int tt, float* xf) {
         float rf[VPL], rs[VPL];
         hf_raw(tt, rf, rs);
@@ -832,14 +838,16 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
     const int t_lo = n_lo / U;
     const int nfr = (n_hi - 1) / U - t_lo + 2;                       // frames t_lo .. t_last + 1
     // ---- all frames of the chunk in one batch: branch-free addresses, every load issued before the first use
-    const float* shp = p.shifts ? p.shifts : p.hd;         // no shifts: any finite [R, T, H] buffer, times 0
-    const float sh_on = p.shifts ? 1.0f : 0.0f;
+    // shifts from the [R, T, H] tensor, or formed from inharm_coef [R, T]; neither: any finite buffer, ignored
+    const bool from_inh = !p.shifts && p.inh;
+    const float* shp = p.shifts ? p.shifts : (from_inh ? p.inh : p.hd);
+    const size_t sh_stride = from_inh ? 1 : H;
     const float* f0p[VPL];
     const float* shq[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         f0p[j] = p.f0 + (size_t)row * T * S + vs[j];
-        shq[j] = shp + (size_t)row * T * H + vk[j];
+        shq[j] = shp + (size_t)row * T * sh_stride + (from_inh ? 0 : vk[j]);
     }
     float rf[PRE_FR][VPL], rs[PRE_FR][VPL];
 #pragma unroll
@@ -848,7 +856,7 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             rf[u][j] = f0p[j][(size_t)fr * S];
-            rs[u][j] = shq[j][(size_t)fr * H];
+            rs[u][j] = shq[j][(size_t)fr * sh_stride];
         }
     }
     bool same = true;
@@ -858,7 +866,8 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             float f = rf[u][j] * kmul[j];
-            f = f * (1.0f + rs[u][j] * sh_on);
+            if (p.shifts) f = f * (1.0f + rs[u][j]);
+            else if (from_inh) f = f * (1.0f + shift_from_inharm(rs[u][j], kmul[j]));
             f = valid[j] ? f : 0.0f;
             if (u == 0) hf0[j] = f;
             same = same && (f == hf0[j]);
@@ -1341,8 +1350,8 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
 }
 
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
-                              const float* harmonic_shifts, const int* audible, const float* wlin,
-                              const float* whann, float* audio, float* audio_last,
+                              const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                              const float* wlin, const float* whann, float* audio, float* audio_last,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
@@ -1382,6 +1391,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
 
     OscParams p{};
     p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
+    p.inh = harmonic_shifts ? nullptr : inharm_coef;       // shifts formed in the kernels from the raw inharm_coef
     p.audible = audible;
     p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0) | (env_int("DDSPP_BANK_ABLATE", 0) << 8);
     p.wlin = wlin; p.whann = whann;

@@ -233,13 +233,15 @@ def run(plan, inputs, noise=None, need_stems=True):
     else:
         nctl, noise_sig, noise_vq = noise_branch(noise)
     # --- additive branch ------------------------------------------------------------------------
-    ctl = additive._controls(amp, hd, inh, f0, want_counts=compact)
+    # compacted route: harmonic_shifts are never written (the bank forms them from inharm_coef per lane and frame)
+    ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
+                             last_voice_of=(P, vm) if want_last else None)
     additive_last = None
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
-                                                ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N,
+                                                ctl['harmonic_distribution'], None, B, N,
                                                 additive.sample_rate, voice_major=vm, audible=ctl['_audible'],
-                                                split_last=want_last)
+                                                split_last=want_last, inharm_coef=ctl['_inharm_coef'].reshape(R, T))
         if want_last:               # (voices 0 .. P-2 summed, the last voice's stem): one launch, no oscillator twice
             additive_mix, additive_last = additive_mix
         additive_sig = None
@@ -298,7 +300,8 @@ def run(plan, inputs, noise=None, need_stems=True):
             else:
                 dry = core.add_signals([noise_last, additive_last])
             lc = {k: voice(ctl[k], sh) for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
-                                                     ('harmonic_shifts', (T, H)), ('f0_hz', (T, S)))}
+                                                     ('f0_hz', (T, S)))}
+            lc['harmonic_shifts'] = ctl['_shifts_last']       # written by the get_controls kernel for the last voice only
             mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}

@@ -34,8 +34,13 @@ class InHarmonic(Processor):
     def upsampling(self):
         return int(self.sample_rate / self.frame_rate)               # :163-165
 
-    def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz, want_counts=False):
-        """One fused kernel for :183-214 (+ :269); f0_hz may carry several sub-strings."""
+    def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz, want_counts=False, want_shifts=True,
+                  last_voice_of=None):
+        """One fused kernel for :183-214 (+ :269); f0_hz may carry several sub-strings.
+        want_shifts=False: 'harmonic_shifts' is left out (the compacted oscillator bank forms it from inharm_coef per
+        lane and frame, a [R, T, H] tensor less to write and read back); '_inharm_coef' carries the raw coefficients.
+        last_voice_of=(n_voices, voice_major) with want_shifts=False: '_shifts_last' [rows / n_voices, T, H] holds the
+        harmonic_shifts of every segment's last voice (what the reference's outputs dictionary keeps)."""
         amplitudes = core.tf_float32(amplitudes)
         harmonic_distribution = core.tf_float32(harmonic_distribution)
         inharm_coef = core.tf_float32(inharm_coef)
@@ -57,15 +62,30 @@ class InHarmonic(Processor):
         code, prm = kind
         amp_out = torch.empty_like(amplitudes)
         hd_out = torch.empty_like(harmonic_distribution)
-        shifts_out = torch.empty_like(harmonic_distribution)
+        shifts_out = torch.empty_like(harmonic_distribution) if want_shifts else None
         counts = torch.empty((b, t), dtype=torch.int32, device=amplitudes.device) if want_counts else None
-        _lib.check(_lib_().ddspp_inharmonic_controls(
-            _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
-            _ptr(hd_out), _ptr(shifts_out), counts.data_ptr() if counts is not None else None, b, t, h, s, float(self.sample_rate), float(self.min_frequency),
-            code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
-            int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
+        shifts_last = None
+        if last_voice_of is not None and not want_shifts:
+            n_voices, voice_major = last_voice_of
+            shifts_last = torch.empty((b // n_voices, t, h), dtype=torch.float32, device=amplitudes.device)
+            _lib.check(_lib_().ddspp_inharmonic_controls_group(
+                _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
+                _ptr(hd_out), _ptr(shifts_last), counts.data_ptr() if counts is not None else None, b, t, h, s,
+                int(n_voices), int(bool(voice_major)), float(self.sample_rate), float(self.min_frequency),
+                code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+                int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
+        else:
+            _lib.check(_lib_().ddspp_inharmonic_controls(
+                _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
+                _ptr(hd_out), _ptr(shifts_out), counts.data_ptr() if counts is not None else None, b, t, h, s,
+                float(self.sample_rate), float(self.min_frequency),
+                code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+                int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
         ctl = {'amplitudes': amp_out, 'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out,
                'f0_hz': f0_hz}
+        if not want_shifts:
+            ctl['_inharm_coef'] = inharm_coef
+            ctl['_shifts_last'] = shifts_last
         if want_counts:
             ctl['_audible'] = counts       # per-frame count of leading non-silent harmonics (batched route only)
         return ctl

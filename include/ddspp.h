@@ -90,13 +90,17 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
  * reference's Parallelizer.unparallelize leaves the merged controls in (sub_modules.py:573-592), so the per-voice
  * keys `<name>_<i>` can be handed over without a copy.  Only oscillators with a non-zero amplitude somewhere in a
  * span are given a lane, so the work follows the number of partials below Nyquist instead of P * H.
+ * harmonic_shifts NULL and inharm_coef[R,T] given (the raw get_controls input): the kernels form
+ * harmonic_shifts = sqrt(k^2 max(inharm_coef, 0) + 1) - 1 (get_inharmonic_freq, inharm_synth.py:37-44) per lane and
+ * frame -- bit for bit what ddspp_inharmonic_controls writes -- and the [R,T,H] tensor need not exist.
  * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.
  * audio_last[B, T*U] (may be NULL): when given, the LAST voice's stem goes there and `audio` holds the sum of voices
  * 0 .. P-2 -- the reference's DAG re-uses one additive processor for all voices, so its outputs dictionary keeps the
  * last voice's signal next to the mix (polyphonic_dag.py:28-37, piano_model.py:160-164). */
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
-                              const float* harmonic_shifts, const int* audible, const float* wlin,
+                              const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                              const float* wlin,
                               const float* whann, float* audio, float* audio_last,
                               int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -106,7 +110,8 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
 /* InHarmonic.get_controls / MultiInharmonic.get_controls -- inharm_synth.py:167-219, :254-270
  * (+ get_inharmonic_freq :20-46).  amplitudes[R,T], harmonic_distribution[R,T,H], inharm_coef[R,T],
  * f0_hz[R,T,S] -> amplitudes_out[R,T] (already divided by S), harmonic_distribution_out[R,T,H],
- * harmonic_shifts_out[R,T,H]; audible_out[R,T] (int32, may be NULL): bits 0-15 = 1 + index of the last harmonic
+ * harmonic_shifts_out[R,T,H] (may be NULL when the consumer forms the shifts from inharm_coef itself, see
+ * ddspp_polyphonic_additive); audible_out[R,T] (int32, may be NULL): bits 0-15 = 1 + index of the last harmonic
  * with amplitudes_out * harmonic_distribution_out != 0 in the frame, bit 16 = some f0_hz sub-string or the clamped
  * inharm_coef differs from the previous frame's (the harmonic frequencies may have moved).
  * ddspp_polyphonic_additive accepts it as `audible`, so that it need not scan the [R,T,H] tensors again. */
@@ -117,6 +122,17 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
                               hipStream_t stream);
+/* The same over the R = n_segments * n_voices rows of a polyphonic group (segment major, or voice major as
+ * ddspp_polyphonic_additive), writing harmonic_shifts only for every segment's LAST voice (shifts_last_out
+ * [R / n_voices, T, H], may be NULL): ddspp_polyphonic_additive forms the shifts of all voices itself from inharm_coef,
+ * the outputs dictionary of the reference's DAG keeps the last voice's controls (polyphonic_dag.py:28-37). */
+int ddspp_inharmonic_controls_group(const float* amplitudes, const float* harmonic_distribution,
+                                    const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                                    float* harmonic_distribution_out, float* shifts_last_out, int* audible_out,
+                                    int R, int T, int H, int S, int n_voices, int voice_major, float sample_rate,
+                                    float min_frequency, int scale_kind, float exponent, float max_value,
+                                    float threshold, float gain, int normalize_after_nyquist_cut,
+                                    int normalize_below_nyquist, hipStream_t stream);
 
 /* ddsp.synths.FilteredNoise.get_controls: y = scale_fn(x + initial_bias), elementwise. */
 int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_kind, float exponent,

@@ -292,6 +292,13 @@ def test_compacted_additive_equals_voice_stems():
             assert (rest - stems[:, :P - 1].sum(dim=1)).abs().max().item() < 3e-6, (B, P, H, S, spans)
             rest_vm, last_vm = core.polyphonic_additive(*vm, B, N, sr, spans=spans, voice_major=True, split_last=True)
             assert torch.equal(rest_vm, rest) and torch.equal(last_vm, last_v)
+            # harmonic_shifts formed inside the kernels from the raw inharm_coef (no [R, T, H] tensor): the same bits
+            inh_raw = raw_t[2].reshape(R, T).contiguous()
+            mix_inh = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], None, B, N, sr, spans=spans,
+                                               audible=cnt, inharm_coef=inh_raw)
+            assert torch.equal(mix_inh, mix), (B, P, H, S, spans)
+            no_shift = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], None, B, N, sr, spans=spans)
+            assert not torch.equal(no_shift, mix) or float(inh_raw.abs().max()) == 0.0
     # all voices silent: zeros
     z = torch.zeros(4, 20, 8, device='cuda')
     out = core.polyphonic_additive(torch.full((4, 20, 1), 100.0, device='cuda'), torch.zeros(4, 20, device='cuda'), z, z,
