@@ -17,7 +17,7 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
+SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
            'noise.hip', 'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
 HEADERS = ['ddspp_common.h', 'osc_common.h']
@@ -86,6 +86,11 @@ SIGNATURES = {
     'ddspp_version': (c_int, []),
     'ddspp_target_arch': (c_char_p, []),
     'ddspp_last_error': (c_char_p, []),
+    'ddspp_hann_window_host': (c_int, [c_int, c_void_p]),
+    'ddspp_resample_tables_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    'ddspp_fir_matrix_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ddspp_fir_eo_tables_host': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ddspp_resample_linear': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     'ddspp_resample_window': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

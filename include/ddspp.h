@@ -43,6 +43,30 @@ int ddspp_version(void);
 const char* ddspp_target_arch(void);
 const char* ddspp_last_error(void);
 
+/* ---- host builders of the kernels' small tables (csrc/tables.cpp) --------------------------------------------
+ * Everything below that takes a table (lo/hi/w, wlin, whann, window, M, CE/CO/tap_*) gets it from here: a caller that
+ * binds libddspp.so without the Python layer needs nothing else.  Outputs are HOST buffers, the caller uploads them.
+ * The `rule` arguments select between recollections of the un-vendored ddsp / TF details;
+ * 0 is the default everywhere. */
+
+/* tf.signal.hann_window(n) (periodic), float32 arithmetic: window[n].  `whann` of ddspp_harmonic_synthesis /
+ * ddspp_polyphonic_additive and `window` of ddspp_resample_window are ddspp_hann_window_host(2 * U, ...). */
+int ddspp_hann_window_host(int n, float* window);
+/* Source rows and weights of ddsp.core.resample(method='linear') = tf.compat.v1.image.resize(BILINEAR,
+ * align_corners=False): lo[N], hi[N] (int32), w[N] (float32).  rule 0: TF1 legacy kernel, pos = n * T/N;
+ * rule 1: half-pixel centres.  `wlin` of ddspp_harmonic_synthesis / ddspp_polyphonic_additive is w (they require
+ * *aligned == 1: N = T * U and lo[n] == n / U, true for rule 0 and every shipped sample / frame rate pair). */
+int ddspp_resample_tables_host(int T, int N, int rule, int* lo, int* hi, float* w, int* aligned);
+/* FIR length Lw of ddsp.core.frequency_impulse_response(magnitudes[.., K], window_size) and the row count NJ of the
+ * even/odd tables (0: the shape has none -- use ddspp_fir_matrix_host + ddspp_fir_from_magnitudes). */
+int ddspp_fir_tables_shape(int K, int window_size, int* Lw, int* NJ);
+/* M[K,Lw] of ddspp_fir_from_magnitudes; uniq[Lw], mirror[Lw], *n_uniq (all three may be NULL): its symmetry lists.
+ * crop_rule 0: apply_window_to_impulse_response's crop indices as recalled from ddsp 3.7.0; 1: centred crop. */
+int ddspp_fir_matrix_host(int K, int window_size, int crop_rule, float* M, int* uniq, int* mirror, int* n_uniq);
+/* CE[K/2,NJ], CO[K/2,NJ], tap_idx[NJ,4], tap_we[NJ,4], tap_wo[NJ,4] of ddspp_fir_from_magnitudes_eo and
+ * ddspp_frequency_filter_eo* (K in {32, 64, 96, 128}, full-length window). */
+int ddspp_fir_eo_tables_host(int K, int window_size, float* CE, float* CO, int* tap_idx, float* tap_we, float* tap_wo);
+
 /* ---- frame -> sample control upsamplers ------------------------------------------------------ */
 
 /* ddsp.core.resample(x, N, method='linear') -- call site inharm_synth.py:117.

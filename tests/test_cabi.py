@@ -85,3 +85,53 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, null, one, one, one, null, 2, 65, 10, 1, 8, 96, 24000.0,
                                        0, 0, one, 1 << 30, null)
     assert rc == _lib.DDSPP_EINVAL and b'exceeds 64' in lib.ddspp_last_error()
+
+
+def test_host_table_builders_agree_with_the_python_layer():
+    """csrc/tables.cpp (what a caller without the Python layer uses) against core.py's numpy tables: integer tables and
+    the pure float32 products are identical; cosine-derived entries may differ by an ulp of a libm."""
+    import ctypes
+
+    import numpy as np
+
+    from ddsp_piano_amd import _lib, core
+    lib = _lib.load()
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    for n in (2, 64, 192, 257, 384, 190):
+        w = np.empty(n, np.float32)
+        assert lib.ddspp_hann_window_host(n, ptr(w)) == 0
+        assert np.abs(w - core._hann_window_np(n)).max() <= 1.2e-7
+    for rule, name in ((0, 'legacy'), (1, 'half_pixel')):
+        for T, N in ((750, 72000), (37, 1000), (12, 12 * 64), (34000, 34000 * 96)):
+            lo, hi, w = np.empty(N, np.int32), np.empty(N, np.int32), np.empty(N, np.float32)
+            al = ctypes.c_int(-1)
+            assert lib.ddspp_resample_tables_host(T, N, rule, ptr(lo), ptr(hi), ptr(w), ctypes.byref(al)) == 0
+            plo, phi, pw, pal = core._linear_tables_np(T, N, name)
+            assert np.array_equal(lo, plo) and np.array_equal(hi, phi) and np.array_equal(w, pw) and bool(al.value) == pal
+    for K, ws in ((96, 257), (64, 257), (32, 257), (128, 257), (200, 257), (65, 0), (129, 257), (200, 101)):
+        lw, nj = ctypes.c_int(), ctypes.c_int()
+        assert lib.ddspp_fir_tables_shape(K, ws, ctypes.byref(lw), ctypes.byref(nj)) == 0
+        for crop, cname in ((0, 'ddsp370'), (1, 'centred')):
+            pm = core._fir_matrix_np(K, ws, cname)
+            assert pm.shape == (K, lw.value)
+            m = np.empty((K, lw.value), np.float32)
+            uq, mr, nu = np.empty(lw.value, np.int32), np.empty(lw.value, np.int32), ctypes.c_int()
+            assert lib.ddspp_fir_matrix_host(K, ws, crop, ptr(m), ptr(uq), ptr(mr), ctypes.byref(nu)) == 0
+            assert np.abs(m - pm).max() <= 2e-7 * np.abs(pm).max()
+            puq, pmr = core._fir_symmetry_np(K, ws, cname)
+            assert np.array_equal(uq[:nu.value], puq) and np.array_equal(mr[:nu.value], pmr)
+        eo = core._fir_eo_tables_np(K, ws)
+        assert (eo is None) == (nj.value == 0)
+        if eo is not None:
+            ce, co, idx, we, wo, pnj, plw = eo
+            assert pnj == nj.value and plw == lw.value
+            c_ce, c_co = np.empty_like(ce), np.empty_like(co)
+            c_idx, c_we, c_wo = np.empty_like(idx), np.empty_like(we), np.empty_like(wo)
+            assert lib.ddspp_fir_eo_tables_host(K, ws, ptr(c_ce), ptr(c_co), ptr(c_idx), ptr(c_we), ptr(c_wo)) == 0
+            assert np.array_equal(c_idx, idx)
+            for a, b in ((c_ce, ce), (c_co, co), (c_we, we), (c_wo, wo)):
+                assert np.abs(a - b).max() <= 1.2e-7 * max(1.0, float(np.abs(b).max()))
+    assert lib.ddspp_fir_eo_tables_host(65, 0, None, None, None, None, None) == _lib.DDSPP_EINVAL
