@@ -28,11 +28,17 @@ __device__ __forceinline__ cf cdiv(cf a, cf b) {
     const float d = b.re * b.re + b.im * b.im;
     return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
 }
-__device__ __forceinline__ cf cexpi(float phi) {       // exp(j phi), accurate range reduction
-    float s, c;
-    sincosf(phi, &s, &c);
-    return {c, s};
+// Transcendentals (exp(j phi), 10^x) are evaluated in double and rounded once to float32: the correctly rounded
+// float32 value, which every float32 libm (TF's Eigen, numpy, the GPU's) scatters around by an ulp or two.  Near the
+// network's resonances cond(I - F D) ~ 1e4 turns one ulp of such scatter into 5e-4 of the response, so two
+// implementations only agree when both use THE float32 value; the oracle (oracle/ddsp_oracle.py fdn_get_late_ir) does
+// the same.  The arguments (wk * delay, -3 * delay / T60, ...) are formed in float32 exactly as the reference does.
+__device__ __forceinline__ cf cexpi(float phi) {       // exp(j phi)
+    double s, c;
+    sincos((double)phi, &s, &c);
+    return {(float)c, (float)s};
 }
+__device__ __forceinline__ float pow10_f32(float x) { return (float)pow(10.0, (double)x); }
 
 struct cd {
     double re, im;
@@ -85,8 +91,8 @@ __global__ void __launch_bounds__(256) fdn_transfer_kernel(const FdnParams p) {
         float dsum = 0.0f;
         for (int a = 0; a < A; ++a) dsum += p.delays_allpass[((size_t)b * D + d) * A + a];
         const float delay_sec = (dv + dsum) / p.sr;            //                            :265-268
-        const float k = powf(10.0f, -3.0f * delay_sec / t0);   //                            :272
-        const float kpi = powf(10.0f, -3.0f * delay_sec / (al * t0));
+        const float k = pow10_f32(-3.0f * delay_sec / t0);     //                            :272
+        const float kpi = pow10_f32(-3.0f * delay_sec / (al * t0));
         const float g = 2.0f * k * kpi / (k + kpi);
         const float pp = (k - kpi) / (k + kpi);
         filt[d] = cdiv(cf{g, 0.0f}, cf{1.0f - pp * ez.re + 1e-8f, -pp * ez.im});   // g / (1 - p z + 1e-8)  :289-291

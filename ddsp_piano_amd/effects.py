@@ -1,6 +1,6 @@
 """Reverb processors: ddsp.effects.Reverb (maestro-v2.gin:152-164, default_model.py:77-80) and the
-*apply* step of FeedbackDelayNetwork (ddsp_piano/modules/fdn_reverb.py:407-410).  The FDN impulse
-response *generation* (fdn_reverb.py:178-360) is control-side and out of scope."""
+FeedbackDelayNetwork (ddsp_piano/modules/fdn_reverb.py): impulse-response generation (:178-360),
+the apply step (:407-410), and the parameter-holding form the ENSTDkCl configs use as a DAG node."""
 from __future__ import annotations
 
 import torch
@@ -135,24 +135,94 @@ def fdn_impulse_response(input_gain, output_gain, gain_allpass, delays_allpass, 
 
 
 class FeedbackDelayNetwork(Processor):
-    """Frequency-sampled feedback delay network reverb, ddsp_piano/modules/fdn_reverb.py:20-410,
-    inference form (trainable=False: every parameter arrives through get_controls)."""
+    """Frequency-sampled feedback delay network reverb, ddsp_piano/modules/fdn_reverb.py:20-410.
+
+    trainable=False: every parameter arrives through get_controls (the reference's non-trainable branch, :387-396).
+    trainable=True: the layer holds its parameters -- the reference's weights of build() (:130-176): early_ir
+    [early_ir_length], input_gain / output_gain [D], time_rev_0_sec, alpha_tone (scalars; sigmoid applied in
+    get_controls), delays_allpass / gain_allpass [D, 4] and, with delay_trainable, delay_values [D].  This package
+    never trains them: they are initialised with the reference's initialisers (seeded) or set from a checkpoint with
+    load_parameters().  That makes the layer usable as the LAST node of the polyphonic DAG with reverb_controls = []
+    (configs/ENSTDkCl-8kHz.gin:85-86,100-104, ENSTDkCl-32kHz.gin).  The impulse response of fixed parameters is
+    computed once and kept until load_parameters() is called again."""
+
+    PARAMETER_NAMES = ('early_ir', 'input_gain', 'output_gain', 'time_rev_0_sec', 'alpha_tone', 'delay_values',
+                       'delays_allpass', 'gain_allpass')
 
     def __init__(self, trainable=False, name='DelayNetwork', sampling_rate=16000.0, delay_lines=8,
                  delay_values=None, delays_allpass=None, early_ir_length=200, early_reflections=6,
-                 time_control_bands=6, delay_trainable=False):
-        if trainable:
-            raise NotImplementedError('trainable FeedbackDelayNetwork is out of scope (inference only)')
+                 time_control_bands=6, delay_trainable=False, seed=0):
         super().__init__(name=name, trainable=trainable)
         self.sampling_rate = float(sampling_rate)
-        self.freq_points = int(2 * self.sampling_rate)
-        self.delay_values = tuple(delay_values) if delay_values is not None else FDN_DELAY_VALUES
-        self.delays_allpass = delays_allpass if delays_allpass is not None else FDN_DELAYS_ALLPASS
-        self.delay_lines = len(self.delay_values)
+        self.freq_points = int(2 * self.sampling_rate)                  # :81
         self.early_ir_length = early_ir_length
+        self.early_reflections = early_reflections
+        self.time_control_bands = time_control_bands
+        self.delay_trainable = delay_trainable
+        self._ir_cache = None
+        if trainable:
+            d = int(delay_lines)
+            g = torch.Generator().manual_seed(int(seed))
+
+            def normal(mean, std, *shape):
+                return (torch.randn(*shape, generator=g) * std + mean).to(torch.float32)
+            # the initialisers of build() (:130-176)
+            if delay_values is not None:
+                dv = torch.as_tensor(delay_values, dtype=torch.float32)
+                d = dv.numel()
+            elif delay_trainable:
+                dv = normal(400.0, 60.0, d)
+            else:
+                dv = torch.tensor(FDN_DELAY_VALUES, dtype=torch.float32)
+                d = dv.numel()
+            self._params = {
+                'early_ir': normal(0.0, 0.1, int(early_ir_length)),
+                'input_gain': normal(0.25, 0.1, d),
+                'output_gain': normal(0.25, 0.1, d),
+                'time_rev_0_sec': normal(2.0, 0.5, 1).abs().reshape(()),      # NonNeg constraint
+                'alpha_tone': normal(0.0, 0.1, 1).reshape(()),
+                'delay_values': dv,
+                'delays_allpass': normal(400.0, 60.0, d, 4),
+                'gain_allpass': normal(0.25, 0.1, d, 4),
+            }
+            self.delay_values = tuple(float(v) for v in dv)
+            self.delays_allpass = None
+        else:
+            self._params = None
+            self.delay_values = tuple(delay_values) if delay_values is not None else FDN_DELAY_VALUES
+            self.delays_allpass = delays_allpass if delays_allpass is not None else FDN_DELAYS_ALLPASS
+        self.delay_lines = len(self.delay_values)
 
     def __len__(self):
         return self.delay_lines
+
+    def parameters(self):
+        """The layer's own parameters (trainable=True), by the reference's weight roles."""
+        if self._params is None:
+            raise ValueError('a FeedbackDelayNetwork with trainable=False holds no parameters')
+        return dict(self._params)
+
+    def load_parameters(self, params):
+        """Set the layer's parameters (e.g. read from a checkpoint of the reference): a mapping with any of
+        PARAMETER_NAMES.  Shapes follow build(): [D], [D, A], scalars, [early_ir_length]."""
+        if self._params is None:
+            raise ValueError('a FeedbackDelayNetwork with trainable=False holds no parameters')
+        new = dict(self._params)
+        for k, v in params.items():
+            if k not in self.PARAMETER_NAMES:
+                raise KeyError(f'unknown FeedbackDelayNetwork parameter {k!r}; known: {self.PARAMETER_NAMES}')
+            new[k] = torch.as_tensor(v, dtype=torch.float32).detach().cpu().clone()
+        d = new['delay_values'].numel()
+        for k in ('input_gain', 'output_gain'):
+            if new[k].numel() != d:
+                raise ValueError(f'{k} has {new[k].numel()} entries for {d} delay lines')
+        for k in ('delays_allpass', 'gain_allpass'):
+            if new[k].dim() != 2 or new[k].shape[0] != d or new[k].shape != new['gain_allpass'].shape:
+                raise ValueError(f'{k} must be [{d}, stages], got {tuple(new[k].shape)}')
+        self._params = new
+        self.delay_values = tuple(float(v) for v in new['delay_values'])
+        self.delay_lines = d
+        self._ir_cache = None
 
     def get_ir(self, input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir):
         """fdn_reverb.py:336-360 (one instrument; returns [2 * sampling_rate])."""
@@ -168,6 +238,13 @@ class FeedbackDelayNetwork(Processor):
     def get_controls(self, audio_dry=None, input_gain=None, output_gain=None, gain_allpass=None,
                      delays_allpass=None, time_rev_0_sec=None, alpha_tone=None, early_ir=None):
         """fdn_reverb.py:362-405."""
+        if self.trainable:                                                         # :383-392
+            dev = core.tf_float32(audio_dry).device if audio_dry is not None else core.default_device()
+            if self._ir_cache is None or self._ir_cache.device != dev:
+                p = {k: v.to(dev) for k, v in self._params.items()}
+                self._ir_cache = self.get_ir(p['input_gain'], p['output_gain'], p['gain_allpass'], p['delays_allpass'],
+                                             p['time_rev_0_sec'], torch.sigmoid(p['alpha_tone']), p['early_ir'])
+            return {'audio': audio_dry, 'ir': self._ir_cache}
         ir = self.get_ir(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir)
         return {'audio': audio_dry, 'ir': ir}
 

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib, core
 from .core import _lib_, _ptr, _stream
-from .effects import FeedbackDelayNetworkApply, Reverb
+from .effects import FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb
 from .synths import FilteredNoise, InHarmonic, MultiAdd
 
 
@@ -63,9 +63,12 @@ def recognise(dag):
     if has_reverb:
         node = dag[-1]
         reverb = node[0]
-        if not isinstance(reverb, (Reverb, FeedbackDelayNetworkApply)) or getattr(reverb, 'trainable', False):
+        # ddsp.effects.Reverb with the impulse response as a control (maestro-v2.gin:152-153), or holding its own
+        # (trainable=True); a FeedbackDelayNetwork that holds its parameters, reverb_controls = []
+        # (ENSTDkCl-8kHz.gin:85-86) or takes them as controls; the FDN apply step
+        if not isinstance(reverb, (Reverb, FeedbackDelayNetworkApply, FeedbackDelayNetwork)):
             return None
-        if not node[1] or node[1][0] != add.name + '/signal' or len(node[1]) != 2:
+        if not node[1] or node[1][0] != add.name + '/signal':
             return None
         reverb_keys = list(node[1][1:])
         if any('/' in k for k in reverb_keys):

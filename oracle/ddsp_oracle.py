@@ -763,13 +763,22 @@ def fdn_get_late_ir(input_gain, output_gain, mixing_matrix, gain_allpass, delays
     input_gain = tf_float32(input_gain).astype(C64)
     output_gain = tf_float32(output_gain).astype(C64)
     mixing = tf_float32(mixing_matrix).astype(C64)
-    wk = ((F32(2 * np.pi) * np.arange(nb, dtype=F32)).astype(F32) / F32(freq_points)).astype(F32).astype(C64)  # :234-239
-    mj = C64(-1j)
-    z_d = np.stack([np.exp((mj * wk).astype(C64) * C64(np.floor(delay_values[d]))).astype(C64)
-                    for d in range(n_lines)], axis=1)                     # :241-250
+    # Transcendentals (exp(j phi), 10 ** x) are evaluated in float64 and rounded once to float32 -- the correctly
+    # rounded float32 value that any float32 libm (TF's, numpy's, the GPU's) approximates to an ulp or two.  Their
+    # ARGUMENTS are formed in float32 exactly as the reference forms them (wk * delay, -3 * delay / T60, ...).
+    def expj(phi32):                       # exp(1j * phi) for float32 phi
+        phi = np.asarray(phi32, F32).astype(np.float64)
+        return (np.cos(phi).astype(F32) + 1j * np.sin(phi).astype(F32)).astype(C64)
+
+    def pow10(x32):
+        return np.power(10.0, np.asarray(x32, F32).astype(np.float64)).astype(F32)
+
+    wk32 = ((F32(2 * np.pi) * np.arange(nb, dtype=F32)).astype(F32) / F32(freq_points)).astype(F32)   # :234-239
+    wk = wk32.astype(C64)
+    z_d = np.stack([expj(-(wk32 * np.floor(delay_values[d])).astype(F32)) for d in range(n_lines)], axis=1)   # :241-250
     d_eta = (delay_values - np.floor(delay_values)).astype(F32).astype(C64)
     eta = ((C64(1) - d_eta) / (C64(1) + d_eta)).astype(C64)               # :253-254
-    ez = np.exp((mj * wk).astype(C64)).astype(C64)
+    ez = expj(-wk32)
     allpass_interp = np.stack([((eta[d] + ez) / (C64(1) + eta[d] * ez)).astype(C64) for d in range(n_lines)],
                               axis=1)                                     # :255-261
     dd = (z_d * allpass_interp).astype(C64)                               # diagonal of diag_delay_matrix :263
@@ -778,12 +787,12 @@ def fdn_get_late_ir(input_gain, output_gain, mixing_matrix, gain_allpass, delays
     delay_sec = ((delay_values + np.sum(delays_allpass, axis=-1, dtype=F32)).astype(F32) / sr).astype(F32)   # :265-268
     t0 = F32(time_rev_0_sec)
     al = F32(alpha_tone)
-    k = np.power(F32(10.0), (F32(-3) * delay_sec / t0).astype(F32)).astype(F32)                 # :272
-    kpi = np.power(F32(10.0), (F32(-3) * delay_sec / (al * t0)).astype(F32)).astype(F32)        # :274-277
+    k = pow10((F32(-3) * delay_sec / t0).astype(F32))                     # :272
+    kpi = pow10((F32(-3) * delay_sec / (al * t0)).astype(F32))           # :274-277
     g = (F32(2) * k * kpi / (k + kpi)).astype(F32)
     p = ((k - kpi) / (k + kpi)).astype(F32)
     filt = (g.astype(C64)[None, :] / (C64(1) - p.astype(C64)[None, :] * ez[:, None] + C64(1e-8))).astype(C64)  # :289-291
-    z_delays = np.exp((C64(1j) * wk[:, None, None]).astype(C64) * delays_allpass.astype(C64)[None]).astype(C64)  # :302
+    z_delays = expj((wk32[:, None, None] * delays_allpass[None]).astype(F32))                                   # :302
     ga = gain_allpass.astype(C64)[None]
     allpass_transfer = np.prod(((C64(1) + ga * z_delays) / (ga + z_delays)).astype(C64), axis=-1).astype(C64)  # :305-308
     feedback = (filt[:, :, None] * mixing[None, :, :] * allpass_transfer[:, None, :]).astype(C64)               # :314-316

@@ -35,9 +35,13 @@ def test_fdn_impulse_response_matches_oracle(sr):
     # difference in a float32 transfer value (sincosf / powf of numpy vs the GPU maths library -- or of TF) moves
     # the bins around a resonance by cond x 6e-8 ~ 5e-4.  That is the agreement any two correct implementations
     # of the reference's float32 recipe can reach on a lively room; a damped room (below) agrees to round-off.
-    for other in (ref, exact):
-        err = rms_err(got, other)
-        assert err < 2e-3 * rms(other), f'{err:.3e} vs rms {rms(other):.3e}'
+    # Kernel and oracle both use THE float32 value of every transcendental (evaluated in double, rounded once), so
+    # against the float64 solve of the same float32 transfer values the agreement is round-off; the reference's own
+    # complex64 inverse (ref) sits cond x 6e-8 away from both.
+    err = rms_err(got, exact)
+    assert err < 2e-4 * rms(exact), f'{err:.3e} vs rms {rms(exact):.3e}'
+    err = rms_err(got, ref)
+    assert err < 2e-3 * rms(ref), f'{err:.3e} vs rms {rms(ref):.3e}'
     assert np.abs(got[:, :200] - ref[:, :200]).max() < 2e-3 * np.abs(ref).max()
 
 
@@ -69,5 +73,7 @@ def test_fdn_processor_and_fractional_delays():
     out = fdn.get_signal(**ctl).cpu().numpy()
     ref = O.fdn_get_signal(audio, ctl['ir'].cpu().numpy())           # the apply step, on the same ir
     assert rms_err(out, ref) < 1e-5 * rms(ref)
-    with pytest.raises(NotImplementedError):
-        dp.FeedbackDelayNetwork(trainable=True)
+    own = dp.FeedbackDelayNetwork(trainable=True, delay_lines=6, delay_trainable=True, sampling_rate=8000.0)
+    assert len(own) == 6 and set(own.parameters()) == set(own.PARAMETER_NAMES)
+    with pytest.raises(ValueError):
+        fdn.parameters()                       # a non-trainable network holds none
