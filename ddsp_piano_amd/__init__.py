@@ -10,6 +10,7 @@ from . import core  # noqa: F401
 from .core import exp_sigmoid, exp_tanh  # noqa: F401
 from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  # noqa: F401
                       fdn_impulse_response)
+from .noise_band_net import FilterBank, NoiseBandNetSynth  # noqa: F401
 from .midi_encoders import MIDIRoll2Conditioning, ensure_sequence_length, roll_to_conditioning  # noqa: F401
 from .parallelizer import Parallelizer  # noqa: F401
 from .polyphonic_dag import polyphonic_dag  # noqa: F401
@@ -18,6 +19,7 @@ from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiA
                      MultiInharmonic, SurrogateAdditive)
 
 __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
-           'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'Reverb',
+           'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'NoiseBandNetSynth',
+           'FilterBank', 'Reverb',
            'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag',
            'Parallelizer', 'MIDIRoll2Conditioning', 'ensure_sequence_length', 'roll_to_conditioning']

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
 SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
-           'noise.hip', 'reverb.hip', 'fdn.hip']
+           'noise.hip', 'noise_bands.hip', 'reverb.hip', 'fdn.hip']
 ARCH = 'gfx950'
 HEADERS = ['ddspp_common.h', 'osc_common.h']
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
@@ -125,6 +125,7 @@ SIGNATURES = {
     'ddspp_frequency_filter_eo_voices': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float] * 5 + [c_int] * 3 + [c_void_p]),
     'ddspp_time_varying_fir': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
+    'ddspp_noise_bands': (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     'ddspp_uniform_noise': (c_int, [c_void_p, c_size_t, c_uint64, c_uint64, c_void_p]),
     'ddspp_fft_size': (c_int, [c_int, c_int]),
     'ddspp_fftconv_plan_create': (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -243,6 +243,13 @@ int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes
                                      float gain, int n_voices, int voices_per_row, int voice_major,
                                      hipStream_t stream);
 
+/* NoiseBandNetSynth.get_signal -- filtered_noise_synth.py:213-262: audio[r, n] = sum_k noise_bands[(n mod noise_len
+ * - shift) mod noise_len, k] * amplitude_k(n), amplitude_k(n) = the chunk-wise ddsp.core.resample(method='linear') of
+ * amplitudes[r, :, k] given as tables lo/hi (int32[N], frame indices) and w (float32[N]).  noise_bands[noise_len, K] is
+ * the fixed loopable filtered-noise bank of get_noise_bands (:283-309), built on the host. */
+int ddspp_noise_bands(const float* amplitudes, const float* noise_bands, const int* lo, const int* hi, const float* w,
+                      float* audio, int R, int T, int K, int N, int noise_len, int shift, hipStream_t stream);
+
 /* stand-in for the reference's unseeded tf.random.uniform([B, N], -1, 1)
  * (filtered_noise_synth.py:39-40): Philox4x32-10, counter = offset + i / 4, key = seed. */
 int ddspp_uniform_noise(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t stream);

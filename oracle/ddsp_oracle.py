@@ -901,6 +901,94 @@ class SurrogateAdditive(Processor):
 
 
 # ---------------------------------------------------------------------------------------------
+# SURVEY.md 8f-3, second half: NoiseBandNetSynth + FilterBank, ddsp_piano/modules/filtered_noise_synth.py:51-317.
+# scipy.signal (kaiserord, firwin) is the same third-party code the reference calls.  Two TF random draws cannot be
+# restated (a seeded tf.random.uniform stream for the band phases :289-291, an unseeded one for the per-call roll
+# :226-230): both are explicit arguments here; the parity tests hand the same values to the HIP path.
+# ---------------------------------------------------------------------------------------------
+def nbn_frequency_bands(n_filters_linear, n_filters_log, linear_min_f, linear_max_f_cutoff_fs, sample_rate):
+    """FilterBank.get_frequency_bands (:103-113) with get_linear_bands (:86-90) and get_log_bands (:92-101)."""
+    linear_max_f = (sample_rate / 2) / linear_max_f_cutoff_fs
+    linear_bands = np.linspace(linear_min_f, linear_max_f, n_filters_linear)
+    linear_bands = np.vstack((linear_bands[:-1], linear_bands[1:])).T
+    if linear_max_f_cutoff_fs == 1:
+        # :108-109 `return linear_center_f` -- an undefined name: the reference raises NameError on this branch.
+        # The restatement returns the linear bands (the evident intent); no shipped configuration reaches it.
+        return linear_bands
+    log_bands = np.geomspace(start=linear_max_f, stop=sample_rate / 2, num=n_filters_log, endpoint=False)
+    log_bands = np.vstack((log_bands[:-1], log_bands[1:])).T
+    return np.concatenate((linear_bands, log_bands))
+
+
+def nbn_filter(cutoff, sample_rate, attenuation, pass_zero, transition_bandwidth=0.2, scale=True):
+    """FilterBank.get_filter (:121-133)."""
+    from scipy import signal
+    if isinstance(cutoff, np.ndarray):
+        bandwidth = abs(cutoff[1] - cutoff[0])
+    elif pass_zero is True:
+        bandwidth = cutoff
+    else:
+        bandwidth = abs((sample_rate / 2) - cutoff)
+    width = (bandwidth / (sample_rate / 2)) * transition_bandwidth
+    n_taps, beta = signal.kaiserord(ripple=attenuation, width=width)
+    n_taps = 2 * (n_taps // 2) + 1
+    return signal.firwin(numtaps=n_taps, cutoff=cutoff, window=('kaiser', beta), scale=scale, fs=sample_rate,
+                         pass_zero=pass_zero)
+
+
+def nbn_filterbank(n_band, sample_rate, attenuation=50, linear_min_f=20, linear_max_f_cutoff_fs=4):
+    """FilterBank.build_filterbank (:135-158) for NoiseBandNetSynth.build's arguments (:196-201)."""
+    bands = nbn_frequency_bands(n_band // 2, n_band // 2, linear_min_f, linear_max_f_cutoff_fs, sample_rate)
+    filters = []
+    for i in range(bands.shape[0]):
+        if i == 0:
+            filters.append(nbn_filter(bands[i, 0], sample_rate, attenuation, True))
+        filters.append(nbn_filter(bands[i], sample_rate, attenuation, False))
+        if i == bands.shape[0] - 1:
+            filters.append(nbn_filter(bands[i, -1], sample_rate, attenuation, False))
+    return filters
+
+
+def nbn_noise_bands(filters, min_noise_len, normalize, phase_noise):
+    """get_noise_bands (:283-309): [1, noise_len, n_band] float32 and noise_len; phase_noise [n_band, noise_len/2+1]."""
+    max_len = max(len(h) for h in filters)
+    noise_len = int(math.pow(2, math.ceil(math.log(max_len) / math.log(2)))) if max_len > min_noise_len else min_noise_len
+    padded = np.array([np.pad(h, (noise_len - len(h), 0)) for h in filters]).astype(F32)          # pad_filters :271-274
+    magnitude = np.abs(sfft.rfft(padded.astype(np.float64), axis=-1)).astype(F32).astype(C64)    # :277-280
+    phase = np.exp(1j * np.asarray(phase_noise, F32).astype(np.float64)).astype(C64)             # :292
+    phase[:, 0] = 0                                                                              # :293-297
+    phase[:, -1] = 0
+    bands = sfft.irfft((magnitude * phase).astype(np.complex128), n=noise_len, axis=-1).astype(F32)   # :299-300
+    if normalize:
+        bands = (bands / np.max(np.abs(bands))).astype(F32)                                      # :301-302
+    return np.transpose(bands[None], [0, 2, 1]), noise_len                                        # :303-306
+
+
+def nbn_get_signal(amplitudes, noise_bands, noise_len, upsampling, shift):
+    """NoiseBandNetSynth.get_signal (:213-262), the loop written as the reference writes it."""
+    amplitudes = tf_float32(amplitudes)
+    frame_len = int(noise_len / upsampling)
+    n_frames = math.ceil(amplitudes.shape[1] / frame_len)
+    nb = np.roll(noise_bands, shift, axis=1)                                                     # :224-231
+    n_samples = amplitudes.shape[1] * upsampling
+    if amplitudes.shape[1] / frame_len < 1:                                                      # :234-238
+        up = resample(amplitudes, n_samples)
+        return np.sum((nb[:, :n_samples, :] * up).astype(F32), axis=-1, dtype=F32)
+    signal = None
+    for i in range(n_frames):
+        if i == 0:
+            up = resample(amplitudes[:, :frame_len], frame_len * upsampling)
+            signal = np.sum((nb * up).astype(F32), axis=-1, dtype=F32)
+        elif i == n_frames - 1:
+            up = resample(amplitudes[:, i * frame_len:], frame_len * upsampling)
+            signal = np.concatenate([signal, np.sum((nb[:, :up.shape[1]] * up).astype(F32), axis=-1, dtype=F32)], axis=1)
+        else:
+            up = resample(amplitudes[:, i * frame_len:(i + 1) * frame_len], frame_len * upsampling)
+            signal = np.concatenate([signal, np.sum((nb * up).astype(F32), axis=-1, dtype=F32)], axis=1)
+    return signal[:, :n_samples]
+
+
+# ---------------------------------------------------------------------------------------------
 # Input edge: piano roll -> polyphonic conditioning (SURVEY.md 8f-4).
 #
 # *** This part IS pinned ***: ddsp_piano/utils/midi_encoders.py is plain NumPy, so the reference
