@@ -505,7 +505,8 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
-                        sample_rate, spans=0, voice_major=False, audible=None, split_last=False, inharm_coef=None):
+                        sample_rate, spans=0, voice_major=False, audible=None, split_last=False, inharm_coef=None,
+                        phase_state=None):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
@@ -514,7 +515,8 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     per-frame counts of InHarmonic._controls(want_counts=True) (saves a scan of the [R, T, H] controls).
     split_last=True returns (sum of voices 0 .. P-2, the last voice's stem): what the outputs dictionary of the
     reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37).
-    harmonic_shifts=None with inharm_coef [R, T] (raw): the kernels form the shifts themselves (get_inharmonic_freq)."""
+    harmonic_shifts=None with inharm_coef [R, T] (raw): the kernels form the shifts themselves (get_inharmonic_freq).
+    phase_state [R, S * H]: streaming -- the oscillators continue from the state oscillator_phase_state left."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
@@ -536,9 +538,32 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
         _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
         _ptr(inharm_coef) if (inharm_coef is not None and harmonic_shifts is None) else null,
         ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(wlin), _ptr(whann),
-        _ptr(out), _ptr(last), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes,
-        _stream()))
+        _ptr(phase_state), _ptr(out), _ptr(last), b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)),
+        _ptr(ws), nbytes, _stream()))
     return (out, last) if split_last else out
+
+
+def oscillator_phase_state(f0_hz, n_chunks, upsampling, sample_rate, harmonic_shifts=None, inharm_coef=None,
+                           n_harmonics=None, phase_state=None, audible=None):
+    """The state an oscillator bank carries across calls: phase_state [R, S * H] after the first n_chunks 1000-sample
+    chunks of these controls (f0_hz [R, T, S]; harmonic_shifts [R, T, H] or raw inharm_coef [R, T]).  See
+    ddspp_oscillator_phase_state."""
+    r, t, s = f0_hz.shape
+    h = int(harmonic_shifts.shape[-1]) if harmonic_shifts is not None else int(n_harmonics)
+    dev = f0_hz.device
+    _, _, wlin, _ = linear_tables(t, t * int(upsampling), dev)
+    lib = _lib_()
+    nbytes = int(lib.ddspp_oscillator_phase_state_workspace_bytes(r, s, h, int(n_chunks)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((r, s * h), dtype=torch.float32, device=dev)
+    dummy = None
+    if harmonic_shifts is None and inharm_coef is None:
+        dummy = torch.zeros((r, t, h), dtype=torch.float32, device=dev)
+    _lib.check(lib.ddspp_oscillator_phase_state(
+        _ptr(f0_hz), _ptr(harmonic_shifts), _ptr(inharm_coef) if harmonic_shifts is None else ctypes.c_void_p(0), _ptr(dummy),
+        ctypes.c_void_p(audible.data_ptr()) if audible is not None else ctypes.c_void_p(0), _ptr(wlin), _ptr(phase_state),
+        _ptr(out), r, t, s, h, int(upsampling), float(sample_rate), int(n_chunks), _ptr(ws), nbytes, _stream()))
+    return out
 
 
 def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None, harmonic_distribution=None,

@@ -106,7 +106,7 @@ bank_compact_kernel(const OscParams p) {
         asum[j] = 0.0f;
         off[j] = 0.0f;
     }
-    if (p.spans > 1) {
+    if (p.spans > 1 || p.state_in) {       // (a streamed call's first span starts from the carried state)
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             asum[j] = p.astart[((size_t)lrow[j] * p.spans + span) * p.VP + vidx[j]];

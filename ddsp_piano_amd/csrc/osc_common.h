@@ -37,6 +37,9 @@ struct OscParams {
     // slots [wmax_a, wmax) those of the last voice (split_last = 1: the caller wants that voice's stem on its own)
     int split_last, wmax_a;
     float* __restrict__ out_last;      // [B, N] the last voice's stem (split_last = 1), `out` then holds the other voices' sum
+    // streaming: the float32 running sum of chunk end phases (ddsp.core.angular_cumsum's cumsum over chunks) each
+    // oscillator starts from, [rows, V]; null = 0 (a signal that starts here)
+    const float* __restrict__ state_in;
 };
 
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };

@@ -664,7 +664,8 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     float asum[VPL], e_memo[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        asum[j] = 0.0f;
+        // streaming: the row continues a signal whose chunk offsets have already summed up to state_in
+        asum[j] = (p.state_in && vidx[j] < p.V) ? p.state_in[(size_t)row * p.V + vidx[j]] : 0.0f;
         e_memo[j] = 0.0f;
     }
     int memo_t = -1;                   // first frame of the chunk the memo was taken from (-1: none)
@@ -925,7 +926,8 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
 constexpr int SCAN_CT = 256;           // chunks per tile: 64 KB of LDS, 64 registers per thread
 __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __restrict__ ework,
                                                             float* __restrict__ astart, int R,
-                                                            int npre, int VP, int spans, int cps) {
+                                                            int npre, int VP, int spans, int cps,
+                                                            const float* __restrict__ state_in, int V) {
     __shared__ float tile[SCAN_CT * 64];
     const int groups = VP / 64;
     const int row = blockIdx.x / groups, v0 = (blockIdx.x - row * groups) * 64;
@@ -940,7 +942,7 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
         }
     };
     fetch(0);
-    float a = 0.0f;
+    float a = (state_in && v0 + lane < V) ? state_in[(size_t)row * V + v0 + lane] : 0.0f;
     int span = 0, until = 0;                              // chunks left before the next span starts
     float* dst = astart + (size_t)row * spans * VP + v0 + lane;
     for (int c0 = 0; c0 <= npre; c0 += SCAN_CT) {
@@ -975,11 +977,12 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
 // Few chunks (a 3 s segment has 72): one thread per chain, loads batched by 16.
 __global__ void __launch_bounds__(256) osc_offset_scan_short_kernel(const float* __restrict__ ework,
                                                                   float* __restrict__ astart, int R,
-                                                                  int npre, int VP, int spans, int cps) {
+                                                                  int npre, int VP, int spans, int cps,
+                                                                  const float* __restrict__ state_in, int V) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)R * VP) return;
     const int row = (int)(gid / VP), v = (int)(gid - (size_t)row * VP);
-    float a = 0.0f;
+    float a = (state_in && v < V) ? state_in[(size_t)row * V + v] : 0.0f;
     int span = 0;
     constexpr int NB = 16;
     for (int c0 = 0; c0 <= npre; c0 += NB) {
@@ -1001,14 +1004,14 @@ __global__ void __launch_bounds__(256) osc_offset_scan_short_kernel(const float*
 static int env_int(const char* name, int dflt);
 
 static void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
-                               hipStream_t stream) {
+                               hipStream_t stream, const float* state_in = nullptr, int V = 0) {
     const size_t nthr = (size_t)R * VP;
     if (npre > SCAN_CT && !env_int("DDSPP_OSC_SHORT_SCAN", 0))
         hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)(nthr / 64)), dim3(256), 0, stream, ework, astart, R,
-                           npre, VP, spans, cps);
+                           npre, VP, spans, cps, state_in, V);
     else
         hipLaunchKernelGGL(osc_offset_scan_short_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                           ework, astart, R, npre, VP, spans, cps);
+                           ework, astart, R, npre, VP, spans, cps, state_in, V);
 }
 
 // nk[b, span, p] = number of leading harmonics of voice p that have a non-zero amplitude
@@ -1239,6 +1242,51 @@ static int dispatch_vpl(int vpl, const OscParams& p, bool angular, bool sum, hip
     return DDSPP_OK;
 }
 
+// Span start offsets astart[row, span, v] for every (row, oscillator) of R rows (p carries the plan: spans, cps, npre,
+// and the optional streaming state the sums start from): memoised sequential walk when the rows fill the chip,
+// chunk-parallel pre-pass + scan for a few long rows (whole-file mode).
+static void span_starts(const OscParams& p, int R, int V, int vpl_pre, float* astart, float* ework, hipStream_t stream) {
+    const int VP = p.VP, U = p.U;
+    OscParams q = p;
+    q.R = R; q.groups = 1; q.vgrp = V;
+    const bool memo = R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
+    if (memo) {
+        q.ework = astart;
+        // one wavefront per 64 oscillators of a row when the rows alone leave SIMDs with a single wavefront: the walk
+        // is a chain of memory latencies (frames in batches), and 64 loads per batch fit the 63-deep load counter
+        const bool split = V % 64 == 0 && (long long)R * (V / 64) <= 8192 && !env_int("DDSPP_OSC_PREPASS_WHOLE_ROWS", 0);
+        const int tasks = split ? R * (V / 64) : R;
+        if (split) {
+            q.groups = V / 64;
+            q.vgrp = 64;
+        }
+        launch_memo_prepass(split ? 1 : vpl_pre, q, tasks, stream);
+        return;
+    }
+    q.ework = ework;
+    if (q.npre > 0) {
+        const bool chunk_kernel = vpl_pre <= 2 && DDSPP_CHUNK / U + 3 <= PRE_FR && !env_int("DDSPP_OSC_OLD_CHUNK_PREPASS", 0);
+        if (chunk_kernel) {
+            const unsigned wgs = (unsigned)((R * q.npre + 3) / 4);
+            const size_t clds = (size_t)4 * PRE_FR * 64 * vpl_pre * sizeof(float);
+            if (vpl_pre == 1) hipLaunchKernelGGL((osc_prepass_chunk_kernel<1>), dim3(wgs), dim3(256), clds, stream, q);
+            else hipLaunchKernelGGL((osc_prepass_chunk_kernel<2>), dim3(wgs), dim3(256), clds, stream, q);
+        } else {
+            const dim3 grid((unsigned)(R * q.npre)), blk(64);
+            const size_t plds = ((size_t)(TILE * TSTRIDE) + 2 * 32) * sizeof(float);
+            switch (vpl_pre) {
+                case 1: hipLaunchKernelGGL((osc_kernel<1, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 2: hipLaunchKernelGGL((osc_kernel<2, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 3: hipLaunchKernelGGL((osc_kernel<3, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 4: hipLaunchKernelGGL((osc_kernel<4, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 6: hipLaunchKernelGGL((osc_kernel<6, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                default: hipLaunchKernelGGL((osc_kernel<8, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+            }
+        }
+    }
+    launch_offset_scan(ework, astart, R, q.npre, VP, p.spans, p.cps, stream, p.state_in, V);
+}
+
 }  // namespace ddspp
 
 using namespace ddspp;
@@ -1351,8 +1399,8 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
 
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const float* inharm_coef, const int* audible,
-                              const float* wlin, const float* whann, float* audio, float* audio_last,
-                              int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                              const float* wlin, const float* whann, const float* phase_state_in, float* audio,
+                              float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
                   "polyphonic_additive: null buffer");
@@ -1393,6 +1441,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.f0 = f0_hz; p.amp = amplitudes; p.hd = harmonic_distribution; p.shifts = harmonic_shifts;
     p.inh = harmonic_shifts ? nullptr : inharm_coef;       // shifts formed in the kernels from the raw inharm_coef
     p.audible = audible;
+    p.state_in = phase_state_in;
     p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0) | (env_int("DDSPP_BANK_ABLATE", 0) << 8);
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
@@ -1401,45 +1450,8 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
     p.astart = astart;
 
-    // 1. span start offsets for every (row, oscillator) over rows = B * P: memoised sequential walk when
-    //    the rows fill the chip, chunk-parallel pre-pass + scan for a few long rows (whole-file mode)
-    if (sp > 1) {
-        OscParams q = p;
-        q.R = R; q.groups = 1; q.vgrp = V;
-        const bool memo = R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
-        if (memo) {
-            q.ework = astart;
-            // one wavefront per 64 oscillators of a row when the rows alone leave SIMDs with a single wavefront: the walk
-            // is a chain of memory latencies (frames in batches), and 64 loads per batch fit the 63-deep load counter
-            const bool split = V % 64 == 0 && (long long)R * (V / 64) <= 8192 && !env_int("DDSPP_OSC_PREPASS_WHOLE_ROWS", 0);
-            const int tasks = split ? R * (V / 64) : R;
-            if (split) {
-                q.groups = V / 64;
-                q.vgrp = 64;
-            }
-            launch_memo_prepass(split ? 1 : vpl_pre, q, tasks, stream);
-        } else {
-            q.ework = ework;
-            const bool chunk_kernel = vpl_pre <= 2 && DDSPP_CHUNK / U + 3 <= PRE_FR && !env_int("DDSPP_OSC_OLD_CHUNK_PREPASS", 0);
-            if (chunk_kernel) {
-                const unsigned wgs = (unsigned)((R * q.npre + 3) / 4);
-                const size_t clds = (size_t)4 * PRE_FR * 64 * vpl_pre * sizeof(float);
-                if (vpl_pre == 1) hipLaunchKernelGGL((osc_prepass_chunk_kernel<1>), dim3(wgs), dim3(256), clds, stream, q);
-                else hipLaunchKernelGGL((osc_prepass_chunk_kernel<2>), dim3(wgs), dim3(256), clds, stream, q);
-            }
-            const dim3 grid((unsigned)(R * q.npre)), blk(64);
-            const size_t plds = ((size_t)(TILE * TSTRIDE) + 2 * 32) * sizeof(float);
-            if (!chunk_kernel) switch (vpl_pre) {
-                case 1: hipLaunchKernelGGL((osc_kernel<1, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 2: hipLaunchKernelGGL((osc_kernel<2, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 3: hipLaunchKernelGGL((osc_kernel<3, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 4: hipLaunchKernelGGL((osc_kernel<4, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 6: hipLaunchKernelGGL((osc_kernel<6, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                default: hipLaunchKernelGGL((osc_kernel<8, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-            }
-            launch_offset_scan(ework, astart, R, q.npre, VP, sp, cps, stream);
-        }
-    }
+    // 1. span start offsets for every (row, oscillator) over rows = B * P
+    if (sp > 1 || p.state_in) span_starts(p, R, V, vpl_pre, astart, ework, stream);
     // 2. audible-harmonic counts per (segment, span, voice)
     if (audible)
         hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
@@ -1462,6 +1474,53 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
         launch_bank_slot_sum(p, audio, split_last ? audio_last : nullptr, stream);
     }
     DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// Streaming: the state an oscillator bank carries from one call to the next.  ddsp.core.angular_cumsum restarts the
+// phase every 1000 samples and adds the float32 running sum of the chunks' end phases; a call that renders a later
+// piece of the same signal therefore needs exactly that sum per (row, oscillator).  phase_state_out[R, V] =
+// phase_state_in (or 0) + the end phases of the first n_chunks 1000-sample chunks of these controls, accumulated
+// sequentially in float32 -- what a single long call would hold at that point, bit for bit.  T * U >= n_chunks * 1000.
+size_t ddspp_oscillator_phase_state_workspace_bytes(int R, int S, int H, int n_chunks) {
+    if (R <= 0 || S <= 0 || H <= 0 || n_chunks < 0) return 0;
+    const size_t VP = (size_t)pick_vpl(S * H) * 64;
+    return 2 * (size_t)R * (n_chunks + 1) * VP * sizeof(float) + 1024;
+}
+
+int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shifts, const float* inharm_coef,
+                                 const float* harmonic_distribution, const int* audible, const float* wlin,
+                                 const float* phase_state_in, float* phase_state_out, int R, int T, int S, int H, int U,
+                                 float sample_rate, int n_chunks, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
+    DDSPP_REQUIRE(f0_hz && wlin && phase_state_out && workspace && (harmonic_shifts || inharm_coef || harmonic_distribution),
+                  "oscillator_phase_state: null buffer");
+    DDSPP_REQUIRE(R > 0 && T > 0 && S > 0 && H > 0 && U > 0 && U % BLK == 0 && n_chunks >= 0, "oscillator_phase_state: bad dims");
+    const int V = S * H, N = T * U;
+    DDSPP_REQUIRE(pick_vpl(V) != 0, "oscillator_phase_state: n_substrings*n_harmonics=%d exceeds 512", V);
+    DDSPP_REQUIRE((long long)n_chunks * DDSPP_CHUNK <= N, "oscillator_phase_state: %d chunks exceed the %d samples given",
+                  n_chunks, N);
+    DDSPP_REQUIRE(workspace_bytes >= ddspp_oscillator_phase_state_workspace_bytes(R, S, H, n_chunks),
+                  "oscillator_phase_state: workspace too small");
+    const int vpl_pre = pick_vpl(V), VP = vpl_pre * 64;
+    float* astart = (float*)workspace;
+    float* ework = astart + (size_t)R * (n_chunks + 1) * VP;
+    OscParams p{};
+    p.f0 = f0_hz; p.shifts = harmonic_shifts; p.inh = harmonic_shifts ? nullptr : inharm_coef;
+    p.hd = harmonic_distribution;      // read (and ignored) only when there are neither shifts nor inharm_coef
+    p.audible = audible; p.state_in = phase_state_in;
+    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
+    p.wlin = wlin;
+    p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
+    p.spans = n_chunks + 1; p.cps = 1; p.nchunks = n_chunks + 1; p.npre = n_chunks;
+    p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
+    p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.astart = astart;
+    span_starts(p, R, V, vpl_pre, astart, ework, stream);
+    DDSPP_LAUNCH_CHECK();
+    DDSPP_HIP_CHECK(hipMemcpy2DAsync(phase_state_out, (size_t)V * sizeof(float), astart + (size_t)n_chunks * VP,
+                                     (size_t)(n_chunks + 1) * VP * sizeof(float), (size_t)V * sizeof(float), R,
+                                     hipMemcpyDeviceToDevice, stream));
     return DDSPP_OK;
 }
 

@@ -76,3 +76,40 @@ def synthesize_sharded(processor_group, features, group=None):
     if global_batch % world == 0:
         return gather_audio(local, group=group)
     return gather_audio_uneven(local, global_batch, group=group)
+
+
+# ---- one long file over several GPUs: shard TIME (ddsp_piano synthesize_midi_file.py renders one file per call) -------
+def time_shard_range(n_frames, world_size, rank, block=125):
+    """Frames [lo, hi) of a file of n_frames control frames owned by ``rank``: contiguous, whole blocks of `block`
+    frames (1000-sample chunk boundaries, streaming.block_frames), the remainder on the last rank."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} outside world of size {world_size}')
+    n_blocks = n_frames // block
+    lo_b, hi_b = shard_range(n_blocks, world_size, rank)
+    lo, hi = lo_b * block, hi_b * block
+    if rank == world_size - 1:
+        hi = n_frames
+    return lo, hi
+
+
+def synthesize_time_sharded(make_synth, features, group=None, noise=None):
+    """Every rank holds the file's controls ({key_i: [B, T, C]}); rank r renders its time range from scratch
+    (streaming.render_range: a phase-only pass gives the oscillator state at its first frame, the reverb history is
+    rendered L samples early) and the pieces are all-gathered along time.  Returns [B, T * U] on every rank."""
+    from . import streaming
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    syn = make_synth()
+    t = next(v.shape[1] for k, v in features.items() if k not in syn.rkeys)
+    lo, hi = time_shard_range(t, world, rank, syn.block)
+    mine = streaming.render_range(make_synth, features, lo, hi, noise=noise) if hi > lo else None
+    b = next(v.shape[0] for k, v in features.items() if k not in syn.rkeys)
+    sizes = [(time_shard_range(t, world, r, syn.block)[1] - time_shard_range(t, world, r, syn.block)[0]) * syn.U
+             for r in range(world)]
+    biggest = max(sizes)
+    dev = next(v.device for k, v in features.items() if k not in syn.rkeys)
+    pad = torch.zeros((b, biggest), dtype=torch.float32, device=dev)
+    if mine is not None:
+        pad[:, :mine.shape[1]] = mine
+    full = gather_audio(pad.t().contiguous(), group=group)          # [world * biggest, B]: rank-major along time
+    parts = [full[r * biggest: r * biggest + sizes[r]] for r in range(world)]
+    return torch.cat(parts, dim=0).t().contiguous()

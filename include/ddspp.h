@@ -118,16 +118,32 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
  * harmonic_shifts = sqrt(k^2 max(inharm_coef, 0) + 1) - 1 (get_inharmonic_freq, inharm_synth.py:37-44) per lane and
  * frame -- bit for bit what ddspp_inharmonic_controls writes -- and the [R,T,H] tensor need not exist.
  * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.
+ * phase_state_in[R, S*H] (may be NULL): streaming -- these controls continue a signal; every oscillator starts from the
+ * float32 running sum of chunk end phases the previous call left (ddspp_oscillator_phase_state).  The call must start
+ * on a 1000-sample chunk boundary of the whole signal (a multiple of lcm(U, 1000) / U frames).
  * audio_last[B, T*U] (may be NULL): when given, the LAST voice's stem goes there and `audio` holds the sum of voices
  * 0 .. P-2 -- the reference's DAG re-uses one additive processor for all voices, so its outputs dictionary keeps the
  * last voice's signal next to the mix (polyphonic_dag.py:28-37, piano_model.py:160-164). */
 size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                               const float* harmonic_shifts, const float* inharm_coef, const int* audible,
-                              const float* wlin,
-                              const float* whann, float* audio, float* audio_last,
-                              int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                              const float* wlin, const float* whann, const float* phase_state_in, float* audio,
+                              float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* Streaming state of the oscillator banks (synthesize_midi_file.py:41-73 renders minutes of audio; this lets a caller do
+ * it piecewise, or shard one file's TIME over several GPUs).  ddsp.core.angular_cumsum restarts the phase every 1000
+ * samples and adds the float32 running sum of the chunks' end phases, so the only thing a later piece of the same signal
+ * needs is that sum per (row, oscillator): phase_state_out[R, S*H] = phase_state_in (NULL: 0) + the end phases of the
+ * first n_chunks chunks of these controls, added sequentially in float32 -- bit for bit what one long call holds there.
+ * Controls as ddspp_polyphonic_additive (harmonic_shifts, or inharm_coef, or neither + harmonic_distribution as a dummy
+ * [R,T,H] buffer); T * U >= n_chunks * 1000. */
+size_t ddspp_oscillator_phase_state_workspace_bytes(int R, int S, int H, int n_chunks);
+int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shifts, const float* inharm_coef,
+                                 const float* harmonic_distribution, const int* audible, const float* wlin,
+                                 const float* phase_state_in, float* phase_state_out, int R, int T, int S, int H, int U,
+                                 float sample_rate, int n_chunks, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream);
 
 /* ---- get_controls ---------------------------------------------------------------------------- */
 

@@ -82,7 +82,7 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     assert rc == _lib.DDSPP_EINVAL and b'not supported' in lib.ddspp_last_error()
     assert lib.ddspp_fftconv_transform_ir(null, one, 1, one, 0, null) == _lib.DDSPP_EINVAL
     assert lib.ddspp_fftconv_execute_prepared(null, one, 10, one, 10, 0, 1, one, 0, null) == _lib.DDSPP_EINVAL
-    rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, null, one, one, one, null, 2, 65, 10, 1, 8, 96, 24000.0,
+    rc = lib.ddspp_polyphonic_additive(one, one, one, one, null, null, one, one, null, one, null, 2, 65, 10, 1, 8, 96, 24000.0,
                                        0, 0, one, 1 << 30, null)
     assert rc == _lib.DDSPP_EINVAL and b'exceeds 64' in lib.ddspp_last_error()
 

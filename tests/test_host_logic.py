@@ -1,5 +1,7 @@
 """CPU: host side of the product (no kernels run): Processor protocol, DAG walking, DAG recognition,
 table builders against the oracle, error behaviour, sharding arithmetic."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,3 +211,39 @@ def test_parallelizer_merges_and_unmerges_like_the_reference():
         for i in range(P):
             assert torch.equal(un[f'{k}_{i}'], v[i * B:(i + 1) * B])
             assert un[f'{k}_{i}'].data_ptr() == v[i * B:(i + 1) * B].data_ptr()       # a view, not a copy
+
+
+def test_time_shard_ranges_are_whole_blocks():
+    """One long file over several GPUs: every rank's frame range starts on a 1000-sample chunk boundary (a multiple of
+    125 frames) and the ranges tile the file."""
+    from ddsp_piano_amd import parallel, streaming
+    assert [streaming.block_frames(u) for u in (32, 64, 96, 128, 192)] == [125] * 5
+    for t, world in ((34000, 8), (1130, 2), (1000, 3), (100, 4)):
+        rs = [parallel.time_shard_range(t, world, r) for r in range(world)]
+        assert rs[0][0] == 0 and rs[-1][1] == t
+        for (lo, hi), (lo2, _) in zip(rs, rs[1:]):
+            assert hi == lo2 and lo % 125 == 0 and hi % 125 == 0
+    with pytest.raises(ValueError):
+        parallel.time_shard_range(1000, 2, 2)
+
+
+def test_bench_launcher_logic(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher starts N ranks itself, refuses when the box has fewer GPUs, and a
+    launcher that started a different number of ranks is an error -- never a silent one-GPU number."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    assert bench.launcher_command(1, {}, [], 0) is None
+    assert bench.launcher_command(2, {'WORLD_SIZE': '2'}, [], 0) is None
+    with pytest.raises(SystemExit, match='1 GPU'):
+        bench.launcher_command(2, {}, ['--gpus', '2'], 1)
+    with pytest.raises(SystemExit, match='WORLD_SIZE=2'):
+        bench.launcher_command(4, {'WORLD_SIZE': '2'}, [], 8)
+    cmd = bench.launcher_command(8, {}, ['--gpus', '8', '--steps', '3'], 8)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd
+    assert cmd[-4:] == ['--gpus', '8', '--steps', '3'] and '127.0.0.1' in cmd
+    args = bench.parse(['--gpus', '2', '--no-single-stream'])
+    assert args.no_extras and args.call_form == 'outputs_dict'
