@@ -86,6 +86,9 @@ SIGNATURES = {
     'ddspp_version': (c_int, []),
     'ddspp_target_arch': (c_char_p, []),
     'ddspp_last_error': (c_char_p, []),
+    'ddspp_option': (c_int, [c_char_p, c_int]),
+    'ddspp_set_option': (c_int, [c_char_p, c_int]),
+    'ddspp_reload_options': (None, []),
     'ddspp_hann_window_host': (c_int, [c_int, c_void_p]),
     'ddspp_resample_tables_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),
@@ -156,20 +159,38 @@ SIGNATURES = {
 _lib = None
 
 
+def _have_hipcc():
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def load():
-    """Load libddspp.so (building it first if hipcc is available and the sources are newer)."""
+    """Load libddspp.so.  A missing library is built; a library OLDER than its sources is rebuilt when hipcc is here
+    (an edited kernel never runs as a stale binary) and refused with an error otherwise."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        try:
-            build(verbose=False)
-        except Exception as e:  # noqa: BLE001
-            raise RuntimeError(
-                f'libddspp.so is missing at {LIB_PATH} and could not be built ({e}). '
-                'The DDSP-Piano MI355X synthesis path has no CPU fallback: run '
-                '`python -c "import __graft_entry__ as g; g.build()"` on a machine with hipcc.') from e
-    path = os.environ.get('DDSPP_LIB') or LIB_PATH        # DDSPP_LIB: another build of the same sources (A/B timing)
+    custom = os.environ.get('DDSPP_LIB')
+    if not custom and _needs_build():
+        missing = not os.path.exists(LIB_PATH)
+        if _have_hipcc():
+            try:
+                build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(
+                    f'libddspp.so at {LIB_PATH} is {"missing" if missing else "older than csrc/"} and could not be built '
+                    f'({e}).  The DDSP-Piano MI355X synthesis path has no CPU fallback: run '
+                    '`python -c "import __graft_entry__ as g; g.build()"` on a machine with hipcc.') from e
+        elif missing:
+            raise RuntimeError(f'libddspp.so is missing at {LIB_PATH} and hipcc is not available to build it.  '
+                               'There is no CPU fallback for the synthesis path.')
+        else:
+            raise RuntimeError(f'{LIB_PATH} is older than its sources under csrc/ and hipcc is not available to rebuild '
+                               'it: refusing to run a stale kernel library.')
+    path = custom or LIB_PATH                             # DDSPP_LIB: another build of the same sources (A/B timing)
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:
@@ -180,6 +201,28 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+class Options:
+    """Tuning / A-B switches of the host layer, read from the environment ONCE (import time) -- nothing on the call path
+    reads os.environ.  reload() re-reads them and tells the library to forget its cached options too (tests and the A/B
+    tools change variables in-process)."""
+
+    def __init__(self):
+        self.reload(_library=False)
+
+    def reload(self, _library=True):
+        env = os.environ
+        self.voice_sums = int(env.get('DDSPP_VOICE_SUMS', 0))            # voices summed per noise row (0: pick)
+        self.no_voice_sums = env.get('DDSPP_NO_VOICE_SUMS') == '1'
+        self.side_stream_min = int(env.get('DDSPP_SIDE_STREAM_MIN', 1 << 24))
+        self.no_side_stream = env.get('DDSPP_NO_SIDE_STREAM') == '1'
+        self.no_early_ir = env.get('DDSPP_NO_EARLY_IR') == '1'
+        if _library and _lib is not None:
+            _lib.ddspp_reload_options()
+
+
+options = Options()
 
 
 def last_error():

@@ -690,34 +690,84 @@ def get_fft_size(frame_size, ir_size, power_of_2=True):
     return int(convolved_frame_size)
 
 
-_plan_cache = {}
-_plan_lock = threading.Lock()
+class _PlanCache:
+    """Bounded cache of library-owned rocFFT plans: least recently used plans are destroyed when the cache is full
+    (whole-file synthesis with ever-changing lengths would otherwise pile plans up), plans pinned by an unfinished
+    two-phase call are never evicted, and every plan carries a lock: its execution info (stream, work buffer) is set
+    at enqueue time, so two host threads must not enqueue on the same plan at once."""
+
+    def __init__(self, destroy_name, maxsize=24):
+        self._destroy_name = destroy_name
+        self._maxsize = maxsize
+        self._entries = {}          # key -> [handle, lock, pins]
+        self._order = []
+        self._lock = threading.Lock()
+        atexit.register(self.clear)
+
+    def get(self, key, create):
+        with self._lock:
+            e = self._entries.get(key)
+            if e is None:
+                e = self._entries[key] = [create(), threading.Lock(), 0]
+                self._order.append(key)
+                self._evict()
+            else:
+                self._order.remove(key)
+                self._order.append(key)
+            return e
+
+    def _evict(self):
+        lib = None
+        i = 0
+        while len(self._order) > self._maxsize and i < len(self._order):
+            key = self._order[i]
+            e = self._entries[key]
+            if e[2] > 0 or e[1].locked():
+                i += 1
+                continue
+            lib = lib or _lib_()
+            getattr(lib, self._destroy_name)(e[0])
+            del self._entries[key]
+            self._order.pop(i)
+
+    def pin(self, entry, delta):
+        with self._lock:
+            entry[2] += delta
+            if delta < 0:
+                self._evict()
+
+    def clear(self):
+        try:
+            lib = _lib_()
+        except Exception:  # noqa: BLE001 -- interpreter / HIP runtime already going down
+            return
+        with self._lock:
+            for e in self._entries.values():
+                try:
+                    getattr(lib, self._destroy_name)(e[0])
+                except Exception:  # noqa: BLE001
+                    pass
+            self._entries.clear()
+            self._order.clear()
+
+    def __len__(self):
+        return len(self._entries)
+
+
+_plan_cache = _PlanCache('ddspp_fftconv_plan_destroy')
 
 
 def _fftconv_plan(b, b_ir, n, l, device, key_stream=None):
     # a plan carries its stream and work buffer while it executes: one plan per (shape, stream), so that callers that
     # keep several segments in flight on different streams never share one
     key = (b, b_ir, n, l, str(device), int((_stream().value or 0) if key_stream is None else key_stream))
-    with _plan_lock:
-        plan = _plan_cache.get(key)
-        if plan is None:
-            handle = ctypes.c_void_p()
-            with torch.cuda.device(device):
-                _lib.check(_lib_().ddspp_fftconv_plan_create(b, b_ir, n, l, ctypes.byref(handle)))
-            plan = handle
-            _plan_cache[key] = plan
-    return plan
 
-
-@atexit.register
-def _destroy_plans():
-    try:
-        lib = _lib_()
-    except Exception:  # noqa: BLE001
-        return
-    for plan in _plan_cache.values():
-        lib.ddspp_fftconv_plan_destroy(plan)
-    _plan_cache.clear()
+    def create():
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib_().ddspp_fftconv_plan_create(b, b_ir, n, l, ctypes.byref(handle)))
+        return handle
+    return _plan_cache.get(key, create)
 
 
 def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False, add_dry=False):
@@ -729,14 +779,16 @@ def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False,
         out_len = l + n - 1
     else:
         raise ValueError('Padding must be \'valid\' or \'same\', instead of {}.'.format(padding))
-    plan = _fftconv_plan(b, b_ir, n, l, audio.device)
+    entry = _fftconv_plan(b, b_ir, n, l, audio.device)
+    plan = entry[0]
     lib = _lib_()
     nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=audio.device)
     out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
-    _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
-                                         _auto_delay(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
-                                         nbytes, _stream()))
+    with entry[1]:
+        _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
+                                             _auto_delay(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
+                                             nbytes, _stream()))
     return out
 
 
@@ -745,12 +797,20 @@ def fft_convolve_prepare(batch, n_samples, ir, mask_dry=False, key_stream=None):
     (which may be a side stream: the IR is known before the audio).  Returns the state fft_convolve_finish needs."""
     ir = tf_float32(ir).contiguous()
     b_ir, l = ir.shape
-    plan = _fftconv_plan(int(batch), int(b_ir), int(n_samples), int(l), ir.device, key_stream=key_stream)
+    entry = _fftconv_plan(int(batch), int(b_ir), int(n_samples), int(l), ir.device, key_stream=key_stream)
+    plan = entry[0]
     lib = _lib_()
     nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=ir.device)
-    _lib.check(lib.ddspp_fftconv_transform_ir(plan, _ptr(ir), int(mask_dry), _ptr(ws), nbytes, _stream()))
-    return {'plan': plan, 'ws': ws, 'nbytes': nbytes, 'n': int(n_samples), 'l': int(l), 'batch': int(batch), 'ir': ir}
+    _plan_cache.pin(entry, +1)                       # stays alive until fft_convolve_finish
+    try:
+        with entry[1]:
+            _lib.check(lib.ddspp_fftconv_transform_ir(plan, _ptr(ir), int(mask_dry), _ptr(ws), nbytes, _stream()))
+    except Exception:
+        _plan_cache.pin(entry, -1)
+        raise
+    return {'plan': plan, 'entry': entry, 'ws': ws, 'nbytes': nbytes, 'n': int(n_samples), 'l': int(l), 'batch': int(batch),
+            'ir': ir}
 
 
 def fft_convolve_finish(state, audio, padding='same', delay_compensation=-1, add_dry=False):
@@ -762,9 +822,15 @@ def fft_convolve_finish(state, audio, padding='same', delay_compensation=-1, add
         raise ValueError(f'audio {tuple(audio.shape)} does not match the prepared {(state["batch"], state["n"])}')
     out_len = n if padding == 'same' else state['l'] + n - 1
     out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
-    _lib.check(_lib_().ddspp_fftconv_execute_prepared(state['plan'], _ptr(audio), n, _ptr(out), out_len,
-                                                      _auto_delay(delay_compensation), int(add_dry), _ptr(state['ws']),
-                                                      state['nbytes'], _stream()))
+    entry = state.pop('entry', None)
+    try:
+        with (entry[1] if entry is not None else threading.Lock()):
+            _lib.check(_lib_().ddspp_fftconv_execute_prepared(state['plan'], _ptr(audio), n, _ptr(out), out_len,
+                                                              _auto_delay(delay_compensation), int(add_dry),
+                                                              _ptr(state['ws']), state['nbytes'], _stream()))
+    finally:
+        if entry is not None:
+            _plan_cache.pin(entry, -1)
     return out
 
 

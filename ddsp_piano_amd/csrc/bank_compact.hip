@@ -182,9 +182,7 @@ bank_compact_kernel(const OscParams p) {
     float* out_row = p.out + ((size_t)row * p.wmax + cw_all) * N;
     int cpos = 0, tpos = 0, tile_n0 = n_begin;
 
-    const int abl = p.dbg_noflags >> 8;
     auto flush_tile = [&](int nt0, int count) {
-        if (abl & 1) return;
         // column sums: lane (col, half) adds 32 of the 64 lane partials of sample `col`
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -236,12 +234,10 @@ bank_compact_kernel(const OscParams p) {
             for (int j = 0; j < VPL; ++j) pv[i][j] = pv[i][j] * INV_P;
         __builtin_amdgcn_sched_barrier(0);
         // ---- stage 3: the cosines of the block in one run -------------------------------------------------------
-        if (!(abl & 4)) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i)
 #pragma unroll
             for (int j = 0; j < VPL; ++j) pv[i][j] = __builtin_amdgcn_cosf(pv[i][j]);
-        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- stage 4: Hann cross-fade of the amplitudes (core.upsample_with_windows: a0 w[U + r] + a1 w[r] with
         // w[U + r] + w[r] = 1 to an ulp = a0 + (a1 - a0) w[r]), Nyquist mask, harmonic sum over the lane's own -------
@@ -260,15 +256,8 @@ bank_compact_kernel(const OscParams p) {
                 if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
                 acc[i] = __builtin_fmaf(a, pv[i][j], acc[i]);
             }
-        if (abl & 2) {
-            float z = 0.f;
-#pragma unroll
-            for (int i = 0; i < BLK; ++i) z += acc[i];
-            if (z == 12345.678f) tile[lane] = z;
-        } else {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) tile[(tpos + i) * TSTRIDE + lane] = acc[i];
-        }
     };
 
     // Hann cross-fade weights w[r + i] and bilinear weights wlin[n0 + i] of the block: scalar loads issued one block

@@ -29,6 +29,8 @@ static inline int ddspp_auto_delay(int delay_compensation, int ir_size) {
 #define DDSPP_WAVE 64
 
 extern "C" void ddspp_set_error(const char* fmt, ...);
+// tuning option `name` (a DDSPP_* environment variable, read once and cached; ddspp_set_option / ddspp_reload_options)
+extern "C" int ddspp_option(const char* name, int dflt);
 
 #define DDSPP_REQUIRE(cond, ...)                 \
     do {                                         \

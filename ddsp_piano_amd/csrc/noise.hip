@@ -736,11 +736,7 @@ static unsigned stream_grid(size_t total) {
     return (unsigned)blocks;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    if (!s || !*s) return dflt;
-    return atoi(s);
-}
+static int env_int(const char* name, int dflt) { return ddspp_option(name, dflt); }
 
 }  // namespace ddspp
 

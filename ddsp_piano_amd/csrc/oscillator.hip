@@ -9,6 +9,7 @@
 //   * the substring loop of MultiInharmonic.get_signal   inharm_synth.py:272-293
 //
 // Work decomposition:
+//   (the compacted polyphonic bank -- what the batched group runs -- lives in bank_compact.hip)
 //   one wavefront = one (row, span) task, row = batch x voice, span = a run of consecutive
 //   1000-sample chunks of ddsp.core.angular_cumsum.  Lane l owns the "virtual oscillators"
 //   v = l + 64 j (j < VPL), v = substring * H + harmonic, and walks time SEQUENTIALLY, so the
@@ -27,34 +28,18 @@
 
 namespace ddspp {
 
-template <int VPL, bool FUSED, int MODE, bool SUM, bool COMPACT = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? 4 : 1, COMPACT ? 4 : 8)))
-osc_kernel(const OscParams p) {
-    static_assert(!COMPACT || (VPL <= 2 && FUSED && MODE == MODE_MAIN && SUM), "compact mode: fused main kernel only");
+template <int VPL, bool FUSED, int MODE, bool SUM>
+__global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     // one workgroup = the `groups` wavefronts of one (row, span): they walk the same samples, so
     // their per-tile partial sums can be combined through LDS behind a single barrier per tile
     extern __shared__ float lds_dyn[];
 
     const int lane = threadIdx.x & 63;
     const int wib = wave_uniform(threadIdx.x >> 6);
-    const int grp = COMPACT ? 0 : wib;                     // compact mode: the 4 wavefronts are independent
+    const int grp = wib;
     const int task = blockIdx.x;
     int row, c0, c1;
-    int cw = 0;                                            // compact mode: wavefront slot inside (segment, span)
-    if (COMPACT) {
-        // workgroups (of blockDim / 64 wavefront slots) per (segment, span).  Workgroup index = slot group major,
-        // (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so every XCD gets the same
-        // mix of busy (low slots) and idle (slots past the audible set, exit at once) workgroups, and the busy
-        // ones are dispatched first.  (Slot-group minor with 4 groups parks all the work on half of the XCDs.)
-        const int nbs = p.R * p.spans;
-        const int g = task / nbs;
-        const int bs = task - g * nbs;
-        cw = g * (int)(blockDim.x >> 6) + wib;             // then cw += nslots until the audible set is covered
-        row = bs / p.spans;                                // = segment b
-        const int span = bs - row * p.spans;
-        c0 = span * p.cps;
-        c1 = min(c0 + p.cps, p.nchunks);
-    } else if (MODE == MODE_PREPASS) {
+    if (MODE == MODE_PREPASS) {
         row = task / p.npre;
         c0 = task - row * p.npre;
         c1 = c0 + 1;
@@ -64,11 +49,10 @@ osc_kernel(const OscParams p) {
         c0 = span * p.cps;
         c1 = min(c0 + p.cps, p.nchunks);
     }
-    for (;;) {      // compact mode: one pass per 64 audible oscillators this workgroup is responsible for
     const int vbase = grp * p.vgrp;                       // first oscillator of this wavefront
     const int vlast = min(vbase + p.vgrp, p.V) - 1;       // last one (inclusive)
-    float* tile = lds_dyn + (COMPACT ? wib : grp) * (TILE * TSTRIDE);
-    float* comb = lds_dyn + (COMPACT ? (int)(blockDim.x >> 6) : p.groups) * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
+    float* tile = lds_dyn + grp * (TILE * TSTRIDE);
+    float* comb = lds_dyn + p.groups * (TILE * TSTRIDE);      // [2][groups][32] combine buffer
     int comb_buf = 0;
 
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S, V = p.V;
@@ -92,53 +76,8 @@ osc_kernel(const OscParams p) {
     int vk[VPL], vs[VPL], vcol[VPL], vidx[VPL];
     bool valid[VPL];
     float kmul[VPL];
-    int lrow[VPL];                                         // row (= segment * P + voice) of this lane's j-th oscillator
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) lrow[j] = row;
-    if (COMPACT) {
-        // Pack the audible oscillators of the segment's P * S (voice, sub-string) rows back to back:
-        // sub-row q contributes its first nk harmonics; a wavefront slot covers 64 * VPL of them and
-        // lane l takes the (64 * VPL * cw + l + 64 j)-th, j < VPL.
-        const int Q = p.P * S;
-        const int span = c0 / p.cps;
-        const int len = lane < Q ? p.nk[((size_t)row * p.spans + span) * p.P + lane / S] : 0;
-        int incl = len;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        const int total = __shfl(incl, 63);
-        if (cw == 0 && lane == 0) p.wcount[(size_t)row * p.spans + span] = (total + 64 * VPL - 1) / (64 * VPL);
-        if (64 * VPL * cw >= total) break;                 // nothing audible left for this slot
-        int* offs = reinterpret_cast<int*>(tile);          // exclusive offsets of the sub-rows, via LDS
-        offs[lane] = incl - len;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-            const int g = 64 * VPL * cw + lane + 64 * j;
-            const int gc = min(g, total - 1);
-            int q = 0;                                     // last sub-row whose offset is <= gc
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-                if (q + step < Q && offs[q + step] <= gc) q += step;
-            const int k = gc - offs[q];
-            lrow[j] = p.vmajor ? (q / S) * p.R + row : row * p.P + q / S;
-            vs[j] = q - (q / S) * S;
-            vk[j] = k;
-            vcol[j] = vs[j] * H + k;
-            vidx[j] = vcol[j];
-            valid[j] = g < total;
-            kmul[j] = (float)(k + 1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-#pragma unroll
-    for (int j = 0; j < VPL && !COMPACT; ++j) {
+    for (int j = 0; j < VPL; ++j) {
         const int v = vbase + (CONTIG ? lane * VPL + j : lane + 64 * j);
         vidx[j] = v;
         valid[j] = v <= vlast;
@@ -161,7 +100,7 @@ osc_kernel(const OscParams p) {
         const int span = c0 / p.cps;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            asum[j] = p.astart[((size_t)lrow[j] * p.spans + span) * p.VP + vidx[j]];
+            asum[j] = p.astart[((size_t)row * p.spans + span) * p.VP + vidx[j]];
             off[j] = mod_2pi(asum[j]);
         }
     }
@@ -178,7 +117,7 @@ osc_kernel(const OscParams p) {
     auto frame_request = [&](int tt) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            const size_t fr = (size_t)lrow[j] * T + tt;
+            const size_t fr = (size_t)row * T + tt;
             q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
             q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : (p.inh ? p.inh[fr] : 0.0f);
@@ -246,7 +185,7 @@ osc_kernel(const OscParams p) {
         classify_frame();
     }
 
-    float* out_row = p.out + (COMPACT ? ((size_t)row * p.wmax + cw) * N : (size_t)row * N);
+    float* out_row = p.out + (size_t)row * N;
     int cpos = 0;                      // position inside the current 1000-sample chunk
     int chunk = c0;
     const float* fe_row = FUSED ? nullptr : p.fe + (size_t)row * N * H;
@@ -517,9 +456,6 @@ osc_kernel(const OscParams p) {
             }
         }
     }
-    if (!COMPACT) break;
-    cw += p.nslots;
-    }   // for (;;)
 }
 
 // Fused source, spans > 1: chunk end phases and span start offsets in ONE sequential walk per
@@ -636,7 +572,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         t_checked = max(t_checked, t_need);
     };
     auto check_upto = [&](int t_need) {
-        if (p.audible && !(p.dbg_noflags & 1)) {
+        if (p.audible && !p.dbg_noflags) {
             flagged_upto(t_need);
             return;
         }
@@ -1080,11 +1016,7 @@ static bool sample_rate_is_checked(float sr) {
     return false;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    if (!s || !*s) return dflt;
-    return atoi(s);
-}
+static int env_int(const char* name, int dflt) { return ddspp_option(name, dflt); }
 
 static int pick_vpl(int V) {
     const int need = (V + 63) / 64;
@@ -1442,7 +1374,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.inh = harmonic_shifts ? nullptr : inharm_coef;       // shifts formed in the kernels from the raw inharm_coef
     p.audible = audible;
     p.state_in = phase_state_in;
-    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0) | (env_int("DDSPP_BANK_ABLATE", 0) << 8);
+    p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
     p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;

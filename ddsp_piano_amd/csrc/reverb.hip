@@ -121,10 +121,9 @@ int ddspp_fft_size(int N, int L) {
 // DDSPP_FFT_POW2=1 keeps the reference's size, DDSPP_FFT_SIZE=n forces a length (tuning).
 static int fast_fft_size(int N, int L) {
     const long long need = (long long)N + L - 1;
-    const char* e = getenv("DDSPP_FFT_POW2");
-    if (e && *e == '1') return ddspp_fft_size(N, L);
-    const char* f = getenv("DDSPP_FFT_SIZE");
-    if (f && atoll(f) >= need && atoll(f) % 8 == 0) return (int)atoll(f);
+    if (ddspp_option("DDSPP_FFT_POW2", 0) == 1) return ddspp_fft_size(N, L);
+    const int forced = ddspp_option("DDSPP_FFT_SIZE", 0);
+    if (forced >= need && forced % 8 == 0) return forced;
     long long best = -1;
     double best_cost = 0.0;
     for (int p5 = 0; p5 <= 3; ++p5)

@@ -70,29 +70,28 @@ FDN_DELAYS_ALLPASS = ((131., 151., 337., 353.), (103., 173., 331., 373.), (89., 
                       (79., 197., 281., 419.), (61., 211., 257., 431.), (47., 229., 251., 443.),
                       (81., 189., 287., 407.), (91., 203., 321., 377.))                  # fdn_reverb.py:102-113
 
-_irfft_plans = {}
+_irfft_plans = core._PlanCache('ddspp_irfft_plan_destroy', maxsize=8)
 
 
 def _irfft(spectrum, n):
     """tf.signal.irfft for [B, n/2+1] complex64 -> [B, n] float32 (rocFFT C2R; the spectrum buffer is consumed)."""
-    import atexit
     import ctypes
     from . import _lib
     from .core import _lib_, _ptr, _stream
     b = spectrum.shape[0]
-    key = (n, b, str(spectrum.device))
-    plan = _irfft_plans.get(key)
-    if plan is None:
+
+    def create():
         handle = ctypes.c_void_p()
         with torch.cuda.device(spectrum.device):
             _lib.check(_lib_().ddspp_irfft_plan_create(n, b, ctypes.byref(handle)))
-        plan = _irfft_plans[key] = handle
-        if len(_irfft_plans) == 1:
-            atexit.register(lambda: [_lib_().ddspp_irfft_plan_destroy(h) for h in _irfft_plans.values()])
+        return handle
+    entry = _irfft_plans.get((n, b, str(spectrum.device)), create)
+    plan = entry[0]
     nbytes = int(_lib_().ddspp_irfft_workspace_bytes(plan))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=spectrum.device)
     out = torch.empty((b, n), dtype=torch.float32, device=spectrum.device)
-    _lib.check(_lib_().ddspp_irfft_execute(plan, _ptr(spectrum), _ptr(out), _ptr(ws), nbytes, _stream()))
+    with entry[1]:
+        _lib.check(_lib_().ddspp_irfft_execute(plan, _ptr(spectrum), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out
 
 

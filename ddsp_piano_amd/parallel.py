@@ -22,15 +22,23 @@ def shard_range(global_batch, world_size, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def shard_features(features, world_size, rank, batch_axis=0):
-    """Slice every tensor of a ProcessorGroup feature dict to this rank's rows (views, no copies)."""
-    sizes = {v.shape[batch_axis] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() > 0}
-    if len(sizes) != 1:
-        raise ValueError(f'features disagree on the batch size: {sorted(sizes)}')
-    lo, hi = shard_range(sizes.pop(), world_size, rank)
+def shard_features(features, world_size, rank, batch_axis=0, global_batch=None):
+    """Slice every batched tensor of a ProcessorGroup feature dict to this rank's rows (views, no copies).
+
+    The batch size is ``global_batch`` or, by default, the leading size of the 3-D control tensors ([B, T, C]).
+    Tensors whose leading size is something else pass through whole: a reverb impulse response shared by all rows
+    ([L], or [1, L] -- ddsp.effects.Reverb accepts both), scalars, non-tensors."""
+    tensors = [v for v in features.values() if isinstance(v, torch.Tensor) and v.dim() > 0]
+    if global_batch is None:
+        sizes = {v.shape[batch_axis] for v in tensors if v.dim() >= 3}
+        if len(sizes) != 1:
+            raise ValueError(f'features disagree on the batch size: {sorted(sizes)}')
+        global_batch = sizes.pop()
+    lo, hi = shard_range(global_batch, world_size, rank)
     out = {}
     for k, v in features.items():
-        out[k] = v.narrow(batch_axis, lo, hi - lo) if isinstance(v, torch.Tensor) and v.dim() > 0 else v
+        batched = isinstance(v, torch.Tensor) and v.dim() > 1 and v.shape[batch_axis] == global_batch
+        out[k] = v.narrow(batch_axis, lo, hi - lo) if batched else v
     return out
 
 
@@ -70,9 +78,11 @@ def gather_audio_uneven(local_audio, global_batch, group=None):
 def synthesize_sharded(processor_group, features, group=None):
     """features hold the GLOBAL batch on every rank; returns the global audio on every rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = {v.shape[0] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() > 0}
+    sizes = {v.shape[0] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() >= 3}
+    if len(sizes) != 1:
+        raise ValueError(f'features disagree on the batch size: {sorted(sizes)}')
     global_batch = sizes.pop()
-    local = processor_group(shard_features(features, world, rank))
+    local = processor_group(shard_features(features, world, rank, global_batch=global_batch))
     if global_batch % world == 0:
         return gather_audio(local, group=group)
     return gather_audio_uneven(local, global_batch, group=group)

@@ -12,8 +12,6 @@ across voices inside the bank -- so their mix differs from the walk's by float32
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import _lib, core
@@ -191,9 +189,10 @@ def run(plan, inputs, noise=None, need_stems=True):
     fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
     # (batch 64, same box: 2.12 ms per step with per-voice rows, 2.08 / 2.05 / 2.03 / 2.04 with 2 / 4 / 8 / 16)
-    voice_sums = int(os.environ.get('DDSPP_VOICE_SUMS', 0)) or next(v for v in (8, 4, 2, 1) if P % v == 0)
+    opt = _lib.options
+    voice_sums = opt.voice_sums or next(v for v in (8, 4, 2, 1) if P % v == 0)
     if not (compact and voice_sums > 1 and P % voice_sums == 0 and
-            os.environ.get('DDSPP_NO_VOICE_SUMS') != '1'):
+            not opt.no_voice_sums):
         voice_sums = 1
 
     last_stem = {}
@@ -221,15 +220,14 @@ def run(plan, inputs, noise=None, need_stems=True):
     # The noise branch does not depend on the additive one until the mix: it is enqueued on a side stream first, so
     # the latency-bound parts of the additive chain (the one-wavefront-per-row pre-pass, kernel tails) overlap with it.
     # (worth the two stream joins only for large batches / long files: 2 % there, a loss for a single 3 s segment)
-    side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= int(os.environ.get('DDSPP_SIDE_STREAM_MIN', 1 << 24)) and
-                                 os.environ.get('DDSPP_NO_SIDE_STREAM') != '1' and
+    side = _side_stream(dev) if (dev.type == 'cuda' and R * N >= opt.side_stream_min and not opt.no_side_stream and
                                  not torch.cuda.is_current_stream_capturing()) else None
     rev_state = None
     if side is not None:
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            if type(plan.reverb) is Reverb and len(plan.reverb_keys) == 1 and os.environ.get('DDSPP_NO_EARLY_IR') != '1':
+            if type(plan.reverb) is Reverb and len(plan.reverb_keys) == 1 and not opt.no_early_ir:
                 # the room's impulse response is an input: its spectrum is ready long before the dry mix
                 rev_state = plan.reverb.begin(B, N, inputs[plan.reverb_keys[0]], key_stream=cur.cuda_stream)
             nctl, noise_sig, noise_vq = noise_branch(noise)

@@ -42,6 +42,12 @@ typedef struct ihipStream_t* hipStream_t;
 int ddspp_version(void);
 const char* ddspp_target_arch(void);
 const char* ddspp_last_error(void);
+/* Tuning options (launch geometry, A/B route switches): named like their DDSPP_* environment
+ * variable.  The environment is consulted ONCE per option (first use) and cached -- no getenv on the call path;
+ * ddspp_set_option overrides a value, ddspp_reload_options forgets the cache (next use reads the environment again). */
+int ddspp_option(const char* name, int default_value);      /* the value in effect */
+int ddspp_set_option(const char* name, int value);
+void ddspp_reload_options(void);
 
 /* ---- host builders of the kernels' small tables (csrc/tables.cpp) --------------------------------------------
  * Everything below that takes a table (lo/hi/w, wlin, whann, window, M, CE/CO/tap_*) gets it from here: a caller that

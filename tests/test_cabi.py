@@ -135,3 +135,27 @@ def test_host_table_builders_agree_with_the_python_layer():
             for a, b in ((c_ce, ce), (c_co, co), (c_we, we), (c_wo, wo)):
                 assert np.abs(a - b).max() <= 1.2e-7 * max(1.0, float(np.abs(b).max()))
     assert lib.ddspp_fir_eo_tables_host(65, 0, None, None, None, None, None) == _lib.DDSPP_EINVAL
+
+
+def test_options_are_read_once_and_reloadable(monkeypatch):
+    """No getenv on the call path: an option's environment variable is consulted on first use and cached;
+    ddspp_set_option overrides it, ddspp_reload_options forgets the cache.  The host layer's switches likewise."""
+    from ddsp_piano_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setenv('DDSPP_TEST_OPTION', '5')
+    lib.ddspp_reload_options()
+    assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 5
+    monkeypatch.setenv('DDSPP_TEST_OPTION', '7')
+    assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 5            # cached
+    assert lib.ddspp_set_option(b'DDSPP_TEST_OPTION', 9) == 0
+    assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 9
+    lib.ddspp_reload_options()
+    assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 7
+    monkeypatch.delenv('DDSPP_TEST_OPTION')
+    lib.ddspp_reload_options()
+    assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 1
+    assert lib.ddspp_set_option(None, 1) == _lib.DDSPP_EINVAL
+    monkeypatch.setenv('DDSPP_NO_SIDE_STREAM', '1')
+    assert _lib.options.no_side_stream is False                      # not re-read per call
+    _lib.options.reload()
+    assert _lib.options.no_side_stream is True

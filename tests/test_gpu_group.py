@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import O, rms, rms_err, synth_controls, synth_ir
+from util import O, rms, rms_err, set_option, synth_controls, synth_ir
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -331,9 +331,9 @@ def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
         amp = ctl['amplitudes'].reshape(R, T).contiguous()
         args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
         mix = core.polyphonic_additive(*args, audible=ctl['_audible'])
-        monkeypatch.setenv('DDSPP_OSC_PREPASS_ONE_WAVE', '1')
+        set_option(monkeypatch, 'DDSPP_OSC_PREPASS_ONE_WAVE', '1')
         one = core.polyphonic_additive(*args, audible=ctl['_audible'])
-        monkeypatch.delenv('DDSPP_OSC_PREPASS_ONE_WAVE')
+        set_option(monkeypatch, 'DDSPP_OSC_PREPASS_ONE_WAVE')
         assert torch.equal(mix, one), nbn
         stems = core.harmonic_synthesis_fused(*args[:4], N, sr, True).reshape(B, P, N)
         assert (mix - stems.sum(dim=1)).abs().max().item() < 5e-6, nbn
@@ -425,14 +425,14 @@ def test_chunk_prepass_kernel_equals_the_block_machinery(monkeypatch):
     amp = ctl['amplitudes'].reshape(B * P, T).contiguous()
     args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
     new = core.polyphonic_additive(*args)
-    monkeypatch.setenv('DDSPP_OSC_OLD_CHUNK_PREPASS', '1')
+    set_option(monkeypatch, 'DDSPP_OSC_OLD_CHUNK_PREPASS', '1')
     old = core.polyphonic_additive(*args)
-    monkeypatch.delenv('DDSPP_OSC_OLD_CHUNK_PREPASS')
+    set_option(monkeypatch, 'DDSPP_OSC_OLD_CHUNK_PREPASS')
     assert torch.isfinite(new).all() and new.abs().max().item() > 0
     assert torch.equal(new, old)
-    monkeypatch.setenv('DDSPP_OSC_SHORT_SCAN', '1')            # a thread per chain instead of the tiled scan
+    set_option(monkeypatch, 'DDSPP_OSC_SHORT_SCAN', '1')            # a thread per chain instead of the tiled scan
     assert torch.equal(core.polyphonic_additive(*args), new)
-    monkeypatch.delenv('DDSPP_OSC_SHORT_SCAN')
+    set_option(monkeypatch, 'DDSPP_OSC_SHORT_SCAN')
     for spans in (1, 5, 307):                                 # and the span split stays invisible
         assert (core.polyphonic_additive(*args, spans=spans) - new).abs().max().item() < 3e-6
 
@@ -469,8 +469,8 @@ def test_side_stream_route_gives_the_same_audio(monkeypatch):
     feats = {k: torch.as_tensor(v, device='cuda') for k, v in _features(rng, B, P, T, H, K, S, L).items()}
     outs = []
     for side in (False, True):
-        monkeypatch.setenv('DDSPP_NO_SIDE_STREAM', '0' if side else '1')
-        monkeypatch.setenv('DDSPP_SIDE_STREAM_MIN', '1')
+        set_option(monkeypatch, 'DDSPP_NO_SIDE_STREAM', '0' if side else '1')
+        set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', '1')
         for _ in range(3):                                   # a few calls in a row: buffers are recycled across streams
             dag, gnoise = _build(dp, P, sr)
             gnoise.seed = 5
@@ -506,7 +506,7 @@ def test_noise_voice_sums_equal_the_per_voice_rows(monkeypatch):
     feats = {k: torch.as_tensor(v, device='cuda') for k, v in _features(rng, 2, 8, 30, 128, 96, 1, 2000).items()}
     outs = []
     for off in ('0', '1'):
-        monkeypatch.setenv('DDSPP_NO_VOICE_SUMS', off)
+        set_option(monkeypatch, 'DDSPP_NO_VOICE_SUMS', off)
         dag, gnoise = _build(dp, 8, 24000)
         gnoise.seed = 9
         outs.append(dp.ProcessorGroup(dag)(feats))

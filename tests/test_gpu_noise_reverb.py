@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import O, rms, rms_err, synth_ir
+from util import O, rms, rms_err, set_option, synth_ir
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -45,7 +45,7 @@ def test_tiled_and_generic_fir_agree(monkeypatch):
     mags = _dev(rng.uniform(0, 1, [B, T, K]).astype(np.float32))
     noise = _dev(rng.uniform(-1, 1, [B, T * U]).astype(np.float32))
     a = core.frequency_filter(noise, mags, window_size=257)
-    monkeypatch.setenv('DDSPP_FIR_GENERIC', '1')
+    set_option(monkeypatch, 'DDSPP_FIR_GENERIC', '1')
     b = core.frequency_filter(noise, mags, window_size=257)
     assert (a - b).abs().max().item() < 2e-6
 
@@ -189,9 +189,9 @@ def test_fused_frequency_filter_equals_the_two_kernel_form(B, T, U, K, monkeypat
     for rs in (None, synth.raw_scale()):
         mags = raw if rs is not None else synth.get_controls(raw)['magnitudes']
         fused = core.frequency_filter(noise, mags, window_size=synth.window_size, raw_scale=rs)
-        monkeypatch.setenv('DDSPP_FIR_NO_FUSED', '1')
+        set_option(monkeypatch, 'DDSPP_FIR_NO_FUSED', '1')
         assert _lib.load().ddspp_frequency_filter_eo_supported(N, T, K, Lw, -1) == 0
         split = core.frequency_filter(noise, mags, window_size=synth.window_size, raw_scale=rs)
-        monkeypatch.delenv('DDSPP_FIR_NO_FUSED')
+        set_option(monkeypatch, 'DDSPP_FIR_NO_FUSED')
         assert fused.shape == split.shape == (B, N)
         assert torch.equal(fused, split), (B, T, U, K, rs is not None)

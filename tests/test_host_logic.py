@@ -184,7 +184,11 @@ def test_shard_ranges():
     sh = parallel.shard_features(feats, 4, 1)
     assert sh['a_0'].shape == (2, 5, 1) and sh['reverb_ir'].shape == (2, 100) and sh['flag'] == 3
     with pytest.raises(ValueError):
-        parallel.shard_features({'a': torch.zeros(8, 1), 'b': torch.zeros(6, 1)}, 2, 0)
+        parallel.shard_features({'a': torch.zeros(8, 5, 1), 'b': torch.zeros(6, 5, 1)}, 2, 0)
+    # an impulse response shared by every row ([L] or [1, L], both accepted by ddsp.effects.Reverb) is not sharded
+    shared = {'a_0': torch.zeros(8, 5, 1), 'ir1': torch.zeros(100), 'ir2': torch.zeros(1, 100), 'ir3': torch.zeros(8, 100)}
+    sh = parallel.shard_features(shared, 4, 3)
+    assert sh['ir1'].shape == (100,) and sh['ir2'].shape == (1, 100) and sh['ir3'].shape == (2, 100) and sh['a_0'].shape[0] == 2
 
 
 def test_parallelizer_merges_and_unmerges_like_the_reference():
@@ -247,3 +251,28 @@ def test_bench_launcher_logic(monkeypatch):
     assert cmd[-4:] == ['--gpus', '8', '--steps', '3'] and '127.0.0.1' in cmd
     args = bench.parse(['--gpus', '2', '--no-single-stream'])
     assert args.no_extras and args.call_form == 'outputs_dict'
+
+
+def test_plan_cache_is_bounded_and_respects_pins(monkeypatch):
+    """rocFFT plans are library-owned handles: the cache destroys the least recently used ones when it is full, never a
+    plan pinned by an unfinished two-phase convolution, and clear() (atexit) tolerates a library that is gone."""
+    destroyed = []
+
+    class FakeLib:
+        def fake_destroy(self, h):
+            destroyed.append(h)
+    monkeypatch.setattr(core, '_lib_', lambda: FakeLib())
+    cache = core._PlanCache('fake_destroy', maxsize=2)
+    a = cache.get('a', lambda: 'A')
+    cache.pin(a, +1)
+    cache.get('b', lambda: 'B')
+    cache.get('c', lambda: 'C')                     # full: 'a' is pinned, so 'b' (the oldest unpinned) goes
+    assert destroyed == ['B'] and len(cache) == 2
+    assert cache.get('a', lambda: 'A2')[0] == 'A'   # still the same plan
+    cache.pin(a, -1)
+    cache.get('d', lambda: 'D')
+    assert 'C' in destroyed and len(cache) == 2
+    cache.clear()
+    assert len(cache) == 0 and set(destroyed) == {'A', 'B', 'C', 'D'}
+    monkeypatch.setattr(core, '_lib_', lambda: (_ for _ in ()).throw(RuntimeError('gone')))
+    cache.clear()                                   # no exception at interpreter exit

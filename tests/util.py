@@ -42,7 +42,18 @@ def synth_ir(rng, B, L):
     return ir.astype(np.float32)
 
 
-__all__ = ['O', 'rms', 'rms_err', 'synth_controls', 'synth_ir']
+def set_option(monkeypatch, name, value=None):
+    """Flip a DDSPP_* tuning / route switch for the rest of the test: the environment variable is changed AND the
+    package is told to re-read its options (neither the library nor the host layer reads the environment per call)."""
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    from ddsp_piano_amd import _lib
+    _lib.options.reload()
+
+
+__all__ = ['O', 'rms', 'rms_err', 'synth_controls', 'synth_ir', 'set_option']
 
 
 def oracle_segments(feats, noises, P, sr, segments, threads=None, **flags):

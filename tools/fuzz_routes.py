@@ -6,7 +6,7 @@ import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import ddsp_piano_amd as dp
-from ddsp_piano_amd import core
+from ddsp_piano_amd import _lib, core
 from util import synth_controls, synth_ir
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(2024)
@@ -24,8 +24,10 @@ for case in range(n_cases):
     syn = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=sr)
     a = core.frequency_filter(x, raw, window_size=syn.window_size, raw_scale=syn.raw_scale())
     os.environ['DDSPP_FIR_NO_FUSED'] = '1'
+    _lib.options.reload()
     b = core.frequency_filter(x, raw, window_size=syn.window_size, raw_scale=syn.raw_scale())
     del os.environ['DDSPP_FIR_NO_FUSED']
+    _lib.options.reload()
     ok1 = torch.equal(a, b)
     # 2. additive: compact mix vs stems
     ctlraw = synth_controls(rng, B * P, T, H, S=S, silent_frac=0.3)
