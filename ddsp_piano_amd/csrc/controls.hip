@@ -54,6 +54,14 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
 #pragma unroll
         for (int j = 0; j < HPL; ++j) raw_hd[u][j] = p.harmonic_distribution[fr * H + min(lane + 64 * j, H - 1)];
     }
+    // shifts_last only: where the wavefront's first frame sits (32-bit arithmetic, R * T < 2^31 checked by the host; a
+    // row has at least CTL_FPW frames or the rows simply advance by more than one -- handled by the generic division)
+    unsigned row0 = 0, tt0 = 0, last_lo = 0;
+    if (p.shifts_last) {
+        row0 = (unsigned)frame0 / (unsigned)p.T;
+        tt0 = (unsigned)frame0 - row0 * (unsigned)p.T;
+        last_lo = (unsigned)(p.R / p.P) * (unsigned)(p.P - 1);          // voice major: first row of the last voice
+    }
 #pragma unroll
     for (int u = 0; u < CTL_FPW; ++u) {
         const size_t frame = frame0 + u;
@@ -115,11 +123,15 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             }
         }
         if (p.shifts_last) {       // what the outputs dictionary of the reference's DAG keeps: the last voice's controls
-            // 32-bit arithmetic (R * T < 2^31 is checked by the host): a 64-bit division per frame cost 0.05 ms at batch 64
-            const unsigned fr32 = (unsigned)frame, row = fr32 / (unsigned)p.T, tt = fr32 - row * (unsigned)p.T;
-            const unsigned nb = (unsigned)(p.R / p.P);
-            const unsigned v = p.vmajor ? row / nb : row % (unsigned)p.P, b = p.vmajor ? row % nb : row / (unsigned)p.P;
-            if (v == (unsigned)p.P - 1) {
+            // (row, frame-in-row) of this frame from the wavefront's first frame: one division per wavefront, not per frame
+            unsigned row = row0, tt = tt0 + (unsigned)u;
+            if (tt >= (unsigned)p.T) {
+                tt -= (unsigned)p.T;
+                ++row;
+            }
+            const bool is_last = p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1;
+            if (is_last) {
+                const unsigned b = p.vmajor ? row - last_lo : row / (unsigned)p.P;
 #pragma unroll
                 for (int j = 0; j < HPL; ++j) {
                     const int k = lane + 64 * j;
@@ -276,7 +288,7 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
     p.amp_out = amplitudes_out; p.hd_out = harmonic_distribution_out; p.shifts_out = harmonic_shifts_out;
     p.count_out = audible_out;
-    DDSPP_REQUIRE(!shifts_last_out || (n_voices >= 1 && R % n_voices == 0 && (long long)R * T < (1ll << 31)),
+    DDSPP_REQUIRE(!shifts_last_out || (n_voices >= 1 && R % n_voices == 0 && (long long)R * T < (1ll << 31) && T >= CTL_FPW),
                   "inharmonic_controls: %d rows are not a whole number of %d-voice segments (or too many frames)", R, n_voices);
     p.shifts_last = shifts_last_out; p.P = n_voices; p.vmajor = voice_major;
     p.R = R; p.T = T; p.H = H; p.S = S;

@@ -13,7 +13,7 @@ SIMDS = 1024
 
 
 def short(name):
-    name = re.sub(r'^void ', '', name)
+    name = re.sub(r'^void ', '', name).replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*$', '', name)
     return name.replace('ddspp::', '')
 
@@ -47,6 +47,8 @@ def main(out):
         ms = dur[k] / calls[k] / 1e6
         print(f'{k[:96]}\n    launches {calls[k]}  avg {ms:.4f} ms')
         gui = c.get('GRBM_GUI_ACTIVE')
+        if gui:
+            gui /= 8.0            # the counter is summed over the 8 XCDs
         clk = gui / (ms * 1e-3) if gui else None
         for name in sorted(c):
             print(f'    {name:30s} {c[name]:18.1f}')
@@ -55,8 +57,7 @@ def main(out):
             frac = c['SQ_INSTS_VALU'] * 2.0 / (SIMDS * gui)
             print(f'    -> clock {clk / 1e9:.3f} GHz; VALU issue fraction (2 cycles per wave64 instruction) = {frac:.3f}')
         if 'SQ_ACTIVE_INST_VALU' in c and 'SQ_BUSY_CYCLES' in c and gui:
-            print(f'    -> SQ_ACTIVE_INST_VALU / (4 * 1024 SIMD-cycles) = {c["SQ_ACTIVE_INST_VALU"] / (4.0 * SIMDS * gui):.3f}'
-                  f'   [counter is in quad-cycles per SIMD]')
+            print(f'    -> SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY = {c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_ACTIVE_INST_ANY", 1.0), 1.0):.2f}')
         if 'FETCH_SIZE' in c or 'WRITE_SIZE' in c:
             rd = 2.0 * c.get('FETCH_SIZE', 0.0) * 1024 / 1e9
             wr = c.get('WRITE_SIZE', 0.0) * 1024 / 1e9
@@ -64,8 +65,7 @@ def main(out):
 
 
     # wave-instruction count of one ddspp_polyphonic_additive call (bench.py roofline_step reads it from profiles/)
-    add_kernels = [k for k in ctr if k.startswith(('osc_prepass', 'osc_count', 'osc_partial_sum', 'osc_offset_scan')) or
-                   re.match(r'osc_kernel<\d, true, 0, true, true>', k)]
+    add_kernels = [k for k in ctr if k.startswith(('osc_prepass', 'osc_count', 'bank_slot_sum', 'osc_offset_scan', 'bank_compact'))]
     tot = sum(ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels)
     if tot:
         import json
