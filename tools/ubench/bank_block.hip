@@ -8,7 +8,7 @@
 constexpr float INV_P = 0x1.45f306p-3f;
 constexpr float P2 = 6.2831855f;
 
-template <bool STAGED, bool WSGPR, bool NOCOS>
+template <bool STAGED, bool WSGPR, bool NOCOS, bool QBLK = false, bool SPLIT4 = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k(float* out, const float* __restrict__ wtab, int iters, float om0, float om1) {
     typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -30,6 +30,19 @@ k(float* out, const float* __restrict__ wtab, int iters, float om0, float om1) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) pv[i][j] = pv[i][j] + off[j];
+        if (QBLK) {
+            float q0[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) q0[j] = -__builtin_rintf(pv[0][j] * INV_P);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pv[i][j] = __builtin_fmaf(q0[j], P2, pv[i][j]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pv[i][j] = pv[i][j] * INV_P;
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -38,6 +51,7 @@ k(float* out, const float* __restrict__ wtab, int iters, float om0, float om1) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) pv[i][j] = __builtin_fmaf(-q[i][j], P2, pv[i][j]) * INV_P;
+        }
         if (STAGED) __builtin_amdgcn_sched_barrier(0);
         if (!NOCOS) {
 #pragma unroll
@@ -47,10 +61,23 @@ k(float* out, const float* __restrict__ wtab, int iters, float om0, float om1) {
         }
         if (STAGED) __builtin_amdgcn_sched_barrier(0);
         float acc[8];
+        if (SPLIT4) {
+            float am[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) am[i][j] = __builtin_fmaf(da[j], w[i], a0[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = am[i][0] * pv[i][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(am[i][1], pv[i][1], acc[i]);
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(da[0], w[i], a0[0]) * pv[i][0];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(__builtin_fmaf(da[1], w[i], a0[1]), pv[i][1], acc[i]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) total += acc[i];
         if (ph[0] > 3000.f) { ph[0] -= 3000.f; ph[1] -= 3000.f; }
@@ -58,7 +85,7 @@ k(float* out, const float* __restrict__ wtab, int iters, float om0, float om1) {
     out[blockIdx.x * 64 + threadIdx.x] = total;
 }
 
-template <bool STAGED, bool WSGPR, bool NOCOS>
+template <bool STAGED, bool WSGPR, bool NOCOS, bool QBLK = false, bool SPLIT4 = false>
 void run(const char* name) {
     float *out, *wtab;
     hipMalloc(&out, 256 * 16 * 64 * 4);
@@ -69,10 +96,10 @@ void run(const char* name) {
     int iters = 20000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<STAGED, WSGPR, NOCOS>), dim3(256 * 16), dim3(64), 0, 0, out, wtab, 10, 0.01f, 0.02f);
+    hipLaunchKernelGGL((k<STAGED, WSGPR, NOCOS, QBLK, SPLIT4>), dim3(256 * 16), dim3(64), 0, 0, out, wtab, 10, 0.01f, 0.02f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<STAGED, WSGPR, NOCOS>), dim3(256 * 16), dim3(64), 0, 0, out, wtab, iters, 0.01f, 0.02f);
+    hipLaunchKernelGGL((k<STAGED, WSGPR, NOCOS, QBLK, SPLIT4>), dim3(256 * 16), dim3(64), 0, 0, out, wtab, iters, 0.01f, 0.02f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -89,5 +116,9 @@ int main() {
     run<false, false, false>("compiler order, weights in VGPRs");
     run<true, true, true>("staged, SGPR weights, no v_cos");
     run<true, false, true>("staged, VGPR weights, no v_cos");
+    run<true, true, false, true>("staged, SGPR w, one 2 pi multiple per block (112+16)");
+    run<true, true, false, true, true>("  + amplitudes first, then the products");
+    run<true, false, false, true, true>("  + the same with weights in VGPRs");
+    run<true, true, true, true, true>("  + SGPR w, no v_cos");
     return 0;
 }
