@@ -248,6 +248,24 @@ def linear_tables(n_frames, n_timesteps, device):
     return _cached(('lin', int(n_frames), int(n_timesteps), str(device), rule), build)
 
 
+def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
+    """Interpolation weight of every sample, float32 [n_timesteps].  sample_offset > 0: the samples are
+    sample_offset, sample_offset + 1, ... of a longer signal with the same frame / sample ratio (a streamed piece,
+    streaming.py): the reference forms float32(n) * scale at the ABSOLUTE n, whose fractional part rounds differently
+    at different magnitudes, so a piece takes the weights the one-call render has at those positions.  Built on the
+    device (exact IEEE float32 multiply / floor / subtract, the same values as the cached numpy table), not cached."""
+    if not sample_offset:
+        return linear_tables(n_frames, n_timesteps, device)[2]
+    scale = float(F32(n_frames) / F32(n_timesteps))
+    n = torch.arange(int(sample_offset), int(sample_offset) + int(n_timesteps), device=device,
+                     dtype=torch.int64).to(torch.float32)
+    if RECALLED['resize'] == 'half_pixel':
+        pos = (n + 0.5) * scale - 0.5
+    else:
+        pos = n * scale
+    return (pos - torch.floor(pos)).contiguous()
+
+
 def hann_window(n, device):
     return _cached(('hann', int(n), str(device)),
                    lambda: torch.from_numpy(_hann_window_np(int(n))).to(device))
@@ -506,7 +524,7 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
                         sample_rate, spans=0, voice_major=False, audible=None, split_last=False, inharm_coef=None,
-                        phase_state=None):
+                        phase_state=None, sample_offset=0):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
@@ -516,14 +534,15 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     split_last=True returns (sum of voices 0 .. P-2, the last voice's stem): what the outputs dictionary of the
     reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37).
     harmonic_shifts=None with inharm_coef [R, T] (raw): the kernels form the shifts themselves (get_inharmonic_freq).
-    phase_state [R, S * H]: streaming -- the oscillators continue from the state oscillator_phase_state left."""
+    phase_state [R, S * H]: streaming -- the oscillators continue from the state oscillator_phase_state left;
+    sample_offset: absolute position of the first sample in the streamed signal (linear_weights)."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
     p = r // b
     u = n_samples // t
     dev = f0_hz.device
-    _, _, wlin, _ = linear_tables(t, n_samples, dev)
+    wlin = linear_weights(t, n_samples, dev, sample_offset)
     whann = hann_window(2 * u, dev)
     lib = _lib_()
     nbytes = int(lib.ddspp_polyphonic_additive_workspace_bytes(b, p, t, s, h, u))
@@ -544,14 +563,14 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
 
 
 def oscillator_phase_state(f0_hz, n_chunks, upsampling, sample_rate, harmonic_shifts=None, inharm_coef=None,
-                           n_harmonics=None, phase_state=None, audible=None):
+                           n_harmonics=None, phase_state=None, audible=None, sample_offset=0):
     """The state an oscillator bank carries across calls: phase_state [R, S * H] after the first n_chunks 1000-sample
-    chunks of these controls (f0_hz [R, T, S]; harmonic_shifts [R, T, H] or raw inharm_coef [R, T]).  See
-    ddspp_oscillator_phase_state."""
+    chunks of these controls (f0_hz [R, T, S]; harmonic_shifts [R, T, H] or raw inharm_coef [R, T]); sample_offset:
+    absolute position of the controls' first sample in the streamed signal.  See ddspp_oscillator_phase_state."""
     r, t, s = f0_hz.shape
     h = int(harmonic_shifts.shape[-1]) if harmonic_shifts is not None else int(n_harmonics)
     dev = f0_hz.device
-    _, _, wlin, _ = linear_tables(t, t * int(upsampling), dev)
+    wlin = linear_weights(t, t * int(upsampling), dev, sample_offset)
     lib = _lib_()
     nbytes = int(lib.ddspp_oscillator_phase_state_workspace_bytes(r, s, h, int(n_chunks)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

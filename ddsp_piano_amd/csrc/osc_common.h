@@ -40,6 +40,9 @@ struct OscParams {
     // streaming: the float32 running sum of chunk end phases (ddsp.core.angular_cumsum's cumsum over chunks) each
     // oscillator starts from, [rows, V]; null = 0 (a signal that starts here)
     const float* __restrict__ state_in;
+    // the span-start walk normally leaves out 64-oscillator groups that are silent in every frame of the call (nothing
+    // reads their start phases); need_all = 1 walks them too: a carried phase state must cover every oscillator
+    int need_all;
 };
 
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };

@@ -498,18 +498,25 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         kmul[j] = (float)(vk[j] + 1);
     }
     // Harmonics that are silent in every frame of the row (above Nyquist for this note, or a silent voice) never
-    // get a lane in the compacted oscillator bank, so their start phases are not needed: a 64-lane group made only
-    // of such harmonics reads frame 0 over and over (cache hits) instead of streaming its [T, 64] slice.
+    // get a lane in the compacted oscillator bank, so their start phases are not needed: a task made only of such
+    // harmonics has nothing to do (all wavefronts of the workgroup share the task: a uniform exit), and in a mixed
+    // task the silent 64-lane groups read frame 0 over and over (cache hits) instead of streaming their [T, 64]
+    // slice.  Not so for a carried phase state (need_all): the reference advances every partial's phase, heard or not.
     bool need[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) need[j] = true;
-    if (p.audible) {
+    if (p.audible && !p.need_all) {
         int amax = 0;
         for (int t0 = lane; t0 < T; t0 += 64) amax = max(amax, p.audible[(size_t)row * T + t0] & 0xffff);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
+        bool any_needed = false;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) need[j] = __any(valid[j] && vk[j] < amax);
+        for (int j = 0; j < VPL; ++j) {
+            need[j] = __any(valid[j] && vk[j] < amax);
+            any_needed = any_needed || need[j];
+        }
+        if (!any_needed) return;
     }
     // raw loads and arithmetic are kept apart (and free of branches) so that a batch of frames is
     // fetched with all its loads in flight at once
@@ -1441,6 +1448,7 @@ int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shift
     p.f0 = f0_hz; p.shifts = harmonic_shifts; p.inh = harmonic_shifts ? nullptr : inharm_coef;
     p.hd = harmonic_distribution;      // read (and ignored) only when there are neither shifts nor inharm_coef
     p.audible = audible; p.state_in = phase_state_in;
+    p.need_all = 1;          // the state of every oscillator, whether or not this piece lets it be heard
     p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
     p.wlin = wlin;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;

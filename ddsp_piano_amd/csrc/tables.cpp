@@ -106,6 +106,22 @@ int ddspp_resample_tables_host(int T, int N, int rule, int* lo, int* hi, float* 
     return DDSPP_OK;
 }
 
+// Interpolation weights of samples first_sample .. first_sample + n - 1 of a signal upsampled by N / T (a streamed
+// piece, ddspp_polyphonic_additive with phase_state_in): the resize kernel multiplies float32(n) by the float32 scale
+// at the ABSOLUTE n, and the rounding of that product depends on its magnitude -- a piece that wants the one-call
+// render's numbers takes them from here.  first_sample = 0, n = N gives w of ddspp_resample_tables_host.
+int ddspp_linear_weights_host(int T, int N, int rule, long long first_sample, int n, float* w) {
+    DDSPP_REQUIRE(T >= 1 && N >= 1 && n >= 1 && first_sample >= 0 && w, "linear_weights_host: bad arguments");
+    DDSPP_REQUIRE(rule == 0 || rule == 1, "linear_weights_host: unknown rule %d", rule);
+    const float scale = (float)T / (float)N;
+    for (int i = 0; i < n; ++i) {
+        const float x = (float)(first_sample + i);
+        const float pos = rule == 1 ? (x + 0.5f) * scale - 0.5f : x * scale;
+        w[i] = pos - floorf(pos);
+    }
+    return DDSPP_OK;
+}
+
 // Length of the FIRs frequency_impulse_response(magnitudes[..., K], window_size) returns, and the number of even/odd
 // table rows NJ (0 when the even/odd design kernels do not take this shape: K not in {32, 64, 96, 128} or a cropped window).
 int ddspp_fir_tables_shape(int K, int window_size, int* Lw, int* NJ) {

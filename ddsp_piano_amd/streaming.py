@@ -9,6 +9,9 @@ internally between two samples.  For this path that is exactly:
     of the chunks' end phases -- one float per (voice, oscillator), ``core.oscillator_phase_state`` -- provided a piece
     starts on a chunk boundary: pieces are multiples of BLOCK = 1000 / gcd(U, 1000) frames (125 frames = 0.5 s for
     every shipped sample rate); plus ONE frame of look-ahead, because frame t is interpolated towards frame t + 1;
+    plus the piece's ABSOLUTE sample position: the reference's bilinear resize forms float32(n) * (T / N) and takes
+    its fractional part as the interpolation weight, which rounds differently at n = 12000 and n = 1212000
+    (core.linear_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128;
   * FilteredNoise: the time-varying FIR reaches Lw - 1 - delay samples back and `delay` samples forward, at most one
     frame each way: the piece is filtered with one frame of context on either side and cropped.  Noise samples are
     addressed by their absolute position (explicit ``noise=`` rows, or the library's counter-based Philox stream), so a
@@ -108,10 +111,11 @@ class StreamingSynthesizer:
         inh_rows = ctl['_inharm_coef'].reshape(R, Tc)
         mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, Tc), ctl['harmonic_distribution'], None,
                                        B, Tc * U, add.sample_rate, voice_major=vm, audible=ctl['_audible'],
-                                       inharm_coef=inh_rows, phase_state=self.phase)[:, :n]
+                                       inharm_coef=inh_rows, phase_state=self.phase, sample_offset=self.frame * U)[:, :n]
         if not (final and nb == have):
             self.phase = core.oscillator_phase_state(ctl['f0_hz'], n // 1000, U, add.sample_rate, inharm_coef=inh_rows,
-                                                     n_harmonics=H, phase_state=self.phase, audible=ctl['_audible'])
+                                                     n_harmonics=H, phase_state=self.phase, audible=ctl['_audible'],
+                                                     sample_offset=self.frame * U)
         # ---- noise: one frame of context either side
         mags_now, _ = self._rows(self.nkeys[0], sl, vm)
         hist = 0 if self._prev is None else 1

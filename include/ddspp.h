@@ -63,6 +63,11 @@ int ddspp_hann_window_host(int n, float* window);
  * rule 1: half-pixel centres.  `wlin` of ddspp_harmonic_synthesis / ddspp_polyphonic_additive is w (they require
  * *aligned == 1: N = T * U and lo[n] == n / U, true for rule 0 and every shipped sample / frame rate pair). */
 int ddspp_resample_tables_host(int T, int N, int rule, int* lo, int* hi, float* w, int* aligned);
+/* w[n] for samples first_sample .. first_sample + n - 1 of a signal with T frames per N samples: `wlin` of a streamed
+ * piece (ddspp_polyphonic_additive / ddspp_oscillator_phase_state with phase_state_in).  The resize kernel multiplies
+ * float32(sample index) by the float32 scale at the ABSOLUTE index; the fractional part rounds differently at
+ * different magnitudes, so a piece takes the weights the one-call render has at its positions. */
+int ddspp_linear_weights_host(int T, int N, int rule, long long first_sample, int n, float* w);
 /* FIR length Lw of ddsp.core.frequency_impulse_response(magnitudes[.., K], window_size) and the row count NJ of the
  * even/odd tables (0: the shape has none -- use ddspp_fir_matrix_host + ddspp_fir_from_magnitudes). */
 int ddspp_fir_tables_shape(int K, int window_size, int* Lw, int* NJ);
@@ -126,7 +131,8 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
  * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.
  * phase_state_in[R, S*H] (may be NULL): streaming -- these controls continue a signal; every oscillator starts from the
  * float32 running sum of chunk end phases the previous call left (ddspp_oscillator_phase_state).  The call must start
- * on a 1000-sample chunk boundary of the whole signal (a multiple of lcm(U, 1000) / U frames).
+ * on a 1000-sample chunk boundary of the whole signal (a multiple of lcm(U, 1000) / U frames), and wlin then holds the
+ * weights of the piece's absolute sample positions (ddspp_linear_weights_host).
  * audio_last[B, T*U] (may be NULL): when given, the LAST voice's stem goes there and `audio` holds the sum of voices
  * 0 .. P-2 -- the reference's DAG re-uses one additive processor for all voices, so its outputs dictionary keeps the
  * last voice's signal next to the mix (polyphonic_dag.py:28-37, piano_model.py:160-164). */

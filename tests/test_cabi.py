@@ -111,6 +111,21 @@ def test_host_table_builders_agree_with_the_python_layer():
             assert lib.ddspp_resample_tables_host(T, N, rule, ptr(lo), ptr(hi), ptr(w), ctypes.byref(al)) == 0
             plo, phi, pw, pal = core._linear_tables_np(T, N, name)
             assert np.array_equal(lo, plo) and np.array_equal(hi, phi) and np.array_equal(w, pw) and bool(al.value) == pal
+            # a streamed piece: the weights of absolute positions = the matching slice of the long signal's table,
+            # which is what the host layer builds with torch (core.linear_weights)
+            if N % T == 0 and N >= 64:
+                first, n = N // 2, N // 4
+                wp = np.empty(n, np.float32)
+                assert lib.ddspp_linear_weights_host(T, N, rule, first, n, ptr(wp)) == 0
+                assert np.array_equal(wp, pw[first:first + n])
+                prev = core.set_recalled(resize=name)
+                try:
+                    tp = max(T // 4, 1)
+                    wt = core.linear_weights(tp, tp * (N // T), 'cpu', first).numpy()
+                finally:
+                    core.set_recalled(**prev)
+                m = min(n, wt.size)
+                assert np.array_equal(wt[:m], pw[first:first + m])
     for K, ws in ((96, 257), (64, 257), (32, 257), (128, 257), (200, 257), (65, 0), (129, 257), (200, 101)):
         lw, nj = ctypes.c_int(), ctypes.c_int()
         assert lib.ddspp_fir_tables_shape(K, ws, ctypes.byref(lw), ctypes.byref(nj)) == 0

@@ -90,3 +90,38 @@ def test_time_ranges_rendered_from_scratch():
     one = streaming.render_range(make, feats, 0, T)
     two = torch.cat([streaming.render_range(make, feats, 0, 375), streaming.render_range(make, feats, 375, T)], dim=1)
     assert (one - two).abs().max().item() < 3e-5 * float(one.abs().max())
+
+
+def test_state_of_oscillators_that_are_silent_for_a_whole_piece():
+    """A partial that is above Nyquist for a whole piece still advances its phase in the reference (angular_cumsum runs
+    on every frequency envelope, inharm_synth.py:65-75).  Many rows (the memoised phase walk, which skips silent
+    64-partial groups inside ONE call): block 1 glides at a high pitch, block 2 holds it, block 3 drops seven octaves
+    lower partials 64..127 come in -- with the phase they accumulated during blocks 1 and 2."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import streaming
+    rng = np.random.default_rng(77)
+    sr, B, P, T, H, K, S = 24000, 16, 16, 375, 128, 96, 1
+    U = sr // 250
+    feats = {}
+    t = np.arange(T)
+    pitch = np.where(t < 125, 1000.0 * (1.0 + 0.1 * t / 125.0), np.where(t < 250, 1100.0, 55.0))
+    for i in range(P):
+        c = synth_controls(rng, B, T, H, S=S, K=K, silent_frac=0.0)
+        c['f0_hz'] = (pitch[None, :, None] * (1.0 + 0.01 * rng.random([B, 1, 1]))).astype(np.float32) * np.ones([1, 1, S], np.float32)
+        c['inharm_coef'] = np.full([B, T, 1], 1e-4, np.float32)
+        c['amplitudes'] = np.zeros([B, T, 1], np.float32)
+        for k, v in c.items():
+            feats[f'{k}_{i}'] = torch.as_tensor(v, device='cuda')
+    noise = torch.zeros([B, P, T * U], device='cuda')
+    a, z, _ = _processors(dp, sr)
+    whole = dp.ProcessorGroup(dp.polyphonic_dag(a, z, None, n_synths=P, **{**KEYS, 'reverb_controls': []}))(
+        feats, noise=noise)
+    syn = streaming.StreamingSynthesizer(*_processors(dp, sr)[:2], None, n_synths=P)
+    outs, t0 = [], 0
+    for t1 in (126, 251, T):
+        outs.append(syn.push({k: v[:, t0:t1] for k, v in feats.items()}, noise=noise[:, :, t0 * U:t1 * U], final=(t1 == T)))
+        t0 = t1
+    got = torch.cat(outs, dim=1)
+    assert got.shape == whole.shape
+    err = (got - whole)[:, 250 * U:].abs().max().item()
+    assert err < 1e-6 * float(whole[:, 250 * U:].abs().max()), err
