@@ -471,6 +471,48 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 // adds them up in chunk order -- the same float32 sums in the same order.  A row whose frequencies move in every
 // frame (vibrato, glides) costs 72 sample-by-sample chunk scans: one wavefront took 10 ms for them at batch 64, four
 // at twice the occupancy take 0.3 ms; rows of held notes cost what they did (one memoised scan per wavefront).
+// BLK samples of the phase scan `ph += omega(x0 + (x1 - x0) * w[i])` for one oscillator per lane, in stages that keep
+// BLK independent chains in flight: interpolate all BLK frequencies, scale them all, divide them all, and only then
+// the BLK dependent adds.  Written sample after sample the compiler funnels every omega through the same two
+// temporaries -- one dependent chain of forty instructions per step, and a dependent wave64 instruction issues every
+// 4.4 cycles instead of 2.3 whatever the other wavefronts of the SIMD do (tools/ubench/valu_latency): the
+// moving-frequency pre-pass ran at a third of the issue rate.  srv / rsrv: sample rate and its reciprocal in VECTOR
+// registers (an SGPR operand in a VOP3 fma costs 4.2 cycles).  Arithmetic and order are those of omega_of.
+template <bool FAST>
+__device__ __forceinline__ float scan_block_staged(float ph, float x0, float x1, const float* w, float srv, float rsrv) {
+    float om[BLK], q[BLK];
+    const float dx = x1 - x0;
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = dx * w[i];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = x0 + om[i];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = om[i] * DDSPP_TWO_PI_F32;          // inharm_synth.py:69
+    if (FAST) {                                                              // :70, div_const (ddspp_common.h)
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) q[i] = om[i] * rsrv;
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(-q[i], srv, om[i]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(om[i], rsrv, q[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = om[i] / srv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) ph = ph + om[i];
+    __builtin_amdgcn_sched_barrier(0);
+    return ph;
+}
+
+__device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value copied into a vector register
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
+constexpr int PRE_W = 1024;             // floats of LDS per wavefront for a chunk's interpolation weights (>= DDSPP_CHUNK)
 template <int VPL, int PARTS>
 __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
@@ -478,11 +520,15 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     const int part = wave_uniform(threadIdx.x >> 6);
     const int task = PARTS > 1 ? (int)blockIdx.x : wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (PARTS == 1 && task >= p.R * p.groups) return;
-    const int row = task / p.groups, grp = task - row * p.groups;
+    // group-major task order: consecutive workgroups (which go round-robin to the 8 XCDs) are consecutive ROWS.  With the
+    // groups of a row next to each other, group 1 of 2 (partials 65..128: above Nyquist for most notes, no work) took
+    // every odd XCD and the four even ones did all the scanning.
+    const int grp = task / p.R, row = task - grp * p.R;
     const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
     const int vbase = grp * p.vgrp, vlast = min(vbase + p.vgrp, p.V) - 1;
     typedef const __attribute__((address_space(4))) float* cfloat_p;
-    const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
+    // LDS: [npre][VPL][64] chunk end phases (PARTS > 1), then one PRE_W-float weight buffer per wavefront
+    float* wlds = lds_dyn + (PARTS > 1 ? (size_t)p.npre * VPL * 64 : 0) + (size_t)(threadIdx.x >> 6) * PRE_W;
 
     int vk[VPL], vs[VPL], vidx[VPL];
     bool valid[VPL];
@@ -688,27 +734,38 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                 return p.fastdiv && __all(ok);
             };
             bool fast = pair_ok();
+            const float srv = in_vgpr(p.sr), rsrv = in_vgpr(p.rsr);
+            // the chunk's interpolation weights go through LDS (one coalesced fetch per chunk, then two broadcast
+            // ds_read_b128 per step, requested a step ahead).  Scalar loads a step ahead were not enough here: a step
+            // is 70 instructions, a scalar-cache miss over a thousand cycles, and with every wavefront of the SIMD
+            // waiting for its weights the kernel ran at a third of its issue rate (profiles/, moving-f0 case).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = (lane + 64 * i) * 4;
+                if (idx < n_hi - n_lo)
+                    *reinterpret_cast<float4*>(wlds + idx) = *reinterpret_cast<const float4*>(p.wlin + n_lo + idx);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float wl[BLK], wn[BLK];
-#pragma unroll
-            for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n_lo + i];
+            auto weights_at = [&](int off, float* w) {
+                const float4 wa = *reinterpret_cast<const float4*>(wlds + off);
+                const float4 wb = *reinterpret_cast<const float4*>(wlds + off + 4);
+                w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w;
+                w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+            };
+            weights_at(0, wl);
             for (int n = n_lo; n < n_hi; n += BLK) {
-                const int nn = min(n + BLK, N - BLK);
-#pragma unroll
-                for (int i = 0; i < BLK; ++i) wn[i] = wlin_c[nn + i];
+                weights_at(min(n + BLK, n_hi - BLK) - n_lo, wn);
                 if (fast) {
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) {
-                        const float dx = x1[j] - x0[j];
-#pragma unroll
-                        for (int i = 0; i < BLK; ++i) ph[j] = ph[j] + omega_of<true>(x0[j] + dx * wl[i], p.sr, p.rsr);
-                    }
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<true>(ph[j], x0[j], x1[j], wl, srv, rsrv);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) {
-                        const float dx = x1[j] - x0[j];
-#pragma unroll
-                        for (int i = 0; i < BLK; ++i) ph[j] = ph[j] + omega_of<false>(x0[j] + dx * wl[i], p.sr, p.rsr);
-                    }
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv);
                 }
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
@@ -838,14 +895,22 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
             x0[j] = hfs[(0 * VPL + j) * 64 + lane];
             x1[j] = hfs[(1 * VPL + j) * 64 + lane];
         }
-        for (int n = n_lo; n < n_hi; ++n) {
-            const float wl = wlin_c[n];
+        const float srv = in_vgpr(p.sr), rsrv = in_vgpr(p.rsr);
+        // BLK samples per step (a step never straddles a frame: U % BLK == 0, chunks start on multiples of BLK); the
+        // step's weights are one scalar load, requested a step ahead
+        float wl[BLK], wn[BLK];
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const float fe = x0[j] + (x1[j] - x0[j]) * wl;
-                ph[j] = ph[j] + omega_of<false>(fe, p.sr, p.rsr);
-            }
-            if (++r == U) {
+        for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n_lo + i];
+        for (int n = n_lo; n < n_hi; n += BLK) {
+            const int nn = min(n + BLK, n_hi - BLK);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) wn[i] = wlin_c[nn + i];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
+            r += BLK;
+            if (r == U) {
                 r = 0;
                 ++tt;
 #pragma unroll
@@ -1105,21 +1170,22 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
 // Launch of the memoised pre-pass: `tasks` (row, group) pairs.  Four wavefronts per pair (PARTS = 4) whenever the
 // chunk end phases of a row fit in LDS; one wavefront per pair otherwise (very long rows).
 static void launch_memo_prepass(int vpl, const OscParams& q, int tasks, hipStream_t stream) {
+    const size_t ldsw = (size_t)4 * PRE_W * sizeof(float);              // weight buffers of the four wavefronts
     const size_t lds4 = (size_t)q.npre * vpl * 64 * sizeof(float);
-    const bool parts4 = vpl <= 2 && q.npre >= 8 && lds4 <= 64 * 1024 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
+    const bool parts4 = vpl <= 2 && q.npre >= 8 && lds4 + ldsw <= 64 * 1024 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
     if (parts4) {
-        if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks), dim3(256), lds4, stream, q);
-        else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks), dim3(256), lds4, stream, q);
+        if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks), dim3(256), lds4 + ldsw, stream, q);
+        else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks), dim3(256), lds4 + ldsw, stream, q);
         return;
     }
     const dim3 grid((tasks + 3) / 4), blk(256);
     switch (vpl) {
-        case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 1>), grid, blk, 0, stream, q); break;
-        case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 1>), grid, blk, 0, stream, q); break;
-        case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3, 1>), grid, blk, 0, stream, q); break;
-        case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4, 1>), grid, blk, 0, stream, q); break;
-        case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6, 1>), grid, blk, 0, stream, q); break;
-        default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8, 1>), grid, blk, 0, stream, q); break;
+        case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 1>), grid, blk, ldsw, stream, q); break;
+        case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 1>), grid, blk, ldsw, stream, q); break;
+        case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3, 1>), grid, blk, ldsw, stream, q); break;
+        case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4, 1>), grid, blk, ldsw, stream, q); break;
+        case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6, 1>), grid, blk, ldsw, stream, q); break;
+        default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8, 1>), grid, blk, ldsw, stream, q); break;
     }
 }
 
