@@ -10,10 +10,21 @@
 
 namespace ddspp {
 
+// Sum over the 64 lanes, the same value returned to all of them, on the DPP data path: four in-row steps (quad swaps,
+// half-row and row mirrors) and two row broadcasts, then the total is read from lane 63.  (Six ds_bpermute round
+// trips -- what __shfl_xor compiles to -- were a dependent chain of LDS latencies in every frame of this kernel.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_take<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);       // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);       // row_mirror: every lane holds its row's sum
+    v += dpp_take<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(v);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 struct InharmParams {
@@ -41,7 +52,8 @@ template <int HPL>
 __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmParams p) {
     const int lane = threadIdx.x & 63;
     const size_t nframes = (size_t)p.R * p.T;
-    const size_t frame0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * CTL_FPW;
+    // wave-uniform by construction: saying so keeps the frame bookkeeping and the row base addresses in scalar registers
+    const size_t frame0 = ((size_t)blockIdx.x * 4 + (size_t)wave_uniform(threadIdx.x >> 6)) * CTL_FPW;
     if (frame0 >= nframes) return;
     const int H = p.H;
     float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
@@ -71,21 +83,44 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
         float amp = apply_scale(p.scale, raw_amp[u]);                   // :185
         float hd[HPL], shift[HPL], freq[HPL];
         float sum = 0.0f;
+        // Where this frame sits (only the last voice's shifts are kept when shifts_out is null)
+        bool is_last = false;
+        unsigned row = row0, tt = tt0 + (unsigned)u;
+        if (p.shifts_last) {       // (row, frame-in-row) from the wavefront's first frame: one division per wavefront
+            if (tt >= (unsigned)p.T) {
+                tt -= (unsigned)p.T;
+                ++row;
+            }
+            is_last = p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1;
+        }
+        const bool want_shift = p.shifts_out != nullptr || is_last;                    // wave-uniform
+        // A 64-harmonic group whose FIRST harmonic is already at or above Nyquist is cut to zero whatever its raw
+        // values (:200-208; the frequencies grow with the harmonic number and the inharmonicity factor is >= 1, so
+        // f0 * (64 j + 1) >= nyquist settles it for the whole group): with the cut before the normalisation (the
+        // default flags) the group contributes nothing to the sum either, and its scale function, square roots and
+        // divisions are skipped.  For a piano, harmonics 65..128 are above Nyquist for every note above F#3.
+        const bool cut_first = p.normalize_below_nyquist && p.normalize_after_nyquist_cut;
+        bool dead_grp[HPL];
 #pragma unroll
         for (int j = 0; j < HPL; ++j) {
             const int k = lane + 64 * j;
             hd[j] = 0.0f;
             shift[j] = 0.0f;
             freq[j] = 0.0f;
+            const bool dead = cut_first && f0 * (float)(64 * j + 1) >= p.nyquist;     // wave-uniform
+            dead_grp[j] = dead;
+            if (dead && !want_shift) continue;
             if (k < H) {
-                hd[j] = apply_scale(p.scale, raw_hd[u][j]);                                 // :186
                 const float m = (float)(k + 1);
                 float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
                 g = g * inharm + 1.0f;                 //                                        :38
                 g = sqrtf(g);                          //                                        :39
-                freq[j] = (f0 * m) * g;                // f0_hz * int_multiplier * inharm_factor :42
                 shift[j] = g - 1.0f;                   //                                        :44  (= osc_common.h shift_from_inharm)
-                sum += hd[j];
+                if (!dead) {
+                    hd[j] = apply_scale(p.scale, raw_hd[u][j]);                             // :186
+                    freq[j] = (f0 * m) * g;            // f0_hz * int_multiplier * inharm_factor :42
+                    sum += hd[j];
+                }
             }
         }
         if (!p.normalize_after_nyquist_cut) {                                // :194-198
@@ -111,7 +146,8 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             const float tot = wave_sum(sum);
             const float den = tot == 0.0f ? 1e-7f : tot;
 #pragma unroll
-            for (int j = 0; j < HPL; ++j) hd[j] = hd[j] / den;
+            for (int j = 0; j < HPL; ++j)
+                if (!dead_grp[j]) hd[j] = hd[j] / den;                       // (a cut group stays 0)
         }
         amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
 #pragma unroll
@@ -123,13 +159,6 @@ __global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmPa
             }
         }
         if (p.shifts_last) {       // what the outputs dictionary of the reference's DAG keeps: the last voice's controls
-            // (row, frame-in-row) of this frame from the wavefront's first frame: one division per wavefront, not per frame
-            unsigned row = row0, tt = tt0 + (unsigned)u;
-            if (tt >= (unsigned)p.T) {
-                tt -= (unsigned)p.T;
-                ++row;
-            }
-            const bool is_last = p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1;
             if (is_last) {
                 const unsigned b = p.vmajor ? row - last_lo : row / (unsigned)p.P;
 #pragma unroll
