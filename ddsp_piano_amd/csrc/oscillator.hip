@@ -205,9 +205,9 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
             if (CONTIG && VPL > 1) {
                 typedef float vecf __attribute__((ext_vector_type(VPL)));
                 const size_t o = base + vcol[0];
-                const vecf f = *reinterpret_cast<const vecf*>(fe_row + o);
+                const vecf f = __builtin_nontemporal_load(reinterpret_cast<const vecf*>(fe_row + o));
                 vecf a = {};
-                if (MODE != MODE_PREPASS) a = *reinterpret_cast<const vecf*>(ae_row + o);
+                if (MODE != MODE_PREPASS) a = __builtin_nontemporal_load(reinterpret_cast<const vecf*>(ae_row + o));
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     fb[i][j] = f[j];
