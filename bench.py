@@ -19,7 +19,7 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
   * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
                      TF/ddsp reference here) and an op-by-op torch-CPU version on all cores, timed on this host;
   * step_ms        : per-step HIP-event times (median / min / max) of the headline call;
-  * audio_only_call, dense_worst_case, moving_f0, single_stream, whole_file: other call forms / inputs.
+  * audio_only_call, dense_worst_case, moving_f0, single_stream (+ hipGraph replay), whole_file: other call forms / inputs.
 Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no torchrun environment the script
 starts the N ranks itself (torch.distributed.run, one process per GPU) and fails loudly when the box has fewer
 than N GPUs.
@@ -504,6 +504,14 @@ def main():
         d1 = min(time_steps(lambda: call(pg1, f1), 20, 3) for _ in range(3))          # best of three runs of 20
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
+        # the same call captured once as a HIP graph and replayed (inputs copied into the captured buffers, fresh
+        # noise drawn, per call): what a launch-bound caller -- one stream, streaming blocks -- would use
+        from ddsp_piano_amd.graph import CapturedGroup
+        cg = CapturedGroup(pg1, f1, return_outputs_dict=(args.call_form == 'outputs_dict'))
+        dg = min(time_steps(lambda: cg(f1), 20, 3) for _ in range(3))
+        extra['single_stream_graph'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay',
+                                        'ms_per_segment': dg / 20 * 1e3, 'rtf': (N * 20 / dg) / sr}
+        del cg
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
