@@ -512,7 +512,7 @@ __device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value
     return v;
 }
 
-constexpr int PRE_W = 1024;             // floats of LDS per wavefront for a chunk's interpolation weights (>= DDSPP_CHUNK)
+constexpr int PRE_W = 256;              // floats of LDS per wavefront: the interpolation weights of the next PRE_W samples
 template <int VPL, int PARTS>
 __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
@@ -735,21 +735,19 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
             };
             bool fast = pair_ok();
             const float srv = in_vgpr(p.sr), rsrv = in_vgpr(p.rsr);
-            // the chunk's interpolation weights go through LDS (one coalesced fetch per chunk, then two broadcast
-            // ds_read_b128 per step, requested a step ahead).  Scalar loads a step ahead were not enough here: a step
-            // is 70 instructions, a scalar-cache miss over a thousand cycles, and with every wavefront of the SIMD
-            // waiting for its weights the kernel ran at a third of its issue rate (profiles/, moving-f0 case).
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = (lane + 64 * i) * 4;
-                if (idx < n_hi - n_lo)
-                    *reinterpret_cast<float4*>(wlds + idx) = *reinterpret_cast<const float4*>(p.wlin + n_lo + idx);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the interpolation weights go through LDS, PRE_W samples at a time (one coalesced float4 per lane, then two
+            // broadcast ds_read_b128 per step, requested a step ahead).  Scalar loads a step ahead were not enough
+            // here: a step is 60 instructions, a scalar-cache miss over a thousand cycles.
+            auto stage_weights = [&](int n_first) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int idx = lane * 4;
+                if (n_first + idx < n_hi)
+                    *reinterpret_cast<float4*>(wlds + idx) = *reinterpret_cast<const float4*>(p.wlin + n_first + idx);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
             float wl[BLK], wn[BLK];
             auto weights_at = [&](int off, float* w) {
                 const float4 wa = *reinterpret_cast<const float4*>(wlds + off);
@@ -757,9 +755,13 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                 w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w;
                 w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
             };
-            weights_at(0, wl);
             for (int n = n_lo; n < n_hi; n += BLK) {
-                weights_at(min(n + BLK, n_hi - BLK) - n_lo, wn);
+                const int woff = (n - n_lo) & (PRE_W - 1);
+                if (woff == 0) {                   // (the look-ahead never crosses a refill: the step reads its own weights)
+                    stage_weights(n);
+                    weights_at(0, wl);
+                }
+                if (woff + BLK < PRE_W && n + BLK < n_hi) weights_at(woff + BLK, wn);
                 if (fast) {
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<true>(ph[j], x0[j], x1[j], wl, srv, rsrv);
