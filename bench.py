@@ -264,12 +264,13 @@ def measure_roofline_step(dp, base, args, T, U, device):
     R = B * P
     additive = dp.MultiInharmonic(sample_rate=args.sample_rate, inference=True)
     ctl = additive._controls(base['amplitudes'].reshape(R, T, 1), base['harmonic_distribution'].reshape(R, T, H),
-                             base['inharm_coef'].reshape(R, T, 1), base['f0_hz'].reshape(R, T, S), want_counts=True)
+                             base['inharm_coef'].reshape(R, T, 1), base['f0_hz'].reshape(R, T, S), want_counts=True,
+                             want_shifts=False)
 
-    def launch():
+    def launch():          # as the batched group calls it: shifts formed in the kernels from inharm_coef
         core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],
-                                 ctl['harmonic_shifts'], B, N, args.sample_rate, voice_major=False,
-                                 audible=ctl['_audible'])
+                                 None, B, N, args.sample_rate, voice_major=False, audible=ctl['_audible'],
+                                 inharm_coef=ctl['_inharm_coef'].reshape(R, T))
 
     ts = event_times(launch, 10, warmup=2)
     t = float(np.median(ts)) * 1e-3
@@ -284,6 +285,13 @@ def measure_roofline_step(dp, base, args, T, U, device):
             insts = float(prof['valu_wave_instructions_per_call'])
             out.update({'valu_wave_instructions': insts, 'achieved': insts / t,
                         'frac': insts / t / out['peak'], 'counters': prof.get('source')})
+            trans = float(prof.get('valu_trans_wave_instructions_per_call', 0.0))
+            if trans:
+                # a v_cos_f32 / v_sqrt_f32 / v_rcp_f32 occupies the SIMD for 8 cycles, not 2: the share of the call's
+                # time its instruction mix accounts for at full issue rate (1.0 = nothing but issue cycles)
+                out.update({'valu_trans_wave_instructions': trans,
+                            'frac_mix': ((insts - trans) * 2.0 + trans * 8.0) / (N_SIMDS * MAX_CLOCK_HZ * t),
+                            'frac_mix_note': 'issue cycles with transcendentals at 8 cycles / (1024 SIMDs x 2.4 GHz x time)'})
         except Exception:  # noqa: BLE001
             pass
     return out

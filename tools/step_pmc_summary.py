@@ -36,7 +36,7 @@ def main(out):
                 dur[k] = dur.get(k, 0.0) + float(row['TotalDurationNs'])
                 calls[k] = calls.get(k, 0) + int(row['Calls'])
     ctr = defaultdict(dict)
-    for sub in ('a', 'b', 'f', 'w'):
+    for sub in ('a', 'b', 'c', 'f', 'w'):
         for k, cs in pmc(os.path.join(out, sub)).items():
             for c, v in cs.items():
                 ctr[k][c] = sum(v) / len(v)
@@ -56,6 +56,10 @@ def main(out):
             # kernel time under the counter pass differs slightly from the trace pass: use the pass's own GRBM cycles
             frac = c['SQ_INSTS_VALU'] * 2.0 / (SIMDS * gui)
             print(f'    -> clock {clk / 1e9:.3f} GHz; VALU issue fraction (2 cycles per wave64 instruction) = {frac:.3f}')
+            if c.get('SQ_INSTS_VALU_TRANS_F32'):
+                tr = c['SQ_INSTS_VALU_TRANS_F32']
+                mix = ((c['SQ_INSTS_VALU'] - tr) * 2.0 + tr * 8.0) / (SIMDS * gui)
+                print(f'    -> with the {tr / c["SQ_INSTS_VALU"]:.1%} quarter-rate transcendentals at 8 cycles: {mix:.3f} of the issue cycles')
         if 'SQ_ACTIVE_INST_VALU' in c and 'SQ_BUSY_CYCLES' in c and gui:
             print(f'    -> SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY = {c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_ACTIVE_INST_ANY", 1.0), 1.0):.2f}')
         if 'FETCH_SIZE' in c or 'WRITE_SIZE' in c:
@@ -69,9 +73,10 @@ def main(out):
     tot = sum(ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels)
     if tot:
         import json
-        json.dump({'valu_wave_instructions_per_call': tot,
+        trans = sum(ctr[k].get('SQ_INSTS_VALU_TRANS_F32', 0.0) for k in add_kernels)
+        json.dump({'valu_wave_instructions_per_call': tot, 'valu_trans_wave_instructions_per_call': trans,
                    'kernels': {k: ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels},
-                   'source': 'rocprofv3 --pmc SQ_INSTS_VALU over bench.py --steps 3 --warmup 1 (tools/step_pmc.sh), '
+                   'source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_TRANS_F32 over bench.py --steps 3 --warmup 1 (tools/step_pmc.sh), '
                              'per-launch averages of the kernels of ddspp_polyphonic_additive at BASELINE config 3'},
                   open(os.path.join(out, 'step_valu.json'), 'w'), indent=1)
 
