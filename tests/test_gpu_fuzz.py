@@ -43,22 +43,30 @@ def musical_controls(rng, R, T, H, S, sr):
     return dict(amplitudes=amp, harmonic_distribution=hd, inharm_coef=inh, f0_hz=f0)
 
 
-CASES = [  # (seed, B, P, T, H, S, U)
-    (1, 1, 4, 60, 128, 1, 96), (2, 2, 3, 130, 96, 2, 64), (3, 3, 5, 47, 64, 1, 128), (4, 1, 16, 260, 128, 1, 96),
-    (5, 16, 16, 64, 128, 1, 96),            # 256 rows: the memoised pre-pass (and its silent-group exit)
-    (6, 20, 16, 33, 96, 2, 64), (7, 2, 2, 700, 48, 1, 32), (8, 1, 1, 300, 192, 1, 128), (9, 5, 7, 90, 16, 1, 192),
+CASES = [  # (seed, B, P, T, H, S, U, flags)
+    (1, 1, 4, 60, 128, 1, 96, {}), (2, 2, 3, 130, 96, 2, 64, {}), (3, 3, 5, 47, 64, 1, 128, {}), (4, 1, 16, 260, 128, 1, 96, {}),
+    (5, 16, 16, 64, 128, 1, 96, {}),            # 256 rows: the memoised pre-pass (and its silent-group exit)
+    (6, 20, 16, 33, 96, 2, 64, {}), (7, 2, 2, 700, 48, 1, 32, {}), (8, 1, 1, 300, 192, 1, 128, {}), (9, 5, 7, 90, 16, 1, 192, {}),
+    # the ENSTDkCl configurations' flags (ENSTDkCl-8kHz.gin / -32kHz.gin): exp_tanh, no renormalisation after the cut
+    (31, 2, 16, 120, 48, 1, 32, dict(scale='exp_tanh', normalize_after_nyquist_cut=False)),
+    (32, 1, 8, 90, 192, 1, 128, dict(scale='exp_tanh', normalize_after_nyquist_cut=False)),
+    # partials are NOT cut at the frame rate: only the per-sample mask of the oscillator bank silences them
+    (33, 2, 5, 80, 128, 1, 96, dict(normalize_below_nyquist=False)),
+    (34, 17, 16, 50, 128, 1, 96, dict(normalize_below_nyquist=False, normalize_after_nyquist_cut=False)),
 ]
 
 
-@pytest.mark.parametrize('seed,B,P,T,H,S,U', CASES)
-def test_compacted_bank_equals_the_stems(seed, B, P, T, H, S, U):
+@pytest.mark.parametrize('seed,B,P,T,H,S,U,flags', CASES)
+def test_compacted_bank_equals_the_stems(seed, B, P, T, H, S, U, flags):
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import core
     rng = np.random.default_rng(seed)
     sr = 250 * U
     R, N = B * P, T * U
     raw = musical_controls(rng, R, T, H, S, sr)
-    add = dp.MultiInharmonic(sample_rate=sr, inference=True)
+    flags = dict(flags)
+    scale_name = flags.pop('scale', 'exp_sigmoid')
+    add = dp.MultiInharmonic(sample_rate=sr, inference=True, scale_fn=getattr(dp, scale_name), **flags)
     dev = [torch.as_tensor(raw[k], device='cuda') for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]
     ctl = add._controls(*dev, want_counts=True)
     amp = ctl['amplitudes'].reshape(R, T).contiguous()
@@ -83,7 +91,8 @@ def test_compacted_bank_equals_the_stems(seed, B, P, T, H, S, U):
     assert (last - stems[:, P - 1]).abs().max().item() < 6e-6 * scale
     assert ((rest + last) - want).abs().max().item() < 6e-6 * scale
     if R * N * H <= 16 * 36000 * 128:                      # small enough for the numpy oracle: a few seconds
-        ref = O.MultiInharmonic(sample_rate=sr, inference=True)(**raw).reshape(B, P, N).sum(1)
+        ref = O.MultiInharmonic(sample_rate=sr, inference=True, scale_fn=getattr(O, scale_name), **flags)(**raw)
+        ref = ref.reshape(B, P, N).sum(1)
         assert rms_err(outs['counts'].cpu().numpy(), ref) < 2e-6
 
 
