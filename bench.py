@@ -520,6 +520,18 @@ def main():
         extra['single_stream_graph'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay',
                                         'ms_per_segment': dg / 20 * 1e3, 'rtf': (N * 20 / dg) / sr}
         del cg
+        # the library's one-call driver (ddspp_group_run behind ddsp_piano_amd.NativeGroup): the same kernels enqueued
+        # from C++ instead of a dozen ctypes calls -- what a caller without the Python layer gets
+        ng1 = dp.NativeGroup(pg1, f1)
+        dn = min(time_steps(lambda: ng1(f1, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, 3) for _ in range(3))
+        extra['single_stream_native'] = {'workload': extra['single_stream']['workload'] + ', ddspp_group_run',
+                                         'ms_per_segment': dn / 20 * 1e3, 'rtf': (N * 20 / dn) / sr}
+        del ng1
+        ngb = dp.NativeGroup(pg, feats)
+        ts = event_times(lambda: ngb(feats, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, warmup=3)
+        extra['native_group_call'] = {'workload': 'the headline batch and call form through ddspp_group_run',
+                                      'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        del ngb
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)

@@ -9,6 +9,7 @@ Nothing else of the reference (control networks, MIDI file / audio I/O, training
 from . import core  # noqa: F401
 from .core import exp_sigmoid, exp_tanh  # noqa: F401
 from .graph import CapturedGroup  # noqa: F401
+from .native_group import NativeGroup  # noqa: F401
 from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  # noqa: F401
                       fdn_impulse_response)
 from .noise_band_net import FilterBank, NoiseBandNetSynth  # noqa: F401
@@ -23,4 +24,4 @@ __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Ad
            'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'NoiseBandNetSynth',
            'FilterBank', 'Reverb',
            'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag',
-           'Parallelizer', 'CapturedGroup', 'MIDIRoll2Conditioning', 'ensure_sequence_length', 'roll_to_conditioning']
+           'Parallelizer', 'CapturedGroup', 'NativeGroup', 'MIDIRoll2Conditioning', 'ensure_sequence_length', 'roll_to_conditioning']

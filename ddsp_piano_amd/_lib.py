@@ -18,9 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
 SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
-           'noise.hip', 'noise_bands.hip', 'reverb.hip', 'fdn.hip']
+           'noise.hip', 'noise_bands.hip', 'reverb.hip', 'fdn.hip', 'group.cpp']
 ARCH = 'gfx950'
-HEADERS = ['ddspp_common.h', 'osc_common.h']
+HEADERS = ['ddspp_common.h', 'osc_common.h', os.path.join('..', '..', 'include', 'ddspp.h')]
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
 PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'],
@@ -91,6 +91,11 @@ SIGNATURES = {
     'ddspp_reload_options': (None, []),
     'ddspp_hann_window_host': (c_int, [c_int, c_void_p]),
     'ddspp_resample_tables_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ddspp_group_create': (c_int, [c_void_p, c_void_p]),
+    'ddspp_group_destroy': (None, [c_void_p]),
+    'ddspp_group_workspace_bytes': (ctypes.c_size_t, [c_void_p]),
+    'ddspp_group_n_samples': (c_int, [c_void_p]),
+    'ddspp_group_run': (c_int, [c_void_p] * 11 + [ctypes.c_size_t, c_void_p]),
     'ddspp_linear_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
     'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),
     'ddspp_fir_matrix_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,324 @@
+// The polyphonic processor group as ONE call: processor_group(features, return_outputs_dict=True)
+// (ddsp_piano/modules/piano_model.py:160) = the DAG of ddsp_piano/modules/polyphonic_dag.py:24-40 --
+// MultiInharmonic.get_controls / get_signal, FilteredNoise, the MultiAdd chain, Reverb -- for P voices of B segments.
+//
+// ddspp_group_create builds, once per configuration, everything the kernels need besides the caller's tensors: the
+// small tables (host builders of tables.cpp, uploaded here -- the only device memory the library allocates itself) and
+// the rocFFT plan of the reverb.  ddspp_group_run enqueues the whole chain on the caller's stream inside a workspace
+// the caller owns: get_controls over all rows -> compacted oscillator bank -> fused FilteredNoise with voice sums ->
+// add chain -> reverb; with `outputs` also what the reference's outputs dictionary holds (the dry mix, the last
+// voice's stems and conditioned controls, the last `add` node's first operand).  No host synchronisation, no
+// allocation, nothing but kernel launches: the call can be captured in a HIP graph.  The Python layer's batched route
+// (ddsp_piano_amd/polyphonic.py) enqueues the same kernels with the same arguments (tests/test_gpu_native_group.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "ddspp_common.h"
+#include "../../include/ddspp.h"
+
+struct ddspp_group {
+    ddspp_group_config c;
+    int R, N, Lw, NJ, vpr;                 // rows, samples, FIR taps, even/odd table rows, voices per noise row
+    bool fused_noise = true;
+    // device tables
+    float *wlin = nullptr, *whann = nullptr, *CE = nullptr, *CO = nullptr, *tap_we = nullptr, *tap_wo = nullptr;
+    int* tap_idx = nullptr;
+    ddspp_fftconv_plan* plan = nullptr;
+    // workspace layout (byte offsets, 256-byte aligned)
+    size_t o_amp, o_hd, o_aud, o_shl, o_addws, o_mix, o_alast, o_noise, o_zrows, o_zlast, o_zpack, o_dry, o_prev, o_fft, o_ir, total;
+    size_t addws_bytes, fft_bytes;
+    // the noise branch (and the impulse response's transform) does not depend on the additive branch until the mix: for
+    // large batches it runs on a stream of the group's own, forked from and joined to the caller's with two events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint64_t calls = 0;                    // counter of the library's own noise stream (one step per run, as the Python layer)
+};
+
+namespace {
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& host) {
+    DDSPP_HIP_CHECK(hipMalloc((void**)dst, host.size() * sizeof(T)));
+    DDSPP_HIP_CHECK(hipMemcpy(*dst, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DDSPP_OK;
+}
+
+void release(ddspp_group* g) {
+    if (!g) return;
+    (void)hipFree(g->wlin); (void)hipFree(g->whann); (void)hipFree(g->CE); (void)hipFree(g->CO);
+    (void)hipFree(g->tap_we); (void)hipFree(g->tap_wo); (void)hipFree(g->tap_idx);
+    if (g->plan) ddspp_fftconv_plan_destroy(g->plan);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->side) (void)hipStreamDestroy(g->side);
+    delete g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
+    DDSPP_REQUIRE(cfg && out, "group_create: null argument");
+    const ddspp_group_config& c = *cfg;
+    DDSPP_REQUIRE(c.n_segments > 0 && c.n_voices > 0 && c.n_frames >= 2 && c.n_harmonics > 0 && c.n_substrings > 0 &&
+                      c.n_bands > 1 && c.upsampling > 0 && c.ir_length >= 0,
+                  "group_create: bad dimensions");
+    DDSPP_REQUIRE(c.upsampling % 8 == 0, "group_create: upsampling=%d must be a multiple of 8", c.upsampling);
+    DDSPP_REQUIRE(c.n_voices * c.n_substrings <= 64, "group_create: n_voices * n_substrings = %d exceeds 64",
+                  c.n_voices * c.n_substrings);
+    DDSPP_REQUIRE(c.ir_batch == 0 || c.ir_batch == 1 || c.ir_batch == c.n_segments,
+                  "group_create: ir_batch must be 1 or n_segments");
+    ddspp_group* g = new (std::nothrow) ddspp_group();
+    DDSPP_REQUIRE(g, "group_create: out of memory");
+    g->c = c;
+    const int B = c.n_segments, P = c.n_voices, T = c.n_frames, H = c.n_harmonics, S = c.n_substrings, K = c.n_bands,
+              U = c.upsampling;
+    g->R = B * P;
+    g->N = T * U;
+    const int N = g->N, R = g->R;
+    int rc = ddspp_fir_tables_shape(K, c.window_size, &g->Lw, &g->NJ);
+    if (rc == DDSPP_OK && g->NJ <= 0) {
+        ddspp_set_error("group_create: n_bands=%d / window_size=%d has no even/odd FIR tables (K in {32, 64, 96, 128}, full window)",
+                        K, c.window_size);
+        rc = DDSPP_EINVAL;
+    }
+    if (rc != DDSPP_OK) {
+        release(g);
+        return rc;
+    }
+    // the fused FilteredNoise kernel (FIR design + time-varying FIR, voices summed in registers) when the shape fits it,
+    // else the two-call form with per-voice rows (e.g. 16 kHz: more than 16 frames reach a window of 1024 samples)
+    g->fused_noise = ddspp_frequency_filter_eo_supported(N, T, K, g->Lw, c.delay_compensation) != 0;
+    g->vpr = 1;
+    if (g->fused_noise)
+        for (int v : {8, 4, 2})
+            if (P % v == 0) {
+                g->vpr = v;
+                break;
+            }
+    // ---- tables -------------------------------------------------------------------------------------------------
+    {
+        std::vector<int> lo(N), hi(N);
+        std::vector<float> w(N), hann(2 * U);
+        int aligned = 0;
+        rc = ddspp_resample_tables_host(T, N, c.resize_rule, lo.data(), hi.data(), w.data(), &aligned);
+        if (rc == DDSPP_OK && !aligned) {
+            ddspp_set_error("group_create: the bilinear source rows of T=%d -> N=%d are not frame aligned", T, N);
+            rc = DDSPP_EINVAL;
+        }
+        if (rc == DDSPP_OK) rc = ddspp_hann_window_host(2 * U, hann.data());
+        const int kh = K / 2, nj = g->NJ;
+        std::vector<float> CE((size_t)kh * nj), CO((size_t)kh * nj), we((size_t)nj * 4), wo((size_t)nj * 4);
+        std::vector<int> idx((size_t)nj * 4);
+        if (rc == DDSPP_OK) rc = ddspp_fir_eo_tables_host(K, c.window_size, CE.data(), CO.data(), idx.data(), we.data(), wo.data());
+        if (rc == DDSPP_OK) rc = upload(&g->wlin, w);
+        if (rc == DDSPP_OK) rc = upload(&g->whann, hann);
+        if (rc == DDSPP_OK) rc = upload(&g->CE, CE);
+        if (rc == DDSPP_OK) rc = upload(&g->CO, CO);
+        if (rc == DDSPP_OK) rc = upload(&g->tap_we, we);
+        if (rc == DDSPP_OK) rc = upload(&g->tap_wo, wo);
+        if (rc == DDSPP_OK) rc = upload(&g->tap_idx, idx);
+    }
+    if (rc == DDSPP_OK && c.ir_length > 0)
+        rc = ddspp_fftconv_plan_create(B, c.ir_batch ? c.ir_batch : B, N, c.ir_length, &g->plan);
+    if (rc == DDSPP_OK && (long long)R * N >= (long long)ddspp_option("DDSPP_SIDE_STREAM_MIN", 1 << 24) &&
+        !ddspp_option("DDSPP_NO_SIDE_STREAM", 0)) {
+        hipError_t e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            ddspp_set_error("group_create: side stream: %s", hipGetErrorString(e));
+            rc = DDSPP_EHIP;
+        }
+    }
+    if (rc != DDSPP_OK) {
+        release(g);
+        return rc;
+    }
+    // ---- workspace layout ---------------------------------------------------------------------------------------
+    g->addws_bytes = ddspp_polyphonic_additive_workspace_bytes(B, P, T, S, H, U);
+    g->fft_bytes = g->plan ? ddspp_fftconv_workspace_bytes(g->plan) : 0;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = up256(o + bytes);
+        return at;
+    };
+    g->o_amp = take((size_t)R * T * 4);
+    g->o_hd = take((size_t)R * T * H * 4);
+    g->o_aud = take((size_t)R * T * 4);
+    g->o_shl = take((size_t)B * T * H * 4);
+    g->o_addws = take(g->addws_bytes);
+    g->o_mix = take((size_t)B * N * 4);
+    g->o_alast = take((size_t)B * N * 4);
+    g->o_noise = take(((size_t)R * N + 3) / 4 * 4 * 4);
+    g->o_zrows = take((size_t)(R / g->vpr) * N * 4);
+    g->o_zlast = take((size_t)B * N * 4);
+    g->o_zpack = take(g->vpr == 1 ? (size_t)B * (P > 1 ? P - 1 : 1) * N * 4 : 0);
+    g->o_dry = take((size_t)B * N * 4);
+    g->o_prev = take((size_t)B * N * 4);
+    g->o_fft = take(g->fft_bytes);
+    g->o_ir = take(g->fused_noise ? 0 : (size_t)R * T * g->Lw * 4);
+    g->total = o;
+    *out = g;
+    return DDSPP_OK;
+}
+
+void ddspp_group_destroy(ddspp_group* g) { release(g); }
+
+size_t ddspp_group_workspace_bytes(const ddspp_group* g) { return g ? g->total : 0; }
+int ddspp_group_n_samples(const ddspp_group* g) { return g ? g->N : -1; }
+
+int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmonic_distribution, const float* inharm_coef,
+                    const float* f0_hz, const float* magnitudes, const float* reverb_ir, const float* noise, float* audio,
+                    const ddspp_group_outputs* outputs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(g && amplitudes && harmonic_distribution && inharm_coef && f0_hz && magnitudes && audio && workspace,
+                  "group_run: null argument");
+    DDSPP_REQUIRE(workspace_bytes >= g->total, "group_run: workspace too small (%zu < %zu)", workspace_bytes, g->total);
+    DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "group_run: workspace must be 256-byte aligned");
+    DDSPP_REQUIRE(!g->plan == !reverb_ir, "group_run: reverb_ir %s", g->plan ? "is missing" : "given, but the group has no reverb");
+    const ddspp_group_config& c = g->c;
+    const int B = c.n_segments, P = c.n_voices, T = c.n_frames, H = c.n_harmonics, S = c.n_substrings, K = c.n_bands,
+              U = c.upsampling, R = g->R, N = g->N, vm = c.voice_major ? 1 : 0, vpr = g->vpr;
+    char* ws = (char*)workspace;
+    float* amp_c = (float*)(ws + g->o_amp);
+    float* hd_c = (float*)(ws + g->o_hd);
+    int* aud = (int*)(ws + g->o_aud);
+    float* mix = (float*)(ws + g->o_mix);
+    float* dry = g->plan ? (outputs && outputs->dry ? outputs->dry : (float*)(ws + g->o_dry)) : audio;
+    const bool want = outputs != nullptr;
+    const int last_row0 = vm ? (P - 1) * B : P - 1;            // first row of the last voice; its rows are B apart x 1 (vm) or x P
+    const size_t row_step = vm ? 1 : (size_t)P;                // in rows
+    int rc;
+
+    // ---- noise branch (filtered_noise_synth.py:27-42): draw, design + time-varying FIR, voices summed per row; and the
+    //      reverb's impulse responses -> spectra (an input: ready long before the dry mix) -- on the side stream if any ------
+    hipStream_t zs = stream;
+    if (g->side) {
+        DDSPP_HIP_CHECK(hipEventRecord(g->ev_fork, stream));
+        DDSPP_HIP_CHECK(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+        zs = g->side;
+    }
+    if (g->plan && g->side) {
+        rc = ddspp_fftconv_transform_ir(g->plan, reverb_ir, 1, ws + g->o_fft, g->fft_bytes, zs);
+        if (rc != DDSPP_OK) return rc;
+    }
+    const float* z = noise;
+    if (!z) {
+        float* zbuf = (float*)(ws + g->o_noise);
+        rc = ddspp_uniform_noise(zbuf, ((size_t)R * N + 3) / 4 * 4, c.noise_seed, g->calls << 40, zs);
+        if (rc != DDSPP_OK) return rc;
+        ++g->calls;
+        z = zbuf;
+    }
+    float* zrows = (float*)(ws + g->o_zrows);
+    float* zlast = want ? (outputs->noise_last ? outputs->noise_last : (float*)(ws + g->o_zlast)) : nullptr;
+    const bool split_in_kernel = want && vpr > 1;
+    if (g->fused_noise) {
+        rc = ddspp_frequency_filter_eo_voices(z, magnitudes, g->CE, g->CO, g->tap_idx, g->tap_we, g->tap_wo, zrows,
+                                              split_in_kernel ? zlast : nullptr, R, N, T, K, g->Lw, g->NJ, c.delay_compensation,
+                                              c.noise_scale_kind, c.noise_bias, c.noise_exponent, c.noise_max_value,
+                                              c.noise_threshold, c.noise_gain, P, vpr, vm, zs);
+    } else {
+        float* ir = (float*)(ws + g->o_ir);
+        rc = ddspp_fir_from_magnitudes_eo(magnitudes, g->CE, g->CO, g->tap_idx, g->tap_we, g->tap_wo, ir, (size_t)R * T, K, g->Lw,
+                                          g->NJ, c.noise_scale_kind, c.noise_bias, c.noise_exponent, c.noise_max_value,
+                                          c.noise_threshold, c.noise_gain, zs);
+        if (rc == DDSPP_OK) rc = ddspp_time_varying_fir(z, ir, zrows, R, N, T, g->Lw, c.delay_compensation, zs);
+    }
+    if (rc != DDSPP_OK) return rc;
+    if (g->side) DDSPP_HIP_CHECK(hipEventRecord(g->ev_join, g->side));
+
+    // ---- get_controls of the additive processor over all rows (inharm_synth.py:167-219, :254-270) -------------------
+    float* shifts_last = want ? (outputs->harmonic_shifts_last ? outputs->harmonic_shifts_last : (float*)(ws + g->o_shl)) : nullptr;
+    rc = ddspp_inharmonic_controls_group(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amp_c, hd_c,
+                                         (want && T >= 4) ? shifts_last : nullptr, aud, R, T, H, S, P, vm, c.sample_rate,
+                                         c.min_frequency, c.scale_kind, c.exponent, c.max_value, c.threshold, c.gain,
+                                         c.normalize_after_nyquist_cut, c.normalize_below_nyquist, stream);
+    if (rc != DDSPP_OK) return rc;
+    DDSPP_REQUIRE(!(want && outputs->harmonic_shifts_last && T < 4), "group_run: harmonic_shifts_last needs at least 4 frames");
+
+    // ---- additive branch: the compacted oscillator bank (inharm_synth.py:272-293 -> :87-127 -> :49-84) ---------------
+    float* add_last = want ? (outputs->additive_last ? outputs->additive_last : (float*)(ws + g->o_alast)) : nullptr;
+    rc = ddspp_polyphonic_additive(f0_hz, amp_c, hd_c, nullptr, inharm_coef, aud, g->wlin, g->whann, nullptr, mix, add_last, B,
+                                   P, T, S, H, U, c.sample_rate, 0, vm, ws + g->o_addws, g->addws_bytes, stream);
+    if (rc != DDSPP_OK) return rc;
+
+    // ---- add chain (polyphonic_dag.py:28-37) -------------------------------------------------------------------------
+    if (g->side) DDSPP_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_join, 0));
+    if (!want) {
+        // voice sums leave the noise kernel segment major ([B, P / vpr, N]); per-voice rows keep the controls' order
+        rc = ddspp_mix_voices(mix, 1, zrows, P / vpr, dry, B, N, N, vpr > 1 ? 0 : vm, stream);
+        if (rc != DDSPP_OK) return rc;
+    } else if (P == 1) {
+        // one voice: it is the last one.  dry = noise + additive (the first `add` node, two operands)
+        if (zlast != zrows) DDSPP_HIP_CHECK(hipMemcpyAsync(zlast, zrows, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
+        rc = ddspp_mix_voices(add_last, 1, zlast, 1, dry, B, N, N, 0, stream);
+        if (rc != DDSPP_OK) return rc;
+    } else {
+        const float* zr = zrows;
+        int pz = P / vpr, zvm = 0;
+        if (!split_in_kernel) {            // per-voice noise rows (P has no even divisor): take the last voice out by copies
+            if (vm) {                      // [P, B, N]: the first (P - 1) B rows are the other voices, the last B rows the last one
+                DDSPP_HIP_CHECK(hipMemcpyAsync(zlast, zrows + (size_t)(P - 1) * B * N, (size_t)B * N * 4, hipMemcpyDeviceToDevice,
+                                               stream));
+                pz = P - 1;
+                zvm = 1;
+            } else {                       // [B, P, N]
+                float* pack = (float*)(ws + g->o_zpack);
+                DDSPP_HIP_CHECK(hipMemcpy2DAsync(pack, (size_t)(P - 1) * N * 4, zrows, (size_t)P * N * 4, (size_t)(P - 1) * N * 4, B,
+                                                 hipMemcpyDeviceToDevice, stream));
+                DDSPP_HIP_CHECK(hipMemcpy2DAsync(zlast, (size_t)N * 4, zrows + (size_t)(P - 1) * N, (size_t)P * N * 4, (size_t)N * 4, B,
+                                                 hipMemcpyDeviceToDevice, stream));
+                zr = pack;
+                pz = P - 1;
+            }
+        }
+        float* prev = outputs->prev ? outputs->prev : (float*)(ws + g->o_prev);
+        rc = ddspp_mix_last_voice(mix, 1, zr, pz, zlast, add_last, prev, dry, B, N, zvm, stream);
+        if (rc != DDSPP_OK) return rc;
+    }
+
+    // ---- the last voice's conditioned controls, as the re-used processors hold them ----------------------------------
+    if (want) {
+        const size_t sp = row_step;
+        if (outputs->amplitudes_last)
+            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->amplitudes_last, (size_t)T * 4, amp_c + (size_t)last_row0 * T, sp * T * 4,
+                                             (size_t)T * 4, B, hipMemcpyDeviceToDevice, stream));
+        if (outputs->harmonic_distribution_last)
+            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->harmonic_distribution_last, (size_t)T * H * 4, hd_c + (size_t)last_row0 * T * H,
+                                             sp * T * H * 4, (size_t)T * H * 4, B, hipMemcpyDeviceToDevice, stream));
+        if (outputs->magnitudes_last) {    // FilteredNoise.get_controls of the last voice: scale_fn(magnitudes + initial_bias)
+            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->magnitudes_last, (size_t)T * K * 4, magnitudes + (size_t)last_row0 * T * K,
+                                             sp * T * K * 4, (size_t)T * K * 4, B, hipMemcpyDeviceToDevice, stream));
+            if (c.noise_scale_kind >= 0) {
+                rc = ddspp_scale_bias(outputs->magnitudes_last, outputs->magnitudes_last, (size_t)B * T * K, c.noise_bias,
+                                      c.noise_scale_kind, c.noise_exponent, c.noise_max_value, c.noise_threshold, c.noise_gain,
+                                      stream);
+                if (rc != DDSPP_OK) return rc;
+            }
+        }
+    }
+
+    // ---- reverb (ddsp.effects.Reverb.get_signal: mask the dry tap, FFT convolution, + dry) -------------------------------
+    if (g->plan) {
+        // _mask_dry_ir + fft_convolve(padding='same', delay_compensation=0) + dry
+        if (g->side)
+            rc = ddspp_fftconv_execute_prepared(g->plan, dry, N, audio, N, 0, c.reverb_add_dry ? 1 : 0, ws + g->o_fft, g->fft_bytes,
+                                                stream);
+        else
+            rc = ddspp_fftconv_execute(g->plan, dry, N, reverb_ir, audio, N, 0, 1, c.reverb_add_dry ? 1 : 0, ws + g->o_fft,
+                                       g->fft_bytes, stream);
+        if (rc != DDSPP_OK) return rc;
+    }
+    return DDSPP_OK;
+}
+
+}  // extern "C"

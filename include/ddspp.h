@@ -13,7 +13,7 @@
  *   - functions only enqueue work on `stream` and return 0, or a negative errno-style code after
  *     storing a message for ddspp_last_error(); nothing is thrown across the boundary;
  *   - the caller owns all buffers, including workspaces; the library owns only rocFFT plans
- *     behind ddspp_fftconv_plan.
+ *     behind ddspp_fftconv_plan and the table set behind ddspp_group.
  */
 #ifndef DDSPP_H_
 #define DDSPP_H_
@@ -354,6 +354,64 @@ int ddspp_midi_conditioning_run_f64(ddspp_midi_state* state, const double* roll,
                                     double* conditioning, double* polyphony);
 int ddspp_midi_conditioning_run_f32(ddspp_midi_state* state, const float* roll, int n_frames, int n_pitches,
                                     float* conditioning, float* polyphony);
+
+/* ---- the whole polyphonic group in one call ---------------------------------------------------------------------
+ * processor_group(features, return_outputs_dict=True) -- ddsp_piano/modules/piano_model.py:160 over the DAG of
+ * ddsp_piano/modules/polyphonic_dag.py:24-40: P voices x B segments of MultiInharmonic (get_controls + get_signal),
+ * FilteredNoise, the MultiAdd chain and Reverb, enqueued as one sequence of kernels (csrc/group.cpp): get_controls
+ * over all rows -> compacted oscillator bank -> fused FilteredNoise with voice sums -> add chain -> reverb.
+ *
+ * ddspp_group_create builds, once per configuration, the small tables the kernels take (uploaded here: the only device
+ * memory the library allocates itself) and the reverb's rocFFT plan; ddspp_group_run only launches kernels on `stream`
+ * inside the caller's workspace -- no host synchronisation, no allocation: it can be captured in a HIP graph.
+ * Rows: every control tensor is [R, T, .] with R = n_segments * n_voices rows, segment major ([B, P]) or voice major
+ * ([P, B], what the reference's Parallelizer.unparallelize hands over, sub_modules.py:586-592).
+ * Takes the shapes the compacted bank and the even/odd FIR design take (U % 8 == 0, P * S <= 64, K in {32, 64, 96, 128}
+ * with the full-length window); FilteredNoise runs fused when its kernel fits the shape, in the two-call form otherwise. */
+typedef struct ddspp_group ddspp_group;
+typedef struct {
+    int n_segments, n_voices, n_frames, n_harmonics, n_substrings, n_bands, upsampling;
+    int ir_length;                 /* L of the reverb's impulse response; 0: the DAG has no reverb node */
+    int ir_batch;                  /* rows of reverb_ir: 1 (shared by all segments) or n_segments (0 = n_segments) */
+    int reverb_add_dry;            /* ddsp.effects.Reverb(add_dry=True) */
+    int voice_major;               /* 0: rows are [B, P]; 1: [P, B] */
+    float sample_rate, min_frequency;                      /* InHarmonic(sample_rate, min_frequency=20) */
+    int scale_kind;                                        /* additive scale_fn: DDSPP_SCALE_* */
+    float exponent, max_value, threshold, gain;            /* its parameters (10, 2, 1e-7, 1) */
+    int normalize_after_nyquist_cut, normalize_below_nyquist;   /* inharm_synth.py:141-142 */
+    int window_size;                                       /* FilteredNoise(window_size=257) */
+    int noise_scale_kind;                                  /* FilteredNoise scale_fn (DDSPP_SCALE_*; -1: magnitudes as given) */
+    float noise_bias, noise_exponent, noise_max_value, noise_threshold, noise_gain;   /* initial_bias=-5, 10, 2, 1e-7, 1 */
+    int delay_compensation;        /* frequency_filter: DDSPP_DELAY_AUTO / DDSPP_DELAY_AUTO_HALF / >= 0 */
+    int resize_rule;               /* bilinear rule of ddspp_resample_tables_host (0) */
+    uint64_t noise_seed;           /* the library's Philox stream when ddspp_group_run gets noise = NULL */
+} ddspp_group_config;
+/* What the reference's outputs dictionary holds besides the audio; every pointer may be NULL (not wanted).  The DAG
+ * re-uses one additive and one noise processor for all voices, so the dictionary keeps the LAST voice's stems and
+ * conditioned controls (polyphonic_dag.py:28-37). */
+typedef struct {
+    float* dry;                          /* [B, N]  add/signal: the dry mix the reverb gets */
+    float* prev;                         /* [B, N]  add/controls/signal_0: the mix of voices 0 .. P-2 (P > 1) */
+    float* additive_last;                /* [B, N]  additive/signal */
+    float* noise_last;                   /* [B, N]  noise/signal */
+    float* amplitudes_last;              /* [B, T]    additive/controls/amplitudes */
+    float* harmonic_distribution_last;   /* [B, T, H] additive/controls/harmonic_distribution */
+    float* harmonic_shifts_last;         /* [B, T, H] additive/controls/harmonic_shifts (T >= 4) */
+    float* magnitudes_last;              /* [B, T, K] noise/controls/magnitudes */
+} ddspp_group_outputs;
+int ddspp_group_create(const ddspp_group_config* config, ddspp_group** out_group);
+void ddspp_group_destroy(ddspp_group* group);
+size_t ddspp_group_workspace_bytes(const ddspp_group* group);
+int ddspp_group_n_samples(const ddspp_group* group);      /* N = n_frames * upsampling */
+/* amplitudes[R,T], harmonic_distribution[R,T,H], inharm_coef[R,T], f0_hz[R,T,S], magnitudes[R,T,K] (all raw network
+ * outputs), reverb_ir[ir_batch, L] (NULL without reverb), noise[R,N] uniform(-1, 1) draws in the rows' order or NULL
+ * (the library's Philox stream, one counter step per call) -> audio[B, N].  outputs: NULL = audio only (the voices'
+ * noise is summed in registers, no stem is formed); else the dictionary's entries, each optional.  workspace: 256-byte
+ * aligned device memory of ddspp_group_workspace_bytes.  One run at a time per group object. */
+int ddspp_group_run(ddspp_group* group, const float* amplitudes, const float* harmonic_distribution,
+                    const float* inharm_coef, const float* f0_hz, const float* magnitudes, const float* reverb_ir,
+                    const float* noise, float* audio, const ddspp_group_outputs* outputs, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 //   both write <dir>/audio.f32 (c2 also dry.f32).  Dimensions come from <dir>/dims.txt (one integer per line).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <string>
@@ -193,6 +194,47 @@ int main(int argc, char** argv) {
         write_f32(dir + "dry.f32", download(dry, (size_t)B * N));
         write_f32(dir + "audio.f32", download(wet, (size_t)B * N));
         CK(ddspp_fftconv_plan_destroy(plan));
+
+        // ---- the same segment through the one-call driver: processor_group(features, return_outputs_dict=True) ---------
+        auto stacked = [&](const char* key, size_t per_voice) {             // rows [B = 1, P] segment major
+            std::vector<float> all;
+            for (int v = 0; v < P; ++v) {
+                const std::vector<float> x = read_f32(dir + key + "_" + std::to_string(v) + ".f32", per_voice);
+                all.insert(all.end(), x.begin(), x.end());
+            }
+            return upload(all);
+        };
+        ddspp_group_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.n_segments = B; cfg.n_voices = P; cfg.n_frames = T; cfg.n_harmonics = H; cfg.n_substrings = S; cfg.n_bands = K;
+        cfg.upsampling = U; cfg.ir_length = L; cfg.ir_batch = 1; cfg.reverb_add_dry = 1; cfg.voice_major = 0;
+        cfg.sample_rate = (float)sr; cfg.min_frequency = 20.0f;
+        cfg.scale_kind = DDSPP_SCALE_EXP_SIGMOID; cfg.exponent = 10.0f; cfg.max_value = 2.0f; cfg.threshold = 1e-7f; cfg.gain = 1.0f;
+        cfg.normalize_after_nyquist_cut = 1; cfg.normalize_below_nyquist = 1;
+        cfg.window_size = 257;
+        cfg.noise_scale_kind = DDSPP_SCALE_EXP_SIGMOID; cfg.noise_bias = -5.0f; cfg.noise_exponent = 10.0f;
+        cfg.noise_max_value = 2.0f; cfg.noise_threshold = 1e-7f; cfg.noise_gain = 1.0f;
+        cfg.delay_compensation = DDSPP_DELAY_AUTO; cfg.resize_rule = 0; cfg.noise_seed = 0;
+        ddspp_group* grp = nullptr;
+        CK(ddspp_group_create(&cfg, &grp));
+        const size_t gws_bytes = ddspp_group_workspace_bytes(grp);
+        void* gws = nullptr;
+        HK(hipMalloc(&gws, gws_bytes));
+        float* g_audio = dalloc((size_t)B * N);
+        ddspp_group_outputs go;
+        memset(&go, 0, sizeof(go));
+        go.dry = dalloc((size_t)B * N);
+        go.additive_last = dalloc((size_t)B * N);
+        go.noise_last = dalloc((size_t)B * N);
+        CK(ddspp_group_run(grp, stacked("amplitudes", T), stacked("harmonic_distribution", (size_t)T * H), stacked("inharm_coef", T),
+                           stacked("f0_hz", (size_t)T * S), stacked("magnitudes", (size_t)T * K), rir, stacked("noise", N), g_audio,
+                           &go, gws, gws_bytes, nullptr));
+        HK(hipDeviceSynchronize());
+        write_f32(dir + "audio_group.f32", download(g_audio, (size_t)B * N));
+        write_f32(dir + "dry_group.f32", download(go.dry, (size_t)B * N));
+        write_f32(dir + "additive_last_group.f32", download(go.additive_last, (size_t)B * N));
+        write_f32(dir + "noise_last_group.f32", download(go.noise_last, (size_t)B * N));
+        ddspp_group_destroy(grp);
         return 0;
     }
     return 1;

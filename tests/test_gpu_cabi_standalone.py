@@ -58,3 +58,11 @@ def test_small_config2_full_chain_through_the_header_alone(tmp_path):
     dry = np.fromfile(tmp_path / 'dry.f32', '<f4')[None, :]
     assert rms_err(dry, g['dry']) < TOL
     assert rms_err(audio, g['audio']) < TOL * max(1.0, rms(g['audio']))
+    # the same segment through the one-call driver (ddspp_group_create / ddspp_group_run), outputs dictionary included
+    audio_g = np.fromfile(tmp_path / 'audio_group.f32', '<f4')[None, :]
+    dry_g = np.fromfile(tmp_path / 'dry_group.f32', '<f4')[None, :]
+    assert rms_err(dry_g, g['dry']) < TOL
+    assert rms_err(audio_g, g['audio']) < TOL * max(1.0, rms(g['audio']))
+    assert rms_err(audio_g, audio) < 1e-6 * max(1.0, rms(audio))
+    last = np.fromfile(tmp_path / 'additive_last_group.f32', '<f4') + np.fromfile(tmp_path / 'noise_last_group.f32', '<f4')
+    assert np.isfinite(last).all() and rms(last) > 0

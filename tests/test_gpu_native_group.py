@@ -1,0 +1,112 @@
+"""GPU: the one-call group driver of the library (ddspp_group_*, csrc/group.cpp) through ddsp_piano_amd.NativeGroup
+against ProcessorGroup's batched Python route -- the same kernels with the same arguments -- and a small case against
+the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_fuzz import musical_controls
+from util import oracle_segments
+
+pytestmark = pytest.mark.gpu
+KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'], noise_controls=['magnitudes'])
+
+
+def _setup(seed, B, P, T, H, K, S, U, vm, L, flags=None):
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(seed)
+    sr = 250 * U
+    raw = musical_controls(rng, B * P, T, H, S, sr)
+    raw['magnitudes'] = rng.normal(0.0, 1.5, [B * P, T, K]).astype(np.float32)
+    feats, host = {}, {}
+    for k, v in raw.items():
+        whole = v.reshape(*((P, B) if vm else (B, P)), T, v.shape[-1])
+        dev = torch.as_tensor(whole, device='cuda')
+        for i in range(P):
+            feats[f'{k}_{i}'] = dev[i] if vm else dev[:, i]
+            host[f'{k}_{i}'] = whole[i] if vm else whole[:, i]
+    rk = []
+    if L:
+        ir = (rng.normal(0.0, 1.0, [B, L]) * np.exp(-6.9 * np.arange(L) / L)[None, :] * 0.05).astype(np.float32)
+        feats['reverb_ir'], host['reverb_ir'] = torch.as_tensor(ir, device='cuda'), ir
+        rk = ['reverb_ir']
+    flags = dict(flags or {})
+    scale = getattr(dp, flags.pop('scale', 'exp_sigmoid'))
+
+    def group():
+        return dp.ProcessorGroup(dp.polyphonic_dag(
+            dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True, scale_fn=scale, **flags),
+            dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr, scale_fn=scale),
+            dp.Reverb(name='reverb') if L else None, n_synths=P, reverb_controls=rk, **KEYS))
+    noise = rng.uniform(-1, 1, [B, P, T * U]).astype(np.float32)
+    return dp, group, feats, host, noise, sr
+
+
+def _close(a, b, path=''):
+    """Same kernels, same arguments -- except the Hann tables: the library's host builder evaluates the float32 cosine
+    with libm, the Python layer with numpy, and the two differ by an ulp in a few entries (tests/test_cabi.py)."""
+    assert a.shape == b.shape, path
+    err = (a - b).abs().max().item()
+    assert err <= 2e-6 * max(1.0, float(b.abs().max())), (path, err)
+
+
+def _same(a, b, path=''):
+    if isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            if k != 'inputs':
+                _same(a[k], b[k], f'{path}/{k}')
+    elif torch.is_tensor(a):
+        _close(a, b, path)
+
+
+@pytest.mark.parametrize('seed,B,P,T,H,K,S,U,vm,L,flags', [
+    (1, 3, 16, 125, 128, 96, 1, 96, False, 4000, None), (2, 2, 16, 60, 128, 96, 1, 96, True, 2500, None),
+    (3, 2, 3, 90, 96, 64, 2, 64, False, 3000, None), (4, 5, 3, 50, 96, 64, 1, 64, True, 0, None),
+    (5, 4, 1, 40, 64, 32, 1, 128, False, 1000, None), (6, 2, 6, 75, 48, 32, 1, 32, False, 2000,
+                                                       dict(scale='exp_tanh', normalize_after_nyquist_cut=False)),
+    (7, 17, 16, 33, 128, 96, 1, 96, True, 1500, None)])
+def test_native_group_equals_the_python_route(seed, B, P, T, H, K, S, U, vm, L, flags):
+    dp, group, feats, _, noise, sr = _setup(seed, B, P, T, H, K, S, U, vm, L, flags)
+    z = torch.as_tensor(noise, device='cuda')
+    py, nat = group(), dp.NativeGroup(group(), feats)
+    _close(nat(feats, noise=z), py(feats, noise=z), 'audio only')
+    _same(nat(feats, return_outputs_dict=True, noise=z), py(feats, return_outputs_dict=True, noise=z))
+    # the library's own noise stream: the first call of a fresh pair draws the same numbers (same seed, same counter)
+    py2, nat2 = group(), dp.NativeGroup(group(), feats)
+    _close(nat2(feats), py2(feats), 'own noise')
+    a, b = nat2(feats), nat2(feats)
+    assert (a - b).abs().max().item() > 1e-5            # a new draw per call
+    with pytest.raises(ValueError):
+        nat(({k: (v[:, :T - 1] if k != 'reverb_ir' else v) for k, v in feats.items()}))
+
+
+def test_native_group_against_the_oracle():
+    dp, group, feats, host, noise, sr = _setup(11, 2, 4, 100, 128, 96, 1, 96, False, 3000)
+    nat = dp.NativeGroup(group(), feats)
+    got = nat(feats, return_outputs_dict=True, noise=torch.as_tensor(noise, device='cuda'))
+    ref = oracle_segments(host, noise, 4, sr, [0, 1])
+    for b in (0, 1):
+        r = ref[b]
+        for name, x in (('signal', got['signal'][b]), ('dry', got['controls']['add']['signal'][b]),
+                        ('additive_last', got['controls']['additive']['signal'][b]),
+                        ('noise_last', got['controls']['noise']['signal'][b])):
+            want = np.asarray(r[name]).reshape(-1)
+            err = np.sqrt(np.mean((x.cpu().numpy().astype(np.float64) - want) ** 2))
+            assert err < 1e-4 * max(1e-3, np.sqrt(np.mean(want.astype(np.float64) ** 2))), (name, err)
+
+
+def test_native_group_side_stream(monkeypatch):
+    """The noise branch and the impulse-response transform on the group's own stream (what large batches get), forced on
+    at a small size; several calls back to back re-use the workspace across the fork / join."""
+    from util import set_option
+    set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', 1)
+    dp, group, feats, _, noise, sr = _setup(21, 4, 16, 125, 128, 96, 1, 96, False, 5000)
+    z = torch.as_tensor(noise, device='cuda')
+    nat = dp.NativeGroup(group(), feats)
+    set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', None)
+    want = group()(feats, return_outputs_dict=True, noise=z)
+    for _ in range(3):
+        got = nat(feats, return_outputs_dict=True, noise=z)
+    _same(got, want)
+    _close(nat(feats, noise=z), want['signal'], 'audio only')
