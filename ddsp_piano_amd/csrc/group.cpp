@@ -192,7 +192,8 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     float* hd_c = (float*)(ws + g->o_hd);
     int* aud = (int*)(ws + g->o_aud);
     float* mix = (float*)(ws + g->o_mix);
-    float* dry = g->plan ? (outputs && outputs->dry ? outputs->dry : (float*)(ws + g->o_dry)) : audio;
+    // the dry mix: the caller's buffer when the dictionary wants it, else scratch (or, without a reverb, the audio itself)
+    float* dry = (outputs && outputs->dry) ? outputs->dry : (g->plan ? (float*)(ws + g->o_dry) : audio);
     const bool want = outputs != nullptr;
     const int last_row0 = vm ? (P - 1) * B : P - 1;            // first row of the last voice; its rows are B apart x 1 (vm) or x P
     const size_t row_step = vm ? 1 : (size_t)P;                // in rows
@@ -317,6 +318,8 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
             rc = ddspp_fftconv_execute(g->plan, dry, N, reverb_ir, audio, N, 0, 1, c.reverb_add_dry ? 1 : 0, ws + g->o_fft,
                                        g->fft_bytes, stream);
         if (rc != DDSPP_OK) return rc;
+    } else if (dry != audio) {             // no reverb node: the group's signal is the dry mix
+        DDSPP_HIP_CHECK(hipMemcpyAsync(audio, dry, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
     }
     return DDSPP_OK;
 }
