@@ -112,3 +112,17 @@ def test_native_group_side_stream(monkeypatch):
         got = nat(feats, return_outputs_dict=True, noise=z)
     _same(got, want)
     _close(nat(feats, noise=z), want['signal'], 'audio only')
+
+
+def test_native_group_32khz_and_captured():
+    """K = 128 / U = 128 (the ENSTDkCl 32 kHz dimensions: FilteredNoise in the two-call form), and the driver inside a
+    replayed HIP graph (ddspp_group_run only launches kernels)."""
+    dp, group, feats, _, noise, sr = _setup(31, 2, 4, 64, 192, 128, 1, 128, False, 2000,
+                                            dict(scale='exp_tanh', normalize_after_nyquist_cut=False))
+    z = torch.as_tensor(noise, device='cuda')
+    py, nat = group(), dp.NativeGroup(group(), feats)
+    _same(nat(feats, return_outputs_dict=True, noise=z), py(feats, return_outputs_dict=True, noise=z))
+    fast = dp.CapturedGroup(nat, feats, return_outputs_dict=True)
+    got = fast(feats, noise=z)
+    _close(got['signal'], py(feats, noise=z), 'graph replay')
+    _close(fast(feats, noise=z)['controls']['add']['signal'], py(feats, return_outputs_dict=True, noise=z)['controls']['add']['signal'])
