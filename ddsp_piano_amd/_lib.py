@@ -91,6 +91,8 @@ SIGNATURES = {
     'ddspp_reload_options': (None, []),
     'ddspp_hann_window_host': (c_int, [c_int, c_void_p]),
     'ddspp_resample_tables_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ddspp_group_config_bytes': (ctypes.c_size_t, []),
+    'ddspp_group_outputs_bytes': (ctypes.c_size_t, []),
     'ddspp_group_create': (c_int, [c_void_p, c_void_p]),
     'ddspp_group_destroy': (None, [c_void_p]),
     'ddspp_group_workspace_bytes': (ctypes.c_size_t, [c_void_p]),

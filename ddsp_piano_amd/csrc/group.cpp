@@ -173,6 +173,10 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
 
 void ddspp_group_destroy(ddspp_group* g) { release(g); }
 
+// sizes of the two structs as this build of the library sees them: a binding checks its own declaration against them
+size_t ddspp_group_config_bytes(void) { return sizeof(ddspp_group_config); }
+size_t ddspp_group_outputs_bytes(void) { return sizeof(ddspp_group_outputs); }
+
 size_t ddspp_group_workspace_bytes(const ddspp_group* g) { return g ? g->total : 0; }
 int ddspp_group_n_samples(const ddspp_group* g) { return g ? g->N : -1; }
 

@@ -84,6 +84,8 @@ class NativeGroup:
         c.noise_seed = int(getattr(nz, 'seed', 0)) & (2 ** 64 - 1)
         self.config = c
         lib = _lib_()
+        if ctypes.sizeof(_Config) != lib.ddspp_group_config_bytes() or ctypes.sizeof(_Outputs) != lib.ddspp_group_outputs_bytes():
+            raise RuntimeError('ddspp_group_config / ddspp_group_outputs: this binding and libddspp.so disagree on the layout')
         h = ctypes.c_void_p()
         _lib.check(lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)))
         self._h = h

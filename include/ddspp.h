@@ -399,6 +399,9 @@ typedef struct {
     float* harmonic_shifts_last;         /* [B, T, H] additive/controls/harmonic_shifts (T >= 4) */
     float* magnitudes_last;              /* [B, T, K] noise/controls/magnitudes */
 } ddspp_group_outputs;
+/* sizeof the two structs above in this build of the library (a binding in another language checks its declaration) */
+size_t ddspp_group_config_bytes(void);
+size_t ddspp_group_outputs_bytes(void);
 int ddspp_group_create(const ddspp_group_config* config, ddspp_group** out_group);
 void ddspp_group_destroy(ddspp_group* group);
 size_t ddspp_group_workspace_bytes(const ddspp_group* group);

@@ -174,3 +174,35 @@ def test_options_are_read_once_and_reloadable(monkeypatch):
     assert _lib.options.no_side_stream is False                      # not re-read per call
     _lib.options.reload()
     assert _lib.options.no_side_stream is True
+
+
+def test_group_driver_argument_errors(lib):
+    """ddspp_group_create validates the configuration before it touches the device; ddspp_group_run refuses null
+    arguments; the struct the Python layer passes has the layout of the header's (size check through a known field)."""
+    import ctypes
+    from ddsp_piano_amd import _lib
+    from ddsp_piano_amd.native_group import _Config, _Outputs
+    h = ctypes.c_void_p()
+    assert lib.ddspp_group_create(None, ctypes.byref(h)) == _lib.DDSPP_EINVAL
+    c = _Config()
+    assert lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)) == _lib.DDSPP_EINVAL          # all-zero dimensions
+    assert b'bad dimensions' in lib.ddspp_last_error()
+    c.n_segments, c.n_voices, c.n_frames, c.n_harmonics, c.n_substrings, c.n_bands, c.upsampling = 2, 16, 50, 128, 1, 96, 100
+    assert lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)) == _lib.DDSPP_EINVAL
+    assert b'multiple of 8' in lib.ddspp_last_error()
+    c.upsampling, c.n_voices, c.n_substrings = 96, 40, 2
+    assert lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)) == _lib.DDSPP_EINVAL
+    assert b'exceeds 64' in lib.ddspp_last_error()
+    c.n_voices, c.n_substrings, c.ir_batch = 16, 1, 3
+    assert lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)) == _lib.DDSPP_EINVAL
+    assert b'ir_batch' in lib.ddspp_last_error()
+    c.ir_batch, c.n_bands, c.window_size = 0, 65, 257
+    assert lib.ddspp_group_create(ctypes.byref(c), ctypes.byref(h)) == _lib.DDSPP_EINVAL            # no even/odd tables
+    assert b'even/odd' in lib.ddspp_last_error()
+    assert lib.ddspp_group_run(None, None, None, None, None, None, None, None, None, None, None, 0, None) == _lib.DDSPP_EINVAL
+    assert lib.ddspp_group_workspace_bytes(None) == 0 and lib.ddspp_group_n_samples(None) == -1
+    lib.ddspp_group_destroy(None)                                                                   # a no-op
+    # 11 ints, 2 floats, 1 int, 4 floats, 4 ints, 5 floats, 2 ints, (pad), uint64 -- as include/ddspp.h declares them
+    assert ctypes.sizeof(_Config) == 29 * 4 + 4 + 8 and _Config.noise_seed.offset == 120
+    assert ctypes.sizeof(_Config) == lib.ddspp_group_config_bytes()
+    assert ctypes.sizeof(_Outputs) == lib.ddspp_group_outputs_bytes() == 8 * ctypes.sizeof(ctypes.c_void_p)
