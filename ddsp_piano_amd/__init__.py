@@ -10,8 +10,8 @@ from . import core  # noqa: F401
 from .core import exp_sigmoid, exp_tanh  # noqa: F401
 from .graph import CapturedGroup  # noqa: F401
 from .native_group import NativeGroup  # noqa: F401
-from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb,  # noqa: F401
-                      fdn_impulse_response)
+from .effects import (FeedbackDelayNetwork, FeedbackDelayNetworkApply, MultiInstrumentFeedbackDelayReverb,  # noqa: F401
+                      MultiInstrumentReverb, Reverb, fdn_impulse_response)
 from .noise_band_net import FilterBank, NoiseBandNetSynth  # noqa: F401
 from .midi_encoders import MIDIRoll2Conditioning, ensure_sequence_length, roll_to_conditioning  # noqa: F401
 from .parallelizer import Parallelizer  # noqa: F401
@@ -23,5 +23,6 @@ from .synths import (DynamicSizeFilteredNoise, FilteredNoise, InHarmonic, MultiA
 __all__ = ['core', 'exp_sigmoid', 'exp_tanh', 'Processor', 'ProcessorGroup', 'Add', 'InHarmonic',
            'MultiInharmonic', 'SurrogateAdditive', 'MultiAdd', 'FilteredNoise', 'DynamicSizeFilteredNoise', 'NoiseBandNetSynth',
            'FilterBank', 'Reverb',
-           'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'polyphonic_dag',
+           'FeedbackDelayNetwork', 'FeedbackDelayNetworkApply', 'fdn_impulse_response', 'MultiInstrumentReverb',
+           'MultiInstrumentFeedbackDelayReverb', 'polyphonic_dag',
            'Parallelizer', 'CapturedGroup', 'NativeGroup', 'MIDIRoll2Conditioning', 'ensure_sequence_length', 'roll_to_conditioning']

@@ -37,12 +37,16 @@ _TWO_PI_F32 = F32(2.0 * np.pi)
 #   resize       core.resample(method='linear'): 'legacy' (TF1 bilinear, pos = n * T/N) | 'half_pixel'.
 #                Host tables; the fused oscillator path needs 'legacy' (else the three-operator route runs).
 #   window_crop  apply_window_to_impulse_response, window_size < ir_size: 'ddsp370' | 'centred'.  Host matrix.
+# One more switch of the same kind is not about ddsp but about TensorFlow's arithmetic:
+#   fdn_solve    FeedbackDelayNetwork.get_late_ir's per-bin 8 x 8 system: 'float64' (solved in double: the value the
+#                reference's recipe approximates) | 'complex64' (tf.linalg.inv + matmuls in complex64 as
+#                fdn_reverb.py:314-333 writes them).  C-ABI: ddspp_fdn_transfer(solve).
 # The other three recalled items are ordinary arguments here (exp_sigmoid's exponent / max_value / threshold,
 # FilteredNoise(initial_bias=)) or oracle-only (the inclusive scan of angular_cumsum is what the kernels implement).
 # ----------------------------------------------------------------------------------------------------
-RECALLED = {'auto_delay': 'ddsp370', 'resize': 'legacy', 'window_crop': 'ddsp370'}
+RECALLED = {'auto_delay': 'ddsp370', 'resize': 'legacy', 'window_crop': 'ddsp370', 'fdn_solve': 'float64'}
 _RECALLED_CHOICES = {'auto_delay': ('ddsp370', 'half'), 'resize': ('legacy', 'half_pixel'),
-                     'window_crop': ('ddsp370', 'centred')}
+                     'window_crop': ('ddsp370', 'centred'), 'fdn_solve': ('float64', 'complex64')}
 
 
 def set_recalled(**rules):

@@ -28,6 +28,10 @@ static inline int ddspp_auto_delay(int delay_compensation, int ir_size) {
 }
 #define DDSPP_WAVE 64
 
+// ddspp_fdn_transfer(solve): how the D x D system of a frequency bin is solved (fdn.hip)
+#define DDSPP_FDN_SOLVE_F64 0
+#define DDSPP_FDN_SOLVE_C64_INVERSE 1
+
 extern "C" void ddspp_set_error(const char* fmt, ...);
 // tuning option `name` (a DDSPP_* environment variable, read once and cached; ddspp_set_option / ddspp_reload_options)
 extern "C" int ddspp_option(const char* name, int dflt);

@@ -67,6 +67,11 @@ struct FdnParams {
     float sr;
 };
 
+// SOLVE = 0: the D x D system of a bin is solved in float64 (default).  SOLVE = 1: the reference's own arithmetic,
+// tf.linalg.inv in complex64 followed by the complex64 products (fdn_reverb.py:314-333) -- an LU inverse with partial
+// pivoting, only good to cond(I - F D) x 6e-8 near the network's resonances; kept as a switch so that a TF-made golden
+// can be matched either way.
+template <int SOLVE>
 __global__ void __launch_bounds__(256) fdn_transfer_kernel(const FdnParams p) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)p.B * p.nb) return;
@@ -103,6 +108,70 @@ __global__ void __launch_bounds__(256) fdn_transfer_kernel(const FdnParams p) {
             prod = cmul(prod, cdiv(cf{1.0f + ga * z.re, ga * z.im}, cf{ga + z.re, z.im}));   // :305-308
         }
         ap[d] = prod;
+    }
+    if (SOLVE == 1) {
+        // feedback = diag(filt) M diag(ap); a = I - feedback diag(dd); inv = a^-1 (Gauss-Jordan on [a | I], partial
+        // pivoting); H = output_gain^T (diag(dd) inv) input_gain -- every product and sum in complex64
+        cf a[FDN_DMAX][2 * FDN_DMAX];
+#pragma unroll
+        for (int i = 0; i < FDN_DMAX; ++i)
+#pragma unroll
+            for (int j = 0; j < FDN_DMAX; ++j) {
+                cf v = {i == j ? 1.0f : 0.0f, 0.0f};
+                if (i < D && j < D) {
+                    const float m = p.mixing[i * D + j];
+                    const cf f = cmul(cmul(cmul(filt[i], cf{m, 0.0f}), ap[j]), dd[j]);
+                    v = csub(v, f);
+                }
+                a[i][j] = v;
+                a[i][FDN_DMAX + j] = cf{i == j ? 1.0f : 0.0f, 0.0f};
+            }
+#pragma unroll
+        for (int c = 0; c < FDN_DMAX; ++c) {
+            float best = a[c][c].re * a[c][c].re + a[c][c].im * a[c][c].im;
+            int piv = c;
+#pragma unroll
+            for (int r = c + 1; r < FDN_DMAX; ++r) {
+                const float m = a[r][c].re * a[r][c].re + a[r][c].im * a[r][c].im;
+                if (m > best) {
+                    best = m;
+                    piv = r;
+                }
+            }
+#pragma unroll
+            for (int r = c + 1; r < FDN_DMAX; ++r) {
+                if (r == piv) {
+#pragma unroll
+                    for (int j = 0; j < 2 * FDN_DMAX; ++j) {
+                        const cf t = a[c][j];
+                        a[c][j] = a[r][j];
+                        a[r][j] = t;
+                    }
+                }
+            }
+            const cf inv = cdiv(cf{1.0f, 0.0f}, a[c][c]);
+#pragma unroll
+            for (int j = 0; j < 2 * FDN_DMAX; ++j) a[c][j] = cmul(a[c][j], inv);
+#pragma unroll
+            for (int r = 0; r < FDN_DMAX; ++r) {
+                if (r == c) continue;
+                const cf f = a[r][c];
+#pragma unroll
+                for (int j = 0; j < 2 * FDN_DMAX; ++j) a[r][j] = csub(a[r][j], cmul(f, a[c][j]));
+            }
+        }
+        cf h = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < FDN_DMAX; ++i) {
+            if (i >= D) continue;
+            cf row = {0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < FDN_DMAX; ++j)
+                if (j < D) row = cadd(row, cmul(cmul(dd[i], a[i][FDN_DMAX + j]), cf{p.input_gain[(size_t)b * D + j], 0.0f}));
+            h = cadd(h, cmul(cf{p.output_gain[(size_t)b * D + i], 0.0f}, row));
+        }
+        p.H[gid] = make_float2(h.re, h.im);
+        return;
     }
     // a = I - F diag(dd),  F[i][j] = filt_i M_ij ap_j ; augmented with rhs = input_gain.
     // The solve runs in float64: I - F D is close to singular near the FDN's resonances (the reference's
@@ -260,21 +329,26 @@ int ddspp_irfft_execute(ddspp_irfft_plan* pl, void* spectrum, float* signal, voi
 
 // FeedbackDelayNetwork.get_late_ir up to (not including) the irfft -- fdn_reverb.py:178-334, for B
 // instruments at once (the tf.vectorized_map of sub_modules.py:444).  H: [B, freq_points/2 + 1] complex64.
+// solve: DDSPP_FDN_SOLVE_F64 (0) or DDSPP_FDN_SOLVE_C64_INVERSE (1, the reference's tf.linalg.inv arithmetic).
 int ddspp_fdn_transfer(const float* input_gain, const float* output_gain, const float* mixing_matrix,
                        const float* gain_allpass, const float* delays_allpass, const float* time_rev_0_sec,
                        const float* alpha_tone, const float* delay_values, void* H, int B, int D, int A,
-                       int freq_points, float sampling_rate, hipStream_t stream) {
+                       int freq_points, float sampling_rate, int solve, hipStream_t stream) {
     DDSPP_REQUIRE(input_gain && output_gain && mixing_matrix && gain_allpass && delays_allpass && time_rev_0_sec &&
                       alpha_tone && delay_values && H, "fdn_transfer: null buffer");
     DDSPP_REQUIRE(B > 0 && D > 0 && D <= FDN_DMAX && A > 0 && A <= FDN_AMAX && freq_points >= 2 && freq_points % 2 == 0,
                   "fdn_transfer: bad dims (delay_lines <= 8, allpass stages <= 8)");
+    DDSPP_REQUIRE(solve == DDSPP_FDN_SOLVE_F64 || solve == DDSPP_FDN_SOLVE_C64_INVERSE, "fdn_transfer: unknown solve mode %d", solve);
     FdnParams p{};
     p.input_gain = input_gain; p.output_gain = output_gain; p.mixing = mixing_matrix;
     p.gain_allpass = gain_allpass; p.delays_allpass = delays_allpass; p.time_rev = time_rev_0_sec;
     p.alpha_tone = alpha_tone; p.delay_values = delay_values; p.H = (float2*)H;
     p.B = B; p.D = D; p.A = A; p.freq_points = freq_points; p.nb = freq_points / 2 + 1; p.sr = sampling_rate;
     const size_t total = (size_t)B * p.nb;
-    hipLaunchKernelGGL(fdn_transfer_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    if (solve == DDSPP_FDN_SOLVE_C64_INVERSE)
+        hipLaunchKernelGGL(fdn_transfer_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(fdn_transfer_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -24,6 +24,7 @@
 //   uniform_noise_kernel : Philox4x32-10 counter based U(-1, 1) noise (the reference draws an
 //       unseeded tf.random.uniform; parity is defined with the noise tensor supplied).
 #include "ddspp_common.h"
+#include "noise_win.h"
 
 namespace ddspp {
 
@@ -744,6 +745,8 @@ using namespace ddspp;
 
 extern "C" {
 
+static bool win_tvfir_shape(int N, int T, int Lw, int delay, WinGeom* g);
+
 // ddsp.core.frequency_impulse_response(magnitudes, window_size) as one product with the host-built
 // matrix M[K, Lw] (ddsp_piano_amd/core.py: irfft basis x window, shifted to causal form).
 // uniq[n_uniq] / mirror[n_uniq] (device int32, may be NULL): the taps to compute and where each
@@ -792,6 +795,12 @@ int ddspp_time_varying_fir(const float* audio, const float* impulse_response, fl
     const int U = N / T;
     const int delay = ddspp_auto_delay(delay_compensation, Lw);
     DDSPP_REQUIRE(delay >= 0, "time_varying_fir: negative delay");
+    {
+        WinGeom wg;
+        if ((uintptr_t)audio % 16 == 0 && (uintptr_t)out % 16 == 0 && !env_int("DDSPP_FIR_GENERIC", 0) &&
+            win_tvfir_shape(N, T, Lw, delay, &wg))
+            return launch_win_tvfir(audio, impulse_response, out, R, N, T, Lw, wg, stream);
+    }
     // Tiled kernel geometry (see tv_fir_kernel).  Tap t of a frame sits at float padl + t of its staged image;
     // padl makes (delay - 3 + padl) a multiple of 4 (aligned 16-byte tap blocks) and puts enough zero blocks in
     // front that segment 0 starts at block dc - 3 >= 0; nb leaves zero blocks behind for every block index the
@@ -882,7 +891,7 @@ int ddspp_fir_from_magnitudes_eo(const float* magnitudes, const float* CE, const
 struct FusedGeom {
     int U, delay, padl, dc, seglen, nb, wpr;
 };
-static bool fused_geometry(int N, int T, int K, int Lw, int delay_compensation, FusedGeom* g) {
+static bool fused_shape(int N, int T, int K, int Lw, int delay_compensation, FusedGeom* g) {
     if (N <= 0 || T <= 0 || N % T != 0 || (K != 32 && K != 64 && K != 96) || Lw != 2 * (K - 1)) return false;
     const int U = N / T;
     const int delay = ddspp_auto_delay(delay_compensation, Lw);
@@ -896,15 +905,35 @@ static bool fused_geometry(int N, int T, int K, int Lw, int delay_compensation, 
     const int frames_max = (FUS_BW + Lw + U - 2) / U + 2;
     const int nxb = FUS_BW / 4 + 4 * seglen - 4;
     if (frames_max > FUS_FRAMES || nb * 4 > 256 || nxb > 512 || 4 * (nxb + nxb / 4) + 4 > 1536 || dc < 3 ||
-        seglen > U / 4 || env_int("DDSPP_FIR_NO_FUSED", 0))
+        seglen > U / 4)
         return false;
     *g = FusedGeom{U, delay, padl, dc, seglen, nb, (N + FUS_BW - 1) / FUS_BW};
+    return true;
+}
+static bool fused_geometry(int N, int T, int K, int Lw, int delay_compensation, FusedGeom* g) {
+    return !env_int("DDSPP_FIR_NO_FUSED", 0) && fused_shape(N, T, K, Lw, delay_compensation, g);
+}
+// The windowed kernels (noise_win.hip) take a shape in both forms or in neither, so that the fused and the two-call
+// form of a shape always run the same walk (bit-identical results).  DDSPP_FIR_WIN=0: round 2's kernels.
+static bool win_fused_shape(int N, int T, int K, int Lw, int delay_compensation, WinGeom* g) {
+    if (N <= 0 || T <= 0 || N % T != 0 || !env_int("DDSPP_FIR_WIN", 1)) return false;
+    return win_fused_supported(N, T, K, Lw, ddspp_auto_delay(delay_compensation, Lw), g);
+}
+static bool win_tvfir_shape(int N, int T, int Lw, int delay, WinGeom* g) {
+    if (!env_int("DDSPP_FIR_WIN", 1) || !win_tvfir_supported(N, T, Lw, delay, g)) return false;
+    FusedGeom fg;
+    WinGeom wg;
+    const int K = Lw / 2 + 1;
+    if (Lw == 2 * (K - 1) && fused_shape(N, T, K, Lw, delay, &fg) && !win_fused_supported(N, T, K, Lw, delay, &wg))
+        return false;          // round 2's fused kernel takes this shape: its two-call form must match it
     return true;
 }
 
 int ddspp_frequency_filter_eo_supported(int N, int T, int K, int Lw, int delay_compensation) {
     FusedGeom g;
-    return fused_geometry(N, T, K, Lw, delay_compensation, &g) ? 1 : 0;
+    WinGeom wg;
+    if (env_int("DDSPP_FIR_NO_FUSED", 0)) return 0;
+    return (win_fused_shape(N, T, K, Lw, delay_compensation, &wg) || fused_shape(N, T, K, Lw, delay_compensation, &g)) ? 1 : 0;
 }
 
 static int launch_fused_noise(const float* audio, const float* magnitudes, const float* CE, const float* CO,
@@ -921,11 +950,17 @@ static int launch_fused_noise(const float* audio, const float* magnitudes, const
                   "frequency_filter_eo: %d voices per output row do not divide %d voices / %d rows", vq, n_voices, R);
     DDSPP_REQUIRE(!out_last || (vq > 1 && (uintptr_t)out_last % 16 == 0),
                   "frequency_filter_eo: out_last needs voices_per_row > 1 and a 16-byte aligned buffer");
+    DDSPP_REQUIRE((uintptr_t)audio % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)magnitudes % 16 == 0,
+                  "frequency_filter_eo: buffers must be 16-byte aligned");
+    WinGeom wg;
+    if (NJ == K / 2 && !env_int("DDSPP_FIR_NO_FUSED", 0) && win_fused_shape(N, T, K, Lw, delay_compensation, &wg)) {
+        const ScaleFn wsf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
+        return launch_win_fused(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, K, NJ, wg, bias,
+                                wsf, vq, n_voices, voice_major, stream);
+    }
     FusedGeom g;
     DDSPP_REQUIRE(fused_geometry(N, T, K, Lw, delay_compensation, &g) && NJ == K / 2,
                   "frequency_filter_eo: shape not supported (N=%d T=%d K=%d Lw=%d)", N, T, K, Lw);
-    DDSPP_REQUIRE((uintptr_t)audio % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)magnitudes % 16 == 0,
-                  "frequency_filter_eo: buffers must be 16-byte aligned");
     const long long tasks = (long long)(R / vq) * g.wpr;
     DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
     const int njp = 16 * ((NJ + 15) / 16);

@@ -1,0 +1,525 @@
+// Time-varying FilteredNoise FIR for gfx950, "one lane = one frame" form (round 3).
+//
+// Same operator as noise.hip (ddsp.core.frequency_filter as reached from DynamicSizeFilteredNoise.get_signal,
+// ddsp_piano/modules/filtered_noise_synth.py:27-42):
+//   out[n] = sum_j noise[j] * ir_{j / U}[n + delay - j]
+// What changed is who owns what.  noise.hip's kernel gives a lane 16 consecutive outputs and a quarter of the
+// input blocks that reach them: the 19 taps of a step are re-read from LDS at every step (six ds_read_b128 per
+// 64 FMAs) and the LDS pipe, not the VALU, is the busy unit.  Here the 64 lanes of a
+// wavefront are 32 consecutive FRAMES x 2 output phases: lane (fr, ph) owns the OPL outputs
+// U (F0 + fr) + OPL ph .. + OPL - 1 and walks ALL the input blocks that reach them, one block (4 samples) per step,
+// from the latest block to the earliest.  Every lane of a half-wave is at the same position relative to its own
+// frame grid, so
+//   * the tap indices of a step are the same for all lanes (each lane reads them from its OWN frame's impulse
+//     response): from one step to the next the window of OPL + 3 taps slides by four -- the window lives in a
+//     register ring and a step loads ONE new 16-byte tap block and ONE noise block: two ds_read_b128 per 4 OPL
+//     FMAs instead of six per 64;
+//   * a lane changes frame only where its block index crosses a multiple of U / 4 (twice per walk): the walk is
+//     cut into per-frame segments, each starting with a fresh ring (all control flow is wave-uniform);
+//   * there is nothing to add up across lanes: no shuffles, no segment bookkeeping, one accumulation chain per
+//     output in a fixed order (the two-call form runs the same core: bit-identical results).
+// LDS layout: images of D = 32 frames at stride gs floats (gs / 4 odd: the 16 lanes of a ds_read_b128 service group
+// are 16 consecutive frames and hit 16 different bank quads), zero gaps between the images wide enough for every
+// tap index a step can form (no bounds logic in the loop); the noise of the D frames with one pad block per frame
+// (stride U / 4 + 1 blocks, odd).  A window computes W = D - 2 frames (the first and the last designed frame only
+// feed their neighbours).
+#include "ddspp_common.h"
+#include "noise_win.h"
+
+namespace ddspp {
+
+constexpr int WIN_D = 32;            // designed frames per window = two MFMA row tiles
+
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// magnitude tile [D][K] without row padding: the 8-float groups of row s are XOR-swizzled by (s / 2) % 4, so that the
+// 16 rows a matrix-core A-operand read touches fall on 8 different bank groups (2-way instead of 8-way)
+__device__ __forceinline__ int win_mswz(int s) { return ((s >> 1) & 3) << 3; }
+
+// One lane's walk, frame by frame (g = frame offset relative to the lane's own frame, from the latest frame that
+// reaches the lane's outputs to the earliest).  The two half-waves are two adjacent output phases A and B = A + 1:
+// B's block range is OPL / 4 steps higher.  Both halves walk the UNION of the two ranges: the steps a half does not
+// need only meet taps outside [0, Lw) -- zeros of the gaps between the frame images -- so every loop bound and every
+// frame change is wave-uniform, nothing is masked, and a lane only adds its frame's offset to the two LDS pointers
+// (54 issued steps for 51 at the headline shape).
+//   gl: the lane's tap pointer for (g = 0, q = 0): image of its own frame + padl + OPL ph + delay - 3
+//   xl: the lane's noise pointer for (g = 0, r = 0)
+//   q_hi, q_lo: first (highest) block index of phase B, last (lowest) of phase A, relative to the lane's frame.
+template <int OPL, int AQ, int RS>
+__device__ __forceinline__ void fir_win_step(const float4 (&ring)[RS], const float4& xq, int u, float (&acc)[OPL]) {
+    float tp[4 * AQ];
+#pragma unroll
+    for (int k = 0; k < AQ; ++k) {
+        const float4 t = ring[(u + k) % RS];
+        tp[4 * k] = t.x; tp[4 * k + 1] = t.y; tp[4 * k + 2] = t.z; tp[4 * k + 3] = t.w;
+    }
+    const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < OPL; ++e) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+}
+
+template <int OPL, int BPF>
+__device__ __forceinline__ void fir_win_core(const float* __restrict__ gl, const float* __restrict__ xl, int q_hi,
+                                             int q_lo, int gs, float (&acc)[OPL]) {
+    constexpr int AQ = (OPL + 6) / 4;        // 16-byte blocks holding the OPL + 3 taps of a step
+    constexpr int RS = AQ + 2;               // register ring: the step's window + the blocks of the next two steps
+    const int g_hi = q_hi >= 0 ? q_hi / BPF : -((-q_hi + BPF - 1) / BPF);
+    const int g_lo = q_lo >= 0 ? q_lo / BPF : -((-q_lo + BPF - 1) / BPF);
+    for (int g = g_hi; g >= g_lo; --g) {
+        const int fq0 = g * BPF;
+        const int qs = min(q_hi, fq0 + BPF - 1), len = qs - max(q_lo, fq0) + 1;
+        const float* gp = gl + g * gs - 4 * qs;
+        const float* xb = xl + 4 * ((BPF + 1) * g + qs - fq0) - 4 * RS;    // noise blocks are walked downwards
+        float4 ring[RS], xr[RS];
+#pragma unroll
+        for (int k = 0; k <= AQ; ++k) ring[k] = lds4(gp + 4 * k);
+        xr[0] = lds4(xb + 4 * RS);
+        xr[1] = lds4(xb + 4 * (RS - 1));
+        int i0 = 0;
+        for (; i0 + RS <= len; i0 += RS) {                               // whole turns of the ring: no exits inside
+#pragma unroll
+            for (int u = 0; u < RS; ++u) {
+                // the tap block and the noise block of step u + 2 are issued BEFORE this step's FMAs
+                ring[(u + AQ + 1) % RS] = lds4(gp + 4 * (u + AQ + 1));
+                xr[(u + 2) % RS] = lds4(xb + 4 * (RS - u - 2));
+                __builtin_amdgcn_sched_barrier(0);
+                fir_win_step<OPL, AQ, RS>(ring, xr[u % RS], u, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gp += 4 * RS;
+            xb -= 4 * RS;
+        }
+#pragma unroll
+        for (int u = 0; u < RS - 1; ++u) {                               // the rest of the segment
+            if (i0 + u < len) {
+                ring[(u + AQ + 1) % RS] = lds4(gp + 4 * (u + AQ + 1));
+                xr[(u + 2) % RS] = lds4(xb + 4 * (RS - u - 2));
+                __builtin_amdgcn_sched_barrier(0);
+                fir_win_step<OPL, AQ, RS>(ring, xr[u % RS], u, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// per-lane pointers of the walk for output phase ph of window-relative frame fr
+template <int OPL, int BPF>
+__device__ __forceinline__ void win_lane(const WinGeom& g, const float* G, const float* Xs, int fr, int ph,
+                                         const float*& gl, const float*& xl) {
+    gl = G + (fr + g.RL) * g.gs + g.padl + OPL * ph + g.delay - 3;
+    xl = Xs + 4 * (BPF + 1) * (fr + g.RL);
+}
+
+// noise of the D frames of a window -> registers (clamped addresses), registers -> LDS (zero outside the signal)
+template <int BPF, int XQ>
+__device__ __forceinline__ void win_fetch_x(const float* __restrict__ xrow, int nblk, int jb0, float4 (&xv)[XQ]) {
+    const float4* xg = reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+    for (int u = 0; u < XQ; ++u) xv[u] = xg[min(max(jb0 + (int)threadIdx.x + 256 * u, 0), nblk - 1)];
+}
+template <int BPF, int XQ>
+__device__ __forceinline__ void win_store_x(float* __restrict__ Xs, int nblk, int jb0, const float4 (&xv)[XQ]) {
+#pragma unroll
+    for (int u = 0; u < XQ; ++u) {
+        const int b = threadIdx.x + 256 * u, jb = jb0 + b;
+        if (b < BPF * WIN_D)
+            *reinterpret_cast<float4*>(Xs + 4 * (b + b / BPF)) =
+                (jb >= 0 && jb < nblk) ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FilteredNoise in one kernel: FIR design on the matrix cores (E = M_even CE, O = M_odd CO, tap weights straight
+// from the accumulators into the frame images in LDS) + the walk above.  Persistent workgroups, three barriers
+// per window of W frames (noise.hip: three per 1024 outputs).
+// ------------------------------------------------------------------------------------------------
+// TRACE (tools/ubench/noise_win_trace.hip only): every wavefront of the first workgroups writes the clock at its phase
+// boundaries to `trace`.
+constexpr int WIN_TRACE_WGS = 64, WIN_TRACE_UNITS = 8, WIN_TRACE_MARKS = 8;
+template <int KH, int JT, int OPL, int BPF, bool TRACE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
+                       const float* __restrict__ mags,       // [R, T, 2 KH]
+                       const float* __restrict__ CE, const float* __restrict__ CO,     // [KH, NJ]
+                       const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
+                       const float* __restrict__ tap_wo,     // [NJ, 4]
+                       float* __restrict__ out,              // [R / vq, N]
+                       float* __restrict__ out_last,         // [R / n_voices, N] or null
+                       int R, int N, int T, int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices,
+                       int vmajor, int tpw, int dbg, long long* __restrict__ trace = nullptr) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int K = 2 * KH, KS = KH / 4, D = WIN_D, U = 4 * BPF, NP = U / OPL, NPASS = (NP + 7) / 8;
+    constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
+    constexpr int TW = 4 / JT;                                   // wavefront groups that share the tiles of a window
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    // LDS: [magnitudes D x K, swizzled][padded noise of D frames][D frame images].  Nothing valid ever reads below
+    // the first image's tap 0 or above the last image's last tap, so the first image starts `gshift` floats early
+    // (its lower gap overlaps the noise region) and there is no tail: 53 152 bytes at the headline shape -- three
+    // workgroups per CU (the allocation granule makes 53 888 bytes two).
+    float* M = lds_dyn;                                       // [D][K], 8-float groups XOR-swizzled by the row
+    float* Xs = M + D * K;                                    // padded noise of D frames
+    float* Gtop = Xs + (BPF + 1) * 4 * D;                     // first float of the image region
+    float* G = Gtop - g.gshift;                               // image s, tap k: G[s gs + padl + k]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wibs = wave_uniform(wib);
+    const int col = lane & 15, kq = lane >> 4;
+
+    // design role: wavefront (tg, jt) owns the 16-column block jt of the tiles tg, tg + TW, ...; its table fragments
+    // stay in registers, the tap weights of its column (12 values) are re-read per window (first-level cache hits)
+    const bool designer = wib < JT * TW;
+    const int jt = wib % JT, tg = wib / JT;
+    const int jcol = 16 * jt + col;
+    const int jc = min(jcol, NJ - 1);
+    float bE[KS], bO[KS];
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        bE[st] = CE[(4 * st + kq) * NJ + jc];
+        bO[st] = CO[(4 * st + kq) * NJ + jc];
+    }
+    for (int i = threadIdx.x; i < D * g.gs - g.gshift; i += 256) Gtop[i] = 0.0f;      // the gaps stay zero for ever
+    // The table fragments must have LANDED before the loop: with loads pending at its entry the compiler makes every
+    // trip wait for "all loads" in the middle of the design (that is, for the noise prefetch: ~2 us per unit).
+#pragma unroll
+    for (int st = 0; st < KS; ++st) asm volatile("" ::"v"(bE[st]), "v"(bO[st]));
+    // FIR role: lane = (frame fr, phase 2 wib + half) of every pass
+    const int half = lane >> 5, fr = min(lane & 31, g.W - 1);
+    const bool fr_ok = (lane & 31) < g.W;
+
+    const int nblk = N / 4;
+    const int ntasks = (R / vq) * g.wpr;
+    const int n_seg = R / n_voices, pq = n_voices / vq;
+    const int nunits = ntasks * vq;                               // (task, voice) units, walked voice-fastest
+
+    auto unit_geometry = [&](int unit, int& row, int& F0) {
+        const int task = unit / vq, iv = unit - task * vq;
+        const int orow = task / g.wpr;
+        if (vq == 1) {
+            row = orow;
+        } else {
+            const int b = orow / pq, v = (orow - b * pq) * vq + iv;
+            row = vmajor ? v * n_seg + b : b * n_voices + v;
+        }
+        F0 = (task - orow * g.wpr) * g.W;
+    };
+    float4 xv[XQ], mv[MQ];
+    // The tap weights of a column are 12 values (4 indices, 4 even and 4 odd weights) and the four lanes (col, kq = 0..3)
+    // of a column need the same twelve: each keeps three of them for the life of the workgroup and the design fetches
+    // the other nine with ds_bpermute -- 3 registers instead of 12, and no loads in the loop (columns past NJ repeat
+    // column NJ - 1: same values, same places).
+    int tq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int v = 3 * kq + i;                                  // 0..3 index, 4..7 even weight, 8..11 odd weight
+        const int* src = v < 4 ? tap_idx : (v < 8 ? reinterpret_cast<const int*>(tap_we) : reinterpret_cast<const int*>(tap_wo));
+        tq[i] = src[4 * jc + (v & 3)];
+    }
+    asm volatile("" ::"v"(tq[0]), "v"(tq[1]), "v"(tq[2]));          // landed before the loop (see above)
+    int4 ti;
+    float4 we, wo;
+    auto load_taps = [&]() {
+        int v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = __shfl(tq[i % 3], col + 16 * (i / 3));
+        ti = make_int4(v[0], v[1], v[2], v[3]);
+        we = make_float4(__int_as_float(v[4]), __int_as_float(v[5]), __int_as_float(v[6]), __int_as_float(v[7]));
+        wo = make_float4(__int_as_float(v[8]), __int_as_float(v[9]), __int_as_float(v[10]), __int_as_float(v[11]));
+    };
+    auto fetch_x = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+        win_fetch_x<BPF, XQ>(x + (size_t)row * N, nblk, BPF * (F0 - g.RL), xv);
+    };
+    auto store_x = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+        win_store_x<BPF, XQ>(Xs, nblk, BPF * (F0 - g.RL), xv);
+    };
+    auto fetch_m = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+#pragma unroll
+        for (int u = 0; u < MQ; ++u) {
+            const int i = min((int)threadIdx.x + 256 * u, D * PER_ROW - 1);
+            const int s = i / PER_ROW, c4 = i - s * PER_ROW;
+            const int f = min(max(F0 - g.RL + s, 0), T - 1);
+            mv[u] = reinterpret_cast<const float4*>(mags + ((size_t)row * T + f) * K)[c4];
+        }
+    };
+    auto store_m = [&]() {                                        // scale_fn on raw magnitudes on the way
+#pragma unroll
+        for (int u = 0; u < MQ; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < D * PER_ROW) {
+                float4 m = mv[u];
+                if (scale.kind >= 0)
+                    m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
+                                    apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
+                const int s = i / PER_ROW, c4 = i - s * PER_ROW;
+                *reinterpret_cast<float4*>(M + s * K + ((4 * c4) ^ win_mswz(s))) = m;
+            }
+        }
+    };
+    // A workgroup walks a contiguous run of tpw tasks (tpw vq units); two barriers per unit:
+    //   [M(u) in LDS]  design u (M -> G) -> BARRIER -> fetch M(u+1), walk u (G, Xs), M(u+1) to LDS -> BARRIER ->
+    //   noise(u+1) registers -> LDS, fetch noise(u+2)
+    // Both prefetches have a whole walk to land (measured: with the magnitudes fetched behind the design only, the
+    // kernel waited ~2 us per unit for them).
+    const int upw = tpw * vq;
+    const int u_begin = min((int)blockIdx.x * upw, nunits), u_end = min(u_begin + upw, nunits);
+    if (u_begin < u_end) {
+        fetch_x(u_begin);
+        fetch_m(u_begin);
+        store_x(u_begin);
+        store_m();
+        fetch_x(u_begin + 1);
+    }
+    __syncthreads();
+    float vsum[NPASS][OPL];
+    auto mark = [&](int unit, int k) {
+        if (TRACE && (int)blockIdx.x < WIN_TRACE_WGS && unit - u_begin < WIN_TRACE_UNITS && lane == 0)
+            trace[(((size_t)blockIdx.x * WIN_TRACE_UNITS + (unit - u_begin)) * 4 + wib) * WIN_TRACE_MARKS + k] = clock64();
+    };
+    for (int unit = u_begin; unit < u_end; ++unit) {
+        const int task = unit / vq, iv = unit - task * vq;
+        int row, F0;
+        unit_geometry(unit, row, F0);
+        mark(unit, 0);
+        // ---- 1. E / O blocks on the matrix cores; tap weights -> frame images (lane holds E, O of the frames
+        // 4 kq .. 4 kq + 3 of the tile at column 16 jt + col)
+        if (designer && !(dbg & 2)) {
+            load_taps();
+            for (int t = tg; t < D / 16; t += TW) {
+                f32x4 accE = f32x4{0.f, 0.f, 0.f, 0.f}, accO = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* arow = M + (16 * t + col) * K + 2 * kq;
+                const int sw = win_mswz(16 * t + col);
+#pragma unroll
+                for (int st = 0; st < KS; ++st) {
+                    const float2 am = *reinterpret_cast<const float2*>(arow + ((8 * st) ^ sw));
+                    accE = __builtin_amdgcn_mfma_f32_16x16x4f32(am.x, bE[st], accE, 0, 0, 0);
+                    accO = __builtin_amdgcn_mfma_f32_16x16x4f32(am.y, bO[st], accO, 0, 0, 0);
+                }
+                // An unused slot has index -1 and weights 0: it writes a zero to the gap float below tap 0 -- no branches.
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float E = accE[rr], O = accO[rr];
+                    float* dst = G + (16 * t + 4 * kq + rr) * g.gs + g.padl;
+                    dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
+                    dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
+                    dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
+                    dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+                }
+            }
+        }
+        mark(unit, 1);
+        __syncthreads();
+        mark(unit, 2);
+        fetch_m(unit + 1);               // in flight during the walk (the design alone is too short to hide the latency)
+        // ---- 2. the walk: NPASS passes of 8 phases
+        const int orow = task / g.wpr;
+        const bool lastv = out_last != nullptr && iv == vq - 1 && (orow % pq) == pq - 1;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int ph = 8 * p + 2 * wib + half;
+            float acc[OPL];
+#pragma unroll
+            for (int e = 0; e < OPL; ++e) acc[e] = 0.f;
+            if ((NP % 8 == 0 || 8 * p + 2 * wibs < NP) && !(dbg & 1)) {   // wave-uniform (NP is even)
+                const float *gl, *xl;
+                win_lane<OPL, BPF>(g, G, Xs, fr, min(ph, NP - 1), gl, xl);
+                const int qA = g.q_hi0 + (OPL / 4) * (8 * p + 2 * wibs);     // phase A's first block
+                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4, qA - g.nsteps + 1, g.gs, acc);
+            }
+            // out_last: the segment's last voice leaves on its own and stays out of the sum -- the outputs dictionary
+            // of the reference's DAG holds that voice's noise next to the mix
+            if (iv == 0) {
+#pragma unroll
+                for (int e = 0; e < OPL; ++e) vsum[p][e] = acc[e];
+            } else if (!lastv) {
+#pragma unroll
+                for (int e = 0; e < OPL; ++e) vsum[p][e] += acc[e];
+            }
+            if (iv == vq - 1 && fr_ok && ph < NP && F0 + fr < T) {
+                const size_t n = (size_t)U * (F0 + fr) + OPL * ph;
+                float4* o = reinterpret_cast<float4*>(out + (size_t)orow * N + n);
+#pragma unroll
+                for (int e4 = 0; e4 < OPL / 4; ++e4)
+                    o[e4] = make_float4(vsum[p][4 * e4], vsum[p][4 * e4 + 1], vsum[p][4 * e4 + 2], vsum[p][4 * e4 + 3]);
+                if (lastv) {
+                    float4* ol = reinterpret_cast<float4*>(out_last + (size_t)(orow / pq) * N + n);
+#pragma unroll
+                    for (int e4 = 0; e4 < OPL / 4; ++e4)
+                        ol[e4] = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
+                }
+            }
+        }
+        mark(unit, 3);
+        store_m();                       // M has been free since the design
+        mark(unit, 4);
+        __syncthreads();                 // G and Xs are free; M holds the next unit's magnitudes
+        mark(unit, 5);
+        store_x(unit + 1);
+        fetch_x(unit + 2);
+        mark(unit, 6);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two-call form's second half (impulse responses [R, T, Lw] from HBM): same layout, same walk.
+// ------------------------------------------------------------------------------------------------
+template <int OPL, int BPF>
+__global__ void __launch_bounds__(256) tv_fir_win_kernel(const float* __restrict__ x,   // [R, N]
+                                                       const float* __restrict__ ir,  // [R, T, Lw]
+                                                       float* __restrict__ out,       // [R, N]
+                                                       int R, int N, int T, int Lw, WinGeom g) {
+    constexpr int D = WIN_D, U = 4 * BPF, NP = U / OPL, NPASS = (NP + 7) / 8, XQ = (BPF * D + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* Xs = lds_dyn;
+    float* Gtop = Xs + (BPF + 1) * 4 * D;
+    float* G = Gtop - g.gshift;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wibs = wave_uniform(wib);
+    const int half = lane >> 5, fr = min(lane & 31, g.W - 1);
+    const bool fr_ok = (lane & 31) < g.W;
+    const int nblk = N / 4;
+    const int ntasks = R * g.wpr;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int row = task / g.wpr, F0 = (task - row * g.wpr) * g.W;
+        float4 xv[XQ];
+        win_fetch_x<BPF, XQ>(x + (size_t)row * N, nblk, BPF * (F0 - g.RL), xv);
+        for (int i = g.gshift + threadIdx.x; i < D * g.gs; i += 256) {
+            const int s = i / g.gs, tap = i - s * g.gs - g.padl;
+            const int f = min(max(F0 - g.RL + s, 0), T - 1);
+            G[i] = (tap >= 0 && tap < Lw) ? ir[((size_t)row * T + f) * Lw + tap] : 0.0f;
+        }
+        win_store_x<BPF, XQ>(Xs, nblk, BPF * (F0 - g.RL), xv);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int ph = 8 * p + 2 * wib + half;
+            if (NP % 8 == 0 || 8 * p + 2 * wib < NP) {
+                float acc[OPL];
+#pragma unroll
+                for (int e = 0; e < OPL; ++e) acc[e] = 0.f;
+                const float *gl, *xl;
+                win_lane<OPL, BPF>(g, G, Xs, fr, min(ph, NP - 1), gl, xl);
+                const int qA = g.q_hi0 + (OPL / 4) * (8 * p + 2 * wibs);     // phase A's first block
+                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4, qA - g.nsteps + 1, g.gs, acc);
+                if (fr_ok && ph < NP && F0 + fr < T) {
+                    float4* o = reinterpret_cast<float4*>(out + (size_t)row * N + (size_t)U * (F0 + fr) + OPL * ph);
+#pragma unroll
+                    for (int e4 = 0; e4 < OPL / 4; ++e4)
+                        o[e4] = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+static int ceildiv(int a, int b) { return -floordiv(-a, b); }
+
+int win_opl_for(int U) {
+    switch (U) {
+        case 64: return 8;
+        case 96: return 12;
+        case 128: return 16;
+        case 192: return 12;
+        default: return 0;
+    }
+}
+
+bool win_geometry(int N, int T, int Lw, int delay, WinGeom* g) {
+    if (N <= 0 || T <= 0 || N % T != 0 || N % 4 != 0 || delay < 0 || Lw <= 0) return false;
+    const int U = N / T, OPL = win_opl_for(U);
+    if (OPL == 0) return false;
+    const int bpf = U / 4, NP = U / OPL, AQ = (OPL + 6) / 4;
+    const int q_hi0 = floordiv(delay + OPL - 1, 4), q_lo0 = ceildiv(delay - Lw - 2, 4);
+    const int RL = -floordiv(q_lo0, bpf), RH = floordiv(q_hi0 + (OPL / 4) * (NP - 1), bpf);
+    const int W = WIN_D - RL - RH;
+    if (RL < 0 || RH < 0 || W < 16) return false;
+    // zero taps a walk meets below an image (phase A at phase B's first step) and above it (phase B at phase A's
+    // last step); one more block above is prefetched and never used
+    int padl = OPL + 3 - delay + 4 * q_hi0;
+    while ((padl + delay - 3) % 4 != 0) ++padl;
+    const int above = delay + OPL - 3 - 4 * q_lo0 + 4 * AQ - Lw;     // (the blocks prefetched past it may hold anything)
+    const int gap = (padl > above ? padl : above);
+    int gs = Lw + gap;
+    while (gs % 4 != 0 || (gs / 4) % 2 == 0) ++gs;
+    g->U = U; g->delay = delay; g->padl = padl; g->gs = gs; g->nsteps = q_hi0 - q_lo0 + 1; g->q_hi0 = q_hi0;
+    g->gshift = padl & ~3;
+    g->RL = RL; g->RH = RH; g->W = W; g->wpr = (T + W - 1) / W; g->opl = OPL; g->bpf = bpf;
+    return true;
+}
+
+size_t win_lds_bytes(const WinGeom& g, int K_or_0) {
+    size_t fl = (size_t)WIN_D * g.gs - g.gshift + (size_t)(g.bpf + 1) * 4 * WIN_D;
+    if (K_or_0 > 0) fl += (size_t)WIN_D * K_or_0;
+    return fl * sizeof(float);
+}
+
+bool win_fused_supported(int N, int T, int K, int Lw, int delay, WinGeom* g) {
+    if (!win_geometry(N, T, Lw, delay, g) || Lw != 2 * (K - 1)) return false;
+    const int U = g->U;
+    const bool inst = (K == 96 && (U == 96 || U == 192)) || (K == 64 && (U == 64 || U == 96)) || (K == 32 && U == 128);
+    return inst && win_lds_bytes(*g, K) <= 64 * 1024;
+}
+
+bool win_tvfir_supported(int N, int T, int Lw, int delay, WinGeom* g) {
+    return win_geometry(N, T, Lw, delay, g) && win_lds_bytes(*g, 0) <= 64 * 1024;
+}
+
+int launch_win_fused(const float* audio, const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
+                     const float* tap_we, const float* tap_wo, float* out, float* out_last, int R, int N, int T, int K,
+                     int NJ, const WinGeom& g, float bias, const ScaleFn& sf, int vq, int n_voices, int voice_major,
+                     hipStream_t stream) {
+    const long long tasks = (long long)(R / vq) * g.wpr;
+    DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
+    const size_t lds = win_lds_bytes(g, K);
+    // About eight (window, voice) units per workgroup: the set-up (zeroed images, table fragments) is paid once per
+    // eight, and there are several times more workgroups than the chip holds at once, so the last round of a launch
+    // is spread over all CUs by the dispatcher instead of leaving a fixed assignment's stragglers.
+    int tpw = ddspp_option("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
+    if (tpw < 1) tpw = 1;
+    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design
+    const dim3 grid((unsigned)((tasks + tpw - 1) / tpw)), block(256);
+#define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \
+    hipLaunchKernelGGL((noise_win_fused_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, CE, \
+                       CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw, dbg)
+    const int U = g.U;
+    if (K == 96 && U == 96) DDSPP_WIN_LAUNCH(48, 3, 12, 24);
+    else if (K == 96 && U == 192) DDSPP_WIN_LAUNCH(48, 3, 12, 48);
+    else if (K == 64 && U == 64) DDSPP_WIN_LAUNCH(32, 2, 8, 16);
+    else if (K == 64 && U == 96) DDSPP_WIN_LAUNCH(32, 2, 12, 24);
+    else if (K == 32 && U == 128) DDSPP_WIN_LAUNCH(16, 1, 16, 32);
+    else DDSPP_REQUIRE(false, "frequency_filter_eo: no windowed kernel for K=%d U=%d", K, U);
+#undef DDSPP_WIN_LAUNCH
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+int launch_win_tvfir(const float* audio, const float* ir, float* out, int R, int N, int T, int Lw, const WinGeom& g,
+                     hipStream_t stream) {
+    const long long tasks = (long long)R * g.wpr;
+    DDSPP_REQUIRE(tasks < (1ll << 31), "time_varying_fir: too many tasks");
+    const size_t lds = win_lds_bytes(g, 0);
+    const dim3 grid((unsigned)tasks), block(256);
+#define DDSPP_WIN_LAUNCH(OPL, BPF) \
+    hipLaunchKernelGGL((tv_fir_win_kernel<OPL, BPF>), grid, block, lds, stream, audio, ir, out, R, N, T, Lw, g)
+    switch (g.U) {
+        case 64: DDSPP_WIN_LAUNCH(8, 16); break;
+        case 96: DDSPP_WIN_LAUNCH(12, 24); break;
+        case 128: DDSPP_WIN_LAUNCH(16, 32); break;
+        case 192: DDSPP_WIN_LAUNCH(12, 48); break;
+        default: DDSPP_REQUIRE(false, "time_varying_fir: no windowed kernel for U=%d", g.U);
+    }
+#undef DDSPP_WIN_LAUNCH
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+}  // namespace ddspp

@@ -102,6 +102,7 @@ def fdn_impulse_response(input_gain, output_gain, gain_allpass, delays_allpass, 
 
     input_gain / output_gain [B, D]; gain_allpass / delays_allpass [B, D, A]; time_rev_0_sec, alpha_tone
     [B] (or [B, 1]); early_ir [B, E] or None  ->  ir [B, 2 * sampling_rate].
+    core.RECALLED['fdn_solve'] selects the float64 solve (default) or the reference's complex64 inverse.
     """
     from . import _lib
     from .core import _lib_, _ptr, _stream
@@ -125,7 +126,8 @@ def fdn_impulse_response(input_gain, output_gain, gain_allpass, delays_allpass, 
     spec = torch.empty((b, nb, 2), dtype=torch.float32, device=dev)
     _lib.check(_lib_().ddspp_fdn_transfer(_ptr(input_gain), _ptr(output_gain), _ptr(mix), _ptr(gain_allpass),
                                           _ptr(delays_allpass), _ptr(t0), _ptr(al), _ptr(dv), _ptr(spec), b, d, a,
-                                          freq_points, float(sampling_rate), _stream()))
+                                          freq_points, float(sampling_rate),
+                                          1 if core.RECALLED['fdn_solve'] == 'complex64' else 0, _stream()))
     ir = _irfft(spec, freq_points)
     if early_ir is not None:
         early = core.tf_float32(early_ir, device=dev).reshape(b, -1).contiguous()
@@ -268,3 +270,170 @@ class FeedbackDelayNetworkApply(Processor):
         if ir.dim() != 1:
             raise ValueError('FeedbackDelayNetwork impulse response must be 1-D [ir_size]')
         return core.fft_convolve(audio, ir[None, :], delay_compensation=0)
+
+
+class _InstrumentTables:
+    """tf.keras.layers.Embedding tables of a multi-instrument reverb layer: name -> [n_instruments, width] float32,
+    kept on the host and moved to the device of the first call (then cached)."""
+
+    def __init__(self, tables):
+        self._host = {k: torch.as_tensor(v, dtype=torch.float32).contiguous() for k, v in tables.items()}
+        self._dev = {}
+
+    def names(self):
+        return tuple(self._host)
+
+    def host(self):
+        return dict(self._host)
+
+    def load(self, params, n_instruments):
+        new = dict(self._host)
+        for k, v in params.items():
+            if k not in new:
+                raise KeyError(f'unknown embedding table {k!r}; known: {tuple(new)}')
+            v = torch.as_tensor(v, dtype=torch.float32).detach().cpu().clone()
+            if v.shape != new[k].shape:
+                raise ValueError(f'{k} must be {tuple(new[k].shape)} ([n_instruments={n_instruments}, width]), '
+                                 f'got {tuple(v.shape)}')
+            new[k] = v.contiguous()
+        self._host, self._dev = new, {}
+
+    def lookup(self, name, index):
+        dev = index.device
+        key = (name, str(dev))
+        if key not in self._dev:
+            self._dev[key] = self._host[name].to(dev)
+        return self._dev[key].index_select(0, index)
+
+
+def _instrument_index(piano_model, n_instruments):
+    """`piano_model` [B, 1] (or [B]) integer ids -> [B] int64 on its device; n_instruments == 1 maps every id to 0
+    (sub_modules.py:353-354, :432-433)."""
+    idx = torch.as_tensor(piano_model)
+    if not idx.is_cuda:
+        idx = idx.to(core.default_device())
+    if idx.dim() == 2:
+        idx = idx[..., 0]
+    if idx.dim() != 1:
+        raise ValueError('piano_model must be [batch, 1] instrument ids')
+    idx = idx.to(torch.int64)
+    return torch.zeros_like(idx) if n_instruments == 1 else idx
+
+
+class MultiInstrumentReverb:
+    """ddsp_piano/modules/sub_modules.py:302-365: one learnt impulse response per instrument (an Embedding of
+    reverb_length values, initialised N(0, 1e-6)); at inference an exponential decay mask past sample 16000.
+    `layer(features)` reads features['piano_model'] [B, 1] and returns {'reverb_ir': [B, reverb_length]} (the
+    nn.DictLayer contract PianoModel relies on, piano_model.py:99-125); `layer.call(piano_model)` returns the tensor."""
+
+    def __init__(self, n_instruments=16, reverb_duration=1.5, sample_rate=16000, inference=False, seed=0,
+                 name='multi_instrument_reverb'):
+        self.name = name
+        self.n_instruments = int(n_instruments)
+        self.reverb_duration = reverb_duration
+        self.sample_rate = sample_rate
+        self.inference = inference
+        g = torch.Generator().manual_seed(int(seed))
+        self._tables = _InstrumentTables(
+            {'reverb_dict': torch.randn(self.n_instruments, self.reverb_length, generator=g) * 1e-6})
+
+    @property
+    def reverb_length(self):
+        return int(self.reverb_duration * self.sample_rate)
+
+    def parameters(self):
+        return self._tables.host()
+
+    def load_parameters(self, params):
+        """{'reverb_dict': [n_instruments, reverb_length]} -- e.g. the dafx22 checkpoint's reverb bank."""
+        self._tables.load(params, self.n_instruments)
+
+    def exponential_decay_mask(self, ir, decay_exponent=4., decay_start=16000):
+        """sub_modules.py:339-349."""
+        n = self.reverb_length - decay_start
+        time = torch.linspace(0.0, 1.0, n, dtype=torch.float32, device=ir.device)
+        mask = torch.cat([torch.ones(decay_start, dtype=torch.float32, device=ir.device),
+                          torch.exp(-decay_exponent * time)])
+        return ir * mask[None, :]
+
+    def call(self, piano_model):
+        ir = self._tables.lookup('reverb_dict', _instrument_index(piano_model, self.n_instruments))
+        return self.exponential_decay_mask(ir) if self.inference else ir
+
+    def __call__(self, features, training=False):
+        pm = features['piano_model'] if isinstance(features, dict) else features
+        return {'reverb_ir': self.call(pm)}
+
+
+class MultiInstrumentFeedbackDelayReverb:
+    """ddsp_piano/modules/sub_modules.py:368-446 -- how the default (maestro-v2) configuration produces `reverb_ir`
+    (configs/maestro-v2.gin:118-122): seven Embedding tables hold one feedback-delay network per instrument,
+    `call(piano_model [B, 1]) -> reverb_ir [B, 2 * sample_rate]` looks the B parameter sets up, conditions two of them
+    (relu on time_rev_0_sec, sigmoid on alpha_tone, :440-441), and evaluates FeedbackDelayNetwork.get_ir for all of them
+    at once (the reference's tf.vectorized_map, :444; here one launch of ddspp_fdn_transfer + one batched C2R).
+
+    Table layout (the Embedding weights, rows = instruments): input_gain / output_gain [n, D]; gain_allpass /
+    delays_allpass [n, 4 D] with reshape_embedding's split-then-stack order (:427-429) -- column a D + d of the table is
+    all-pass stage a of delay line d, i.e. the [D, 4] matrix is table.reshape(4, D).T, NOT table.reshape(D, 4);
+    time_rev_0_sec / alpha_tone [n, 1]; early_ir [n, early_ir_length].  Initialisers as :386-418 (seeded);
+    load_parameters() takes a checkpoint's arrays."""
+
+    TABLES = ('input_gain', 'output_gain', 'gain_allpass', 'delays_allpass', 'time_rev_0_sec', 'alpha_tone', 'early_ir')
+
+    def __init__(self, n_instruments=10, sample_rate=16000, delay_lines=8, early_ir_length=200, regularize_early=False,
+                 seed=0, name='multi_instrument_feedback_delay_reverb'):
+        self.name = name
+        self.n_instruments = int(n_instruments)
+        self.sample_rate = sample_rate
+        self.delay_lines = int(delay_lines)
+        self.early_ir_length = int(early_ir_length)
+        self.regularize_early = regularize_early            # a training-time L1 penalty: nothing to do at synthesis
+        n, d = self.n_instruments, self.delay_lines
+        g = torch.Generator().manual_seed(int(seed))
+
+        def normal(mean, std, *shape):
+            return (torch.randn(*shape, generator=g) * std + mean).to(torch.float32)
+        self._tables = _InstrumentTables({
+            'input_gain': normal(0.25, 0.1, n, d), 'output_gain': normal(0.25, 0.1, n, d),
+            'gain_allpass': normal(0.25, 0.1, n, 4 * d), 'delays_allpass': normal(400.0, 60.0, n, 4 * d),
+            'time_rev_0_sec': normal(2.0, 0.5, n, 1), 'alpha_tone': normal(0.0, 0.1, n, 1),
+            'early_ir': normal(0.0, 0.1, n, self.early_ir_length)})
+        # the reference's inner FeedbackDelayNetwork(trainable=False, sampling_rate=sample_rate): default delay lines
+        self.reverb_model = FeedbackDelayNetwork(trainable=False, sampling_rate=self.sample_rate)
+        if self.reverb_model.delay_lines != d:
+            raise ValueError(f'the inner FeedbackDelayNetwork has {self.reverb_model.delay_lines} delay lines '
+                             f'(fdn_reverb.py:96), delay_lines={d} cannot be evaluated (neither can the reference)')
+
+    def parameters(self):
+        return self._tables.host()
+
+    def load_parameters(self, params):
+        self._tables.load(params, self.n_instruments)
+
+    @staticmethod
+    def reshape_embedding(embedding, splits=4):
+        """sub_modules.py:427-429: tf.stack(tf.split(embedding, splits, axis=-1), axis=-1): [..., splits * D] ->
+        [..., D, splits] with out[..., d, a] = embedding[..., a * D + d]."""
+        d = embedding.shape[-1] // splits
+        return embedding.reshape(embedding.shape[:-1] + (splits, d)).transpose(-1, -2).contiguous()
+
+    def controls(self, piano_model):
+        """The controls_dict of :434-443, batched over the B looked-up instruments."""
+        idx = _instrument_index(piano_model, self.n_instruments)
+        t = self._tables
+        return {'input_gain': t.lookup('input_gain', idx), 'output_gain': t.lookup('output_gain', idx),
+                'gain_allpass': self.reshape_embedding(t.lookup('gain_allpass', idx)),
+                'delays_allpass': self.reshape_embedding(t.lookup('delays_allpass', idx)),
+                'time_rev_0_sec': torch.relu(t.lookup('time_rev_0_sec', idx)),
+                'alpha_tone': torch.sigmoid(t.lookup('alpha_tone', idx)),
+                'early_ir': t.lookup('early_ir', idx)}
+
+    def call(self, piano_model):
+        c = self.controls(piano_model)
+        return fdn_impulse_response(c['input_gain'], c['output_gain'], c['gain_allpass'], c['delays_allpass'],
+                                    c['time_rev_0_sec'], c['alpha_tone'], c['early_ir'],
+                                    self.reverb_model.delay_values, self.reverb_model.sampling_rate)
+
+    def __call__(self, features, training=False):
+        pm = features['piano_model'] if isinstance(features, dict) else features
+        return {'reverb_ir': self.call(pm)}

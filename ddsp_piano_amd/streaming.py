@@ -12,10 +12,12 @@ internally between two samples.  For this path that is exactly:
     plus the piece's ABSOLUTE sample position: the reference's bilinear resize forms float32(n) * (T / N) and takes
     its fractional part as the interpolation weight, which rounds differently at n = 12000 and n = 1212000
     (core.linear_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128;
-  * FilteredNoise: the time-varying FIR reaches Lw - 1 - delay samples back and `delay` samples forward, at most one
-    frame each way: the piece is filtered with one frame of context on either side and cropped.  Noise samples are
-    addressed by their absolute position (explicit ``noise=`` rows, or the library's counter-based Philox stream), so a
-    piece draws the same numbers whichever call renders it;
+  * FilteredNoise: the time-varying FIR reaches Lw - 1 - delay samples back and `delay` samples forward: the piece is
+    filtered with ceil((Lw - 1 - delay) / U) frames of context behind it and ceil(delay / U) frames ahead
+    (``noise_reach``: one frame each way at 16 / 24 kHz, two at ENSTDkCl's 8 kHz with 64 bands) and cropped.  Noise
+    samples are addressed by their absolute position: explicit ``noise=`` rows, or the library's counter-based Philox
+    stream, which here is keyed by (row, absolute sample) -- a piece draws the same numbers whichever PUSH renders it
+    (it is NOT the stream ProcessorGroup / NativeGroup draw for a one-call render, which is keyed by call);
   * reverb: the last L - 1 samples of the dry mix (overlap-save).
 
 The pieces then equal the one-call render: the oscillator phases bit for bit, the sums and FFTs to float32 round-off
@@ -40,6 +42,17 @@ def block_frames(upsampling):
     return 1000 // math.gcd(int(upsampling), 1000)
 
 
+def noise_reach(n_bands, window_size, upsampling):
+    """(frames behind, frames ahead) of a piece that the FilteredNoise FIR of a piece's samples touches: the FIR of
+    ddsp.core.frequency_filter has Lw = min(window_size, 2 (K - 1)) taps and is advanced by crop_and_compensate_delay's
+    `delay`, so output n collects inputs n + delay - (Lw - 1) ... n + delay."""
+    ir_size = 2 * (int(n_bands) - 1)
+    lw = ir_size if (window_size <= 0 or window_size > ir_size) else int(window_size)
+    delay = lw // 2 if core.RECALLED['auto_delay'] == 'half' else (lw - 1) // 2 - 1
+    u = int(upsampling)
+    return max(0, -(-(lw - 1 - delay) // u)), max(0, -(-delay // u))
+
+
 class StreamingSynthesizer:
     """additive: MultiInharmonic(inference=True); noise: (DynamicSize)FilteredNoise; reverb: Reverb, a parameter
     holding FeedbackDelayNetwork, FeedbackDelayNetworkApply or None.  Keys as polyphonic_dag (``<control>_<voice>``)."""
@@ -62,7 +75,7 @@ class StreamingSynthesizer:
         self.phase = phase_state                 # [R, S * H] or None (a signal that starts at frame 0)
         self._buf = None                         # controls not yet rendered: {key: [B, t, C]}
         self._noise_buf = None                   # explicit noise not yet used: [B, P, n]
-        self._prev = None                        # the frame before `frame` (noise controls + noise samples)
+        self._prev = None                        # the frames before `frame` the noise FIR reaches (controls + samples)
         self._tail = None                        # last L - 1 samples of the dry mix
         self._ir = None
 
@@ -82,11 +95,20 @@ class StreamingSynthesizer:
             noise = core.tf_float32(noise)
             self._noise_buf = noise if self._noise_buf is None else torch.cat([self._noise_buf, noise], dim=2)
         have = next(iter(self._buf.values())).shape[1]
-        usable = have if final else ((have - 1) // self.block) * self.block
+        usable = have if final else ((have - self._lookahead()) // self.block) * self.block
         if usable <= 0:
             b = next(iter(self._buf.values())).shape[0]
             return torch.empty((b, 0), dtype=torch.float32, device=next(iter(self._buf.values())).device)
         return self._render(usable, final)
+
+    def _reach(self):
+        k = self._buf[f'{self.nkeys[0]}_0'].shape[-1]
+        return noise_reach(k, getattr(self.noise, 'window_size', 257), self.U)
+
+    def _lookahead(self):
+        """Frames past a piece that must be known to render it: one for the oscillators (frame t is interpolated
+        towards frame t + 1), `ahead` for the noise FIR."""
+        return max(1, self._reach()[1])
 
     # ------------------------------------------------------------------------------------------ one piece
     def _rows(self, key, sl, vm=None):
@@ -95,7 +117,8 @@ class StreamingSynthesizer:
     def _render(self, nb, final):
         P, U = self.P, self.U
         have = next(iter(self._buf.values())).shape[1]
-        look = 0 if (final and nb == have) else 1
+        back, _ = self._reach()
+        look = min(self._lookahead(), have - nb)     # fewer only at the end of the signal: nothing follows there
         sl = slice(0, nb + look)
         amp, vm = self._rows(self.akeys[0], sl)
         hd, _ = self._rows(self.akeys[1], sl, vm)
@@ -116,16 +139,19 @@ class StreamingSynthesizer:
             self.phase = core.oscillator_phase_state(ctl['f0_hz'], n // 1000, U, add.sample_rate, inharm_coef=inh_rows,
                                                      n_harmonics=H, phase_state=self.phase, audible=ctl['_audible'],
                                                      sample_offset=self.frame * U)
-        # ---- noise: one frame of context either side
+        # ---- noise: `back` frames of context behind the piece, `look` ahead
         mags_now, _ = self._rows(self.nkeys[0], sl, vm)
-        hist = 0 if self._prev is None else 1
+        hist = 0 if self._prev is None else self._prev['mags'].shape[1]
         z_now = self._take_noise(B, P, (nb + look) * U, vm, dev)              # [R, (nb + look) U]
         if hist:
             mags_ctx = torch.cat([self._prev['mags'], mags_now], dim=1)
             z_ctx = torch.cat([self._prev['noise'], z_now], dim=1)
         else:
             mags_ctx, z_ctx = mags_now, z_now
-        self._prev = {'mags': mags_now[:, nb - 1:nb].contiguous(), 'noise': z_now[:, (nb - 1) * U:nb * U].contiguous()}
+        keep = min(back, hist + nb)
+        self._prev = None if keep == 0 else {
+            'mags': mags_ctx[:, hist + nb - keep:hist + nb].contiguous(),
+            'noise': z_ctx[:, (hist + nb - keep) * U:(hist + nb) * U].contiguous()}
         nz = self.noise
         sig = nz.get_signal(nz.get_controls(mags_ctx.contiguous())['magnitudes'], noise=z_ctx.contiguous())
         sig = sig[:, hist * U:hist * U + n].contiguous()                       # [R, n]
@@ -201,20 +227,22 @@ def render_range(make_synth, features, frame_lo, frame_hi, noise=None):
         state = core.oscillator_phase_state(f0, start * U // 1000, U, syn.additive.sample_rate,
                                             inharm_coef=inh.reshape(inh.shape[0], -1).contiguous(), n_harmonics=H)
     syn.reset(frame=start, phase_state=state)
-    if start > 0:                               # the frame before `start` is the noise branch's context
+    back, ahead = noise_reach(ctl[f'{syn.nkeys[0]}_0'].shape[-1], getattr(syn.noise, 'window_size', 257), U)
+    c0 = max(0, start - back)
+    if start > c0:                              # the frames before `start` that the noise FIR reaches
         P = syn.P
-        mags, vm = _stack_voices([ctl[f'{syn.nkeys[0]}_{i}'][:, start - 1:start].contiguous() for i in range(P)])
+        mags, vm = _stack_voices([ctl[f'{syn.nkeys[0]}_{i}'][:, c0:start].contiguous() for i in range(P)])
         B = mags.shape[0] // P
         if noise is not None:
-            z = core.tf_float32(noise)[:, :, (start - 1) * U:start * U]
-            zr = (z.transpose(0, 1) if vm else z).contiguous().reshape(B * P, U)
+            z = core.tf_float32(noise)[:, :, c0 * U:start * U]
+            zr = (z.transpose(0, 1) if vm else z).contiguous().reshape(B * P, (start - c0) * U)
         else:
-            syn.frame = start - 1
-            zr = syn._take_noise(B, P, U, vm, mags.device)
+            syn.frame = c0
+            zr = syn._take_noise(B, P, (start - c0) * U, vm, mags.device)
             syn.frame = start
         syn._prev = {'mags': mags.contiguous(), 'noise': zr}
     last = frame_hi >= T
-    stop = T if last else frame_hi + 1           # one frame of look-ahead
+    stop = T if last else min(T, frame_hi + max(1, ahead))      # look-ahead: oscillators one frame, noise FIR `ahead`
     piece = {k: v[:, start:stop] for k, v in ctl.items()}
     for k in syn.rkeys:
         if k in features:

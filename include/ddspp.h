@@ -314,11 +314,16 @@ int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* plan, const float* audio,
 
 /* FeedbackDelayNetwork.get_late_ir up to the irfft -- fdn_reverb.py:178-334, B instruments at once
  * (sub_modules.py:431-446).  gains [B,D], mixing_matrix [D,D], allpass gains/delays [B,D,A],
- * time_rev_0_sec / alpha_tone [B], delay_values [D] -> H [B, freq_points/2+1] complex64. */
+ * time_rev_0_sec / alpha_tone [B], delay_values [D] -> H [B, freq_points/2+1] complex64.
+ * solve: DDSPP_FDN_SOLVE_F64 (0: the per-bin D x D system solved in float64 -- the value the reference's recipe
+ * approximates) or DDSPP_FDN_SOLVE_C64_INVERSE (1: tf.linalg.inv + matmuls in complex64 as fdn_reverb.py:314-333
+ * writes them; good to cond x 6e-8 near the network's resonances). */
+#define DDSPP_FDN_SOLVE_F64 0
+#define DDSPP_FDN_SOLVE_C64_INVERSE 1
 int ddspp_fdn_transfer(const float* input_gain, const float* output_gain, const float* mixing_matrix,
                        const float* gain_allpass, const float* delays_allpass, const float* time_rev_0_sec,
                        const float* alpha_tone, const float* delay_values, void* H, int B, int D, int A,
-                       int freq_points, float sampling_rate, hipStream_t stream);
+                       int freq_points, float sampling_rate, int solve, hipStream_t stream);
 
 /* FeedbackDelayNetwork.get_ir, fdn_reverb.py:354-360: ir[B,L] += zero-padded early_ir[B,E]. */
 int ddspp_fdn_add_early(float* ir, const float* early_ir, int B, int L, int E, hipStream_t stream);

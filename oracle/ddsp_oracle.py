@@ -823,6 +823,66 @@ def fdn_get_ir(input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0
     return (early[:late.shape[0]] + late).astype(F32)
 
 
+def reshape_embedding(embedding, splits=4):
+    """MultiInstrumentFeedbackDelayReverb.reshape_embedding, sub_modules.py:427-429:
+    tf.stack(tf.split(embedding, splits, axis=-1), axis=-1): [..., splits * D] -> [..., D, splits]."""
+    return np.stack(np.split(np.asarray(embedding), splits, axis=-1), axis=-1)
+
+
+class MultiInstrumentFeedbackDelayReverb:
+    """sub_modules.py:368-446 with the Embedding tables given as arrays [n_instruments, width] (names as the layer's
+    attributes without the underscore).  call(piano_model [B, 1]) -> reverb_ir [B, 2 * sample_rate]."""
+
+    def __init__(self, tables, n_instruments, sample_rate=16000, exact_solve=False):
+        self.tables = {k: tf_float32(v) for k, v in tables.items()}
+        self.n_instruments = n_instruments
+        self.sample_rate = sample_rate
+        self.exact_solve = exact_solve
+
+    def controls(self, piano_model):
+        pm = np.asarray(piano_model)
+        if self.n_instruments == 1:                                          # :432-433
+            pm = np.zeros_like(pm, dtype=np.int32)
+        pm = pm[..., 0]                                                      # :434
+        t = self.tables
+        return {'input_gain': t['input_gain'][pm], 'output_gain': t['output_gain'][pm],
+                'gain_allpass': reshape_embedding(t['gain_allpass'][pm]),
+                'delays_allpass': reshape_embedding(t['delays_allpass'][pm]),
+                'time_rev_0_sec': np.maximum(t['time_rev_0_sec'][pm], F32(0)),               # tf.nn.relu, :440
+                'alpha_tone': (F32(1) / (F32(1) + np.exp(-t['alpha_tone'][pm]))).astype(F32),  # tf.math.sigmoid, :441
+                'early_ir': t['early_ir'][pm]}
+
+    def __call__(self, piano_model):
+        c = self.controls(piano_model)
+        b = c['input_gain'].shape[0]
+        return np.stack([fdn_get_ir(c['input_gain'][i], c['output_gain'][i], c['gain_allpass'][i], c['delays_allpass'][i],
+                                    c['time_rev_0_sec'][i, 0], c['alpha_tone'][i, 0], c['early_ir'][i],
+                                    sampling_rate=self.sample_rate, exact_solve=self.exact_solve) for i in range(b)])
+
+
+class MultiInstrumentReverb:
+    """sub_modules.py:302-365: reverb_dict [n_instruments, reverb_length]; exponential decay mask at inference."""
+
+    def __init__(self, reverb_dict, n_instruments, inference=False):
+        self.reverb_dict = tf_float32(reverb_dict)
+        self.n_instruments = n_instruments
+        self.inference = inference
+
+    def __call__(self, piano_model, decay_exponent=4., decay_start=16000):
+        pm = np.asarray(piano_model)
+        if self.n_instruments == 1:
+            pm = np.zeros_like(pm, dtype=np.int32)
+        ir = self.reverb_dict[pm]
+        if ir.ndim == 3:
+            ir = ir[:, 0]
+        if self.inference:                                                   # :339-349
+            n = self.reverb_dict.shape[1]
+            time = np.linspace(0.0, 1.0, n - decay_start).astype(F32)
+            mask = np.concatenate([np.ones(decay_start, F32), np.exp(F32(-decay_exponent) * time).astype(F32)])
+            ir = (ir * mask[None, :]).astype(F32)
+        return ir
+
+
 # ----------------------------------------------------------------------------------------------
 # SURVEY.md 8f-3 ("next" row): SurrogateAdditive, ddsp_piano/modules/surrogate_synth.py
 # ----------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def _processors(dp, sr):
             dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'))
 
 
-@pytest.mark.parametrize('sr,H,K,S', [(24000, 128, 96, 1), (16000, 96, 64, 2)])
+@pytest.mark.parametrize('sr,H,K,S', [(24000, 128, 96, 1), (16000, 96, 64, 2), (8000, 48, 64, 1), (8000, 48, 32, 1)])
 def test_pushes_equal_the_one_call_render(sr, H, K, S):
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import streaming
@@ -87,6 +87,33 @@ def test_time_ranges_rendered_from_scratch():
     with pytest.raises(ValueError):
         streaming.render_range(make, feats, 60, 500, noise=noise)
     # the library's own noise stream is addressed by absolute position: any split renders the same file
+    one = streaming.render_range(make, feats, 0, T)
+    two = torch.cat([streaming.render_range(make, feats, 0, 375), streaming.render_range(make, feats, 375, T)], dim=1)
+    assert (one - two).abs().max().item() < 3e-5 * float(one.abs().max())
+
+
+def test_noise_context_at_8khz_reaches_two_frames():
+    """ENSTDkCl-8kHz with 64 noise bands: hop 32, FIR of 126 taps advanced by 61 -- it reaches 64 samples back and 61
+    ahead, two frames each way.  Ranges rendered from scratch equal the one-call render, with explicit noise
+    and with the library's position-keyed stream."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import streaming
+    assert streaming.noise_reach(64, 257, 32) == (2, 2) and streaming.noise_reach(96, 257, 96) == (1, 1)
+    assert streaming.noise_reach(64, 257, 64) == (1, 1) and streaming.noise_reach(32, 257, 32) == (1, 1)
+    rng = np.random.default_rng(8)
+    sr, B, P, T, H, K, S, L = 8000, 2, 3, 750, 48, 64, 1, 3000
+    U = sr // 250
+    feats = _file(rng, B, P, T, H, K, S, L)
+    noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * U]).astype(np.float32), device='cuda')
+    a, z, r = _processors(dp, sr)
+    whole = dp.ProcessorGroup(dp.polyphonic_dag(a, z, r, n_synths=P, **KEYS))(feats, noise=noise)
+
+    def make():
+        return streaming.StreamingSynthesizer(*_processors(dp, sr), n_synths=P)
+    parts = [streaming.render_range(make, feats, lo, hi, noise=noise) for lo, hi in ((0, 250), (250, 625), (625, T))]
+    got = torch.cat(parts, dim=1)
+    assert got.shape == whole.shape
+    assert (got - whole).abs().max().item() < 3e-5 * float(whole.abs().max())
     one = streaming.render_range(make, feats, 0, T)
     two = torch.cat([streaming.render_range(make, feats, 0, 375), streaming.render_range(make, feats, 375, T)], dim=1)
     assert (one - two).abs().max().item() < 3e-5 * float(one.abs().max())

@@ -91,6 +91,14 @@ def main():
         rs = noise.raw_scale()
         mn, av = timeit(lambda: core.frequency_filter(x, mags, window_size=noise.window_size, raw_scale=rs), args.reps)
         print(f'frequency_filter (raw magnitudes -> filtered noise) min {mn:8.3f} ms avg {av:8.3f} ms')
+    if 'noisev' in which:                 # the batched group's call: voice sums, last voice split off or not
+        x = core.uniform_noise((R, N), seed=1, device=dev)
+        rs = noise.raw_scale()
+        for vq in (8, 4, 2):
+            for split in (False, True):
+                fn = lambda: core.frequency_filter_voice_sums(x, mags, noise.window_size, rs, P, vq, False, split_last=split)  # noqa: E731
+                mn, av = timeit(fn, args.reps)
+                print(f'frequency_filter_voice_sums vq={vq} split_last={int(split)} min {mn:8.3f} ms avg {av:8.3f} ms')
     if 'osc' in which:
         rows = min(args.osc_rows, R)
         c = additive._controls(amp[:rows], hd[:rows], inh[:rows], f0[:rows, :, :1].contiguous())
