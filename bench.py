@@ -18,6 +18,14 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
                      HIP-event time against the VALU issue ceiling, instruction counts from profiles/;
   * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
                      TF/ddsp reference here) and an op-by-op torch-CPU version on all cores, timed on this host;
+  * value          : global batch x samples / MEDIAN of the per-step device times (every step bracketed by HIP events
+                     on the launch stream and synchronised; with N > 1 the step includes its all-gather, max over ranks)
+                     -- SURVEY.md 8(d)'s definition.  `pipelined` holds the wall clock of K back-to-back steps (barrier +
+                     synchronize on both sides, max over ranks), where the side stream / the gather of one step overlap
+                     the next;
+  * roofline.measured_peak : device copy / triad / read rates measured in the same run, next to the 8 TB/s spec;
+  * counters_stale : true when profiles/step_valu.json / osc_traffic.json describe another build of the kernels
+                     (their csrc hash differs): frac_mix / traffic are then dropped;
   * step_ms        : per-step HIP-event times (median / min / max) of the headline call;
   * audio_only_call, dense_worst_case, moving_f0, single_stream (+ hipGraph replay), whole_file: other call forms / inputs.
 Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no torchrun environment the script
@@ -97,7 +105,7 @@ def launcher_command(gpus, env, argv, device_count):
         return None
     if gpus == 1:
         return None
-    if device_count < gpus:
+    if device_count < gpus and env.get('DDSPP_BENCH_SHARE_GPU') != '1':
         raise SystemExit(f'bench.py: --gpus {gpus} requested but this box has {device_count} GPU(s); '
                          'not falling back to fewer ranks')
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}',
@@ -199,6 +207,23 @@ def ms_summary(ts):
     return {'median': float(np.median(ts)), 'min': float(np.min(ts)), 'max': float(np.max(ts)), 'n': len(ts)}
 
 
+def measure_device_peaks(device, nbytes=1 << 30):
+    """HBM rates this device reaches in THIS run (GB/s, bytes read + bytes written): a device copy, a triad, a read."""
+    n = nbytes // 4
+    a = torch.ones(n, dtype=torch.float32, device=device)
+    b = torch.full((n,), 2.0, dtype=torch.float32, device=device)
+    c = torch.empty(n, dtype=torch.float32, device=device)
+    copy = float(np.min(event_times(lambda: c.copy_(a), 6, warmup=2))) * 1e-3
+    triad = float(np.min(event_times(lambda: torch.add(a, b, alpha=3.0, out=c), 6, warmup=2))) * 1e-3
+    read = float(np.min(event_times(lambda: a.sum(), 6, warmup=2))) * 1e-3
+    out = {'copy': 2 * nbytes / copy / 1e9, 'triad': 3 * nbytes / triad / 1e9, 'read': nbytes / read / 1e9,
+           'bytes': nbytes, 'note': 'torch copy_ (hipMemcpyDtoD-class kernel), a + 3 b -> c, sum(a) on 1 GiB float32 buffers; '
+                                    'best of 6, HIP events'}
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
 def measure_roofline(dp, base, args, T, U, device):
     """cos_oscillator_bank at the operator boundary on materialised envelopes (HBM-bound kernel)."""
     from ddsp_piano_amd import core
@@ -236,15 +261,24 @@ def measure_roofline(dp, base, args, T, U, device):
     times = [t * 1e-3 for t in event_times(launch, 5, warmup=1)]
     t = float(np.mean(times))
     alg_bytes = rows * (N * H * 8 + N * 4)
-    traffic = None
+    traffic, stale = None, None
     tf = os.path.join(ROOT, 'profiles', 'osc_traffic.json')
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+            prof = json.load(open(tf))
+            stale = prof.get('csrc_hash') != dp._lib.source_hash()
+            # the counter pass ran at rows=1024: per-launch bytes scale with the rows of this launch
+            if not stale:
+                traffic = prof['hbm_bytes_per_launch'] * alg_bytes / prof['algorithmic_bytes_per_launch']
         except Exception:  # noqa: BLE001
             traffic = None
+    del fe, ae, out
+    torch.cuda.empty_cache()
+    peaks = measure_device_peaks(device)
+    best = max(peaks['copy'], peaks['triad'], peaks['read'])
     return {'bound': 'hbm', 'achieved': alg_bytes / t / 1e9, 'peak': HBM_PEAK_BYTES / 1e9, 'unit': 'GB/s',
-            'frac': alg_bytes / t / HBM_PEAK_BYTES, 'traffic': traffic,
+            'frac': alg_bytes / t / HBM_PEAK_BYTES, 'traffic': traffic, 'counters_stale': stale,
+            'measured_peak': best, 'frac_of_measured_peak': alg_bytes / t / 1e9 / best, 'measured': peaks,
             'kernel': 'ddspp::osc_kernel<VPL, materialised, MODE_MAIN, sum> (ddspp_cos_oscillator_bank, spans=1: '
                       'every envelope byte read once)',
             'rows': rows, 'n_samples': N, 'n_harmonics': H, 'algorithmic_bytes_per_launch': alg_bytes,
@@ -282,6 +316,9 @@ def measure_roofline_step(dp, base, args, T, U, device):
     if os.path.exists(pf):
         try:
             prof = json.load(open(pf))
+            out['counters_stale'] = prof.get('csrc_hash') != dp._lib.source_hash()
+            if out['counters_stale']:          # the counts describe another build of the kernels: no fractions from them
+                return out
             insts = float(prof['valu_wave_instructions_per_call'])
             out.update({'valu_wave_instructions': insts, 'achieved': insts / t,
                         'frac': insts / t / out['peak'], 'counters': prof.get('source')})
@@ -406,8 +443,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # DDSPP_BENCH_SHARE_GPU=1 (dry run of the multi-rank flow on a box with fewer GPUs than ranks: tests/test_gpu_dist.py):
+    # ranks wrap around the devices and the backend must be gloo (RCCL refuses two ranks on one GPU); the line says so.
+    share_gpu = os.environ.get('DDSPP_BENCH_SHARE_GPU') == '1'
+    backend = os.environ.get('DDSPP_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     use_dist = world > 1 or os.environ.get('DDSPP_BENCH_DIST') == '1'   # the latter: exercise RCCL with one rank
     if use_dist:
@@ -415,9 +457,12 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist_mod.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist_mod.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
-        world = dist.get_world_size()            # the ranks RCCL actually sees
+        world = dist.get_world_size()            # the ranks the backend actually sees
 
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import parallel
@@ -456,15 +501,48 @@ def main():
     for _ in range(2):                 # set-up, not a step: rocFFT plans, kernel code objects, allocator pools
         call(pg, feats)
     torch.cuda.synchronize()
+    # (1) W warm-up steps, then EXACTLY K steps, each bracketed by HIP events on the launch stream and synchronised: no step
+    #     overlaps its neighbours.  With N > 1 a step includes its own all-gather (synchronous).  value = global samples /
+    #     the MEDIAN step time, max over ranks ("device-synchronised, median of >= 20 runs").
+    def sync_step():
+        audio = call(pg, feats)
+        if use_dist:
+            parallel.gather_audio(audio, gathered[0])
+        return audio
+
+    for _ in range(args.warmup):
+        sync_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_wall0 = time.perf_counter()
+    step_ts = event_times(sync_step, args.steps, warmup=0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall_sync = time.perf_counter() - t_wall0
+    med = float(np.median(step_ts)) * 1e-3
+    if use_dist:
+        tt = torch.tensor([med, wall_sync], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        med, wall_sync = float(tt[0].item()), float(tt[1].item())
+    value = world * B * N / med
+    # (2) the same K steps back to back (barrier + synchronize on both sides, max over ranks): the side stream and the
+    #     gather of one step overlap the next step's kernels -- what a caller that keeps the GPU fed gets
     dt = time_steps(step, args.steps, args.warmup, dist, drain if use_dist else None)
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    total_samples = world * B * N * args.steps
-    value = total_samples / dt
 
-    extra = {}
+    extra = {'pipelined': {'ms_per_step': dt / args.steps * 1e3, 'value': world * B * N * args.steps / dt,
+                           'note': f'wall clock of {args.steps} back-to-back steps (barrier + synchronize on both sides, max '
+                                   'over ranks); steps overlap at their edges'},
+             'synchronised_wall_ms_per_step': wall_sync / args.steps * 1e3}
+    if use_dist:
+        extra['backend'] = backend
+        if share_gpu:
+            extra['shared_gpu'] = True           # a dry run of the multi-rank flow, not a multi-GPU measurement
     if use_dist:
         # the collective by itself (synchronous), max over ranks: what the overlap has to hide
         audio = call(pg, feats)
@@ -482,8 +560,7 @@ def main():
                               'note': 'synchronous all_gather_into_tensor alone (median of 5, max over ranks); in the timed '
                                       'steps it runs on RCCL\'s stream under the next step\'s kernels'}
     if rank == 0:
-        # per-step device times of the headline call (HIP events on the launch stream; no collective)
-        extra['step_ms'] = ms_summary(event_times(lambda: call(pg, feats), 20, warmup=3))
+        extra['step_ms'] = ms_summary(step_ts)   # the timed steps themselves (this rank)
     if rank == 0 and not args.no_extras:
         other = 'audio_only_call' if want_dict else 'outputs_dict_call'
         fn = (lambda: pg(feats)) if want_dict else (lambda: pg(feats, return_outputs_dict=True))
@@ -532,6 +609,19 @@ def main():
         extra['native_group_call'] = {'workload': 'the headline batch and call form through ddspp_group_run',
                                       'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
         del ngb
+        # the other shipped shapes, driver-run: BASELINE config 5's per-GPU share and the dafx22 model
+        for key, (b_, p_, h_, k_, s_, sr_, ir_s, note) in {
+                'c5_per_gpu_share': (32, 32, 128, 96, 1, 48000, 10.0, 'BASELINE config 5 per GPU (batch 256 / 8): 48 kHz, poly 32, 10 s IR'),
+                'dafx22_dims': (B, 16, 96, 64, 2, 16000, 1.5, 'configs/dafx22.gin dims: 16 kHz, two sub-strings, 1.5 s IR')}.items():
+            u_ = sr_ // 250
+            fx, _ = make_features(b_, p_, T, h_, k_, s_, int(ir_s * sr_), device, seed=41)
+            pgx = build_group(dp, p_, sr_)
+            ts = event_times(lambda: call(pgx, fx), 10, warmup=3)
+            extra[key] = {'workload': f'{note}; batch={b_} x {args.seconds:g} s, H={h_}, K={k_}, S={s_}',
+                          'ms_per_step': ms_summary(ts), 'value': b_ * T * u_ / (float(np.median(ts)) * 1e-3),
+                          'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+            del fx, pgx
+            torch.cuda.empty_cache()
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
@@ -552,11 +642,12 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    stale = [r.get('counters_stale') for r in (roof, roof_step) if r]
     if rank == 0:
         line = {
             'metric': 'audio samples/sec synthesized (24 kHz, poly=16), full chain; real-time factor in rtf',
             'value': value, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': med * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rtf': value / sr,
             'config': {'workload': ('BASELINE config 3 per GPU: ' if (B, P, H, K, S, sr, args.seconds, L) ==
@@ -568,8 +659,9 @@ def main():
                        'call_form': 'processor_group(features, return_outputs_dict=True) (piano_model.py:160)'
                                     if want_dict else 'processor_group(features)',
                        'global_batch': world * B, 'segment_samples': N, 'parallelism': f'batch-shard x{world}'
-                                                                                       + (' + RCCL all-gather overlapped with the next step' if world > 1 else '')},
+                                                                                       + (' + one all-gather of the audio per step (inside the timed step; overlapped with the next step in `pipelined`)' if world > 1 else '')},
             'roofline': roof, 'roofline_step': roof_step, 'cpu_baseline': cpu,
+            'counters_stale': (any(bool(x) for x in stale) if stale else None),
         }
         line.update(extra)
     if dist is not None:

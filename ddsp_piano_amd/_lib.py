@@ -37,6 +37,17 @@ def _hipcc():
     raise RuntimeError('hipcc not found: cannot build libddspp.so')
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers: profiles/*.json that hold counter values of
+    the kernels carry it, so that bench.py can tell when they describe another build (counters_stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(_CSRC, name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def _needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -140,6 +151,7 @@ SIGNATURES = {
                                        c_void_p]),
     'ddspp_noise_bands': (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     'ddspp_uniform_noise': (c_int, [c_void_p, c_size_t, c_uint64, c_uint64, c_void_p]),
+    'ddspp_uniform_noise_rows': (c_int, [c_void_p, c_int, c_size_t, c_uint64, c_uint64, c_uint64, c_void_p]),
     'ddspp_fft_size': (c_int, [c_int, c_int]),
     'ddspp_fftconv_plan_create': (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     'ddspp_fftconv_plan_destroy': (c_int, [c_void_p]),

@@ -270,6 +270,27 @@ def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
     return (pos - torch.floor(pos)).contiguous()
 
 
+def linear_exact_frames(upsampling):
+    """Number of leading frames over which a streamed piece can reproduce the one-call render's bilinear resize: the
+    reference forms float32(n) * float32(1 / U) at the absolute sample n and takes floor / fractional part.  Far enough
+    into a signal that product rounds ACROSS an integer (the last sample of frame k - 1 lands on k, or the first of
+    frame k below it), the one-call render then interpolates between other frames than a piece -- which indexes its
+    frames locally -- can know.  Returns the first frame index at which that happens (2^24 / U if never below 2^24
+    samples, where float32(n) itself stops being exact): 131 072 frames (8.7 min) at U = 96.  streaming.py refuses to
+    go past it."""
+    u = int(upsampling)
+
+    def build():
+        scale = F32(1.0) / F32(u)
+        kmax = (1 << 24) // u
+        k = np.arange(1, kmax, dtype=np.int64)
+        first = np.floor((k * u).astype(F32) * scale) != k                 # first sample of frame k
+        last = np.floor((k * u - 1).astype(F32) * scale) != k - 1          # last sample of frame k - 1
+        bad = np.nonzero(first | last)[0]
+        return int(k[bad[0]]) if bad.size else kmax
+    return _cached(('linexact', u), build)
+
+
 def hann_window(n, device):
     return _cached(('hann', int(n), str(device)),
                    lambda: torch.from_numpy(_hann_window_np(int(n))).to(device))
@@ -725,19 +746,53 @@ class _PlanCache:
         self._entries = {}          # key -> [handle, lock, pins]
         self._order = []
         self._lock = threading.Lock()
+        self._recorders = []        # lists that collect every entry handed out (CapturedGroup pins what a capture used)
         atexit.register(self.clear)
 
-    def get(self, key, create):
+    def get(self, key, create, pin=False):
+        """The entry [handle, lock, pins] of `key`.  pin=True: its pin count is raised under the cache lock, so no other
+        thread can evict it between this call and the caller's use; the caller releases it with pin(entry, -1)."""
         with self._lock:
             e = self._entries.get(key)
             if e is None:
                 e = self._entries[key] = [create(), threading.Lock(), 0]
                 self._order.append(key)
-                self._evict()
             else:
                 self._order.remove(key)
                 self._order.append(key)
+            if pin:
+                e[2] += 1
+            for rec in self._recorders:
+                if not any(x is e for x in rec):
+                    rec.append(e)
+            self._evict()
             return e
+
+    def record(self):
+        """Context manager: the entries handed out while it is open, each pinned once (a captured HIP graph replays the
+        executions of these plans without ever calling get() again, so they must outlive the cache's LRU policy).
+        Release with unpin_all(entries)."""
+        cache = self
+
+        class _Rec:
+            def __enter__(self):
+                self.entries = []
+                with cache._lock:
+                    cache._recorders.append(self.entries)
+                return self.entries
+
+            def __exit__(self, *exc):
+                with cache._lock:
+                    cache._recorders[:] = [r for r in cache._recorders if r is not self.entries]
+                    for e in self.entries:
+                        e[2] += 1
+        return _Rec()
+
+    def unpin_all(self, entries):
+        with self._lock:
+            for e in entries:
+                e[2] -= 1
+            self._evict()
 
     def _evict(self):
         lib = None
@@ -790,7 +845,7 @@ def _fftconv_plan(b, b_ir, n, l, device, key_stream=None):
         with torch.cuda.device(device):
             _lib.check(_lib_().ddspp_fftconv_plan_create(b, b_ir, n, l, ctypes.byref(handle)))
         return handle
-    return _plan_cache.get(key, create)
+    return _plan_cache.get(key, create, pin=True)        # released by the caller once its work is enqueued
 
 
 def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False, add_dry=False):
@@ -808,10 +863,13 @@ def _fft_convolve_single(audio, ir, padding, delay_compensation, mask_dry=False,
     nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=audio.device)
     out = torch.empty((b, out_len), dtype=torch.float32, device=audio.device)
-    with entry[1]:
-        _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
-                                             _auto_delay(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
-                                             nbytes, _stream()))
+    try:
+        with entry[1]:
+            _lib.check(lib.ddspp_fftconv_execute(plan, _ptr(audio), n, _ptr(ir), _ptr(out), out_len,
+                                                 _auto_delay(delay_compensation), int(mask_dry), int(add_dry), _ptr(ws),
+                                                 nbytes, _stream()))
+    finally:
+        _plan_cache.pin(entry, -1)
     return out
 
 
@@ -825,8 +883,7 @@ def fft_convolve_prepare(batch, n_samples, ir, mask_dry=False, key_stream=None):
     lib = _lib_()
     nbytes = int(lib.ddspp_fftconv_workspace_bytes(plan))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=ir.device)
-    _plan_cache.pin(entry, +1)                       # stays alive until fft_convolve_finish
-    try:
+    try:                                             # the pin taken by _fftconv_plan is kept until fft_convolve_finish
         with entry[1]:
             _lib.check(lib.ddspp_fftconv_transform_ir(plan, _ptr(ir), int(mask_dry), _ptr(ws), nbytes, _stream()))
     except Exception:

@@ -188,6 +188,8 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     DDSPP_REQUIRE(workspace_bytes >= g->total, "group_run: workspace too small (%zu < %zu)", workspace_bytes, g->total);
     DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "group_run: workspace must be 256-byte aligned");
     DDSPP_REQUIRE(!g->plan == !reverb_ir, "group_run: reverb_ir %s", g->plan ? "is missing" : "given, but the group has no reverb");
+    DDSPP_REQUIRE(!(outputs && outputs->harmonic_shifts_last && g->c.n_frames < 4),
+                  "group_run: harmonic_shifts_last needs at least 4 frames");
     const ddspp_group_config& c = g->c;
     const int B = c.n_segments, P = c.n_voices, T = c.n_frames, H = c.n_harmonics, S = c.n_substrings, K = c.n_bands,
               U = c.upsampling, R = g->R, N = g->N, vm = c.voice_major ? 1 : 0, vpr = g->vpr;
@@ -205,21 +207,33 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
 
     // ---- noise branch (filtered_noise_synth.py:27-42): draw, design + time-varying FIR, voices summed per row; and the
     //      reverb's impulse responses -> spectra (an input: ready long before the dry mix) -- on the side stream if any ------
+    // Every argument has been validated above: nothing below fails on its inputs.  Should a launch fail all the same
+    // after the fork, the side stream is joined before returning (leave()), so a stream capture stays well formed and
+    // the caller's next use of the workspace is ordered behind the side stream's work.
     hipStream_t zs = stream;
+    bool forked = false, joined = false;
+    auto leave = [&](int code) {
+        if (forked && !joined) {
+            joined = true;
+            if (hipEventRecord(g->ev_join, g->side) == hipSuccess) (void)hipStreamWaitEvent(stream, g->ev_join, 0);
+        }
+        return code;
+    };
     if (g->side) {
         DDSPP_HIP_CHECK(hipEventRecord(g->ev_fork, stream));
         DDSPP_HIP_CHECK(hipStreamWaitEvent(g->side, g->ev_fork, 0));
         zs = g->side;
+        forked = true;
     }
     if (g->plan && g->side) {
         rc = ddspp_fftconv_transform_ir(g->plan, reverb_ir, 1, ws + g->o_fft, g->fft_bytes, zs);
-        if (rc != DDSPP_OK) return rc;
+        if (rc != DDSPP_OK) return leave(rc);
     }
     const float* z = noise;
     if (!z) {
         float* zbuf = (float*)(ws + g->o_noise);
         rc = ddspp_uniform_noise(zbuf, ((size_t)R * N + 3) / 4 * 4, c.noise_seed, g->calls << 40, zs);
-        if (rc != DDSPP_OK) return rc;
+        if (rc != DDSPP_OK) return leave(rc);
         ++g->calls;
         z = zbuf;
     }
@@ -238,7 +252,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
                                           c.noise_threshold, c.noise_gain, zs);
         if (rc == DDSPP_OK) rc = ddspp_time_varying_fir(z, ir, zrows, R, N, T, g->Lw, c.delay_compensation, zs);
     }
-    if (rc != DDSPP_OK) return rc;
+    if (rc != DDSPP_OK) return leave(rc);
     if (g->side) DDSPP_HIP_CHECK(hipEventRecord(g->ev_join, g->side));
 
     // ---- get_controls of the additive processor over all rows (inharm_synth.py:167-219, :254-270) -------------------
@@ -247,26 +261,28 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
                                          (want && T >= 4) ? shifts_last : nullptr, aud, R, T, H, S, P, vm, c.sample_rate,
                                          c.min_frequency, c.scale_kind, c.exponent, c.max_value, c.threshold, c.gain,
                                          c.normalize_after_nyquist_cut, c.normalize_below_nyquist, stream);
-    if (rc != DDSPP_OK) return rc;
-    DDSPP_REQUIRE(!(want && outputs->harmonic_shifts_last && T < 4), "group_run: harmonic_shifts_last needs at least 4 frames");
+    if (rc != DDSPP_OK) return leave(rc);
 
     // ---- additive branch: the compacted oscillator bank (inharm_synth.py:272-293 -> :87-127 -> :49-84) ---------------
     float* add_last = want ? (outputs->additive_last ? outputs->additive_last : (float*)(ws + g->o_alast)) : nullptr;
     rc = ddspp_polyphonic_additive(f0_hz, amp_c, hd_c, nullptr, inharm_coef, aud, g->wlin, g->whann, nullptr, mix, add_last, B,
                                    P, T, S, H, U, c.sample_rate, 0, vm, ws + g->o_addws, g->addws_bytes, stream);
-    if (rc != DDSPP_OK) return rc;
+    if (rc != DDSPP_OK) return leave(rc);
 
     // ---- add chain (polyphonic_dag.py:28-37) -------------------------------------------------------------------------
-    if (g->side) DDSPP_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_join, 0));
+    if (g->side) {
+        DDSPP_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_join, 0));
+        joined = true;
+    }
     if (!want) {
         // voice sums leave the noise kernel segment major ([B, P / vpr, N]); per-voice rows keep the controls' order
         rc = ddspp_mix_voices(mix, 1, zrows, P / vpr, dry, B, N, N, vpr > 1 ? 0 : vm, stream);
-        if (rc != DDSPP_OK) return rc;
+        if (rc != DDSPP_OK) return leave(rc);
     } else if (P == 1) {
         // one voice: it is the last one.  dry = noise + additive (the first `add` node, two operands)
         if (zlast != zrows) DDSPP_HIP_CHECK(hipMemcpyAsync(zlast, zrows, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
         rc = ddspp_mix_voices(add_last, 1, zlast, 1, dry, B, N, N, 0, stream);
-        if (rc != DDSPP_OK) return rc;
+        if (rc != DDSPP_OK) return leave(rc);
     } else {
         const float* zr = zrows;
         int pz = P / vpr, zvm = 0;
@@ -288,7 +304,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         }
         float* prev = outputs->prev ? outputs->prev : (float*)(ws + g->o_prev);
         rc = ddspp_mix_last_voice(mix, 1, zr, pz, zlast, add_last, prev, dry, B, N, zvm, stream);
-        if (rc != DDSPP_OK) return rc;
+        if (rc != DDSPP_OK) return leave(rc);
     }
 
     // ---- the last voice's conditioned controls, as the re-used processors hold them ----------------------------------
@@ -307,7 +323,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
                 rc = ddspp_scale_bias(outputs->magnitudes_last, outputs->magnitudes_last, (size_t)B * T * K, c.noise_bias,
                                       c.noise_scale_kind, c.noise_exponent, c.noise_max_value, c.noise_threshold, c.noise_gain,
                                       stream);
-                if (rc != DDSPP_OK) return rc;
+                if (rc != DDSPP_OK) return leave(rc);
             }
         }
     }

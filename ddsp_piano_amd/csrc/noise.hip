@@ -729,6 +729,26 @@ __global__ void __launch_bounds__(256) uniform_noise_kernel(float* __restrict__ 
     }
 }
 
+// rows of a [R, n] tensor, row r drawn from counters offset + r * row_stride + i / 4: a (row, position)-keyed stream
+__global__ void __launch_bounds__(256) uniform_noise_rows_kernel(float* __restrict__ out, int R, size_t n4, uint64_t seed,
+                                                               uint64_t offset, uint64_t row_stride) {
+    const size_t total = (size_t)R * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t r = g / n4, i = g - r * n4;
+        const uint64_t ctr = offset + r * row_stride + i;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int rr = 0; rr < 10; ++rr) philox_round(c, k);
+        float4 v;
+        v.x = (float)(c[0] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        v.y = (float)(c[1] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        v.z = (float)(c[2] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        v.w = (float)(c[3] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        reinterpret_cast<float4*>(out)[g] = v;
+    }
+}
+
 static unsigned stream_grid(size_t total) {
     size_t blocks = (total + 255) / 256;
     const size_t cap = 256 * 16;
@@ -1016,6 +1036,20 @@ int ddspp_uniform_noise(float* out, size_t n, uint64_t seed, uint64_t offset, hi
     if (n == 0) return DDSPP_OK;
     hipLaunchKernelGGL(uniform_noise_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, stream, out, n / 4, seed,
                        offset);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The same generator for the rows of out[R, n] (n % 4 == 0), row r from the counters offset + r * row_stride + i / 4:
+// a stream keyed by (row, position), so that a piece of a longer signal draws the numbers of its absolute position
+// whichever call renders it (streaming.py; one launch for all rows).
+int ddspp_uniform_noise_rows(float* out, int R, size_t n, uint64_t seed, uint64_t offset, uint64_t row_stride,
+                             hipStream_t stream) {
+    DDSPP_REQUIRE(out, "uniform_noise_rows: null buffer");
+    DDSPP_REQUIRE(R >= 0 && n % 4 == 0, "uniform_noise_rows: n must be a multiple of 4");
+    if (n == 0 || R == 0) return DDSPP_OK;
+    hipLaunchKernelGGL(uniform_noise_rows_kernel, dim3(stream_grid((size_t)R * (n / 4))), dim3(256), 0, stream, out, R, n / 4,
+                       seed, offset, row_stride);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

@@ -85,13 +85,16 @@ def _irfft(spectrum, n):
         with torch.cuda.device(spectrum.device):
             _lib.check(_lib_().ddspp_irfft_plan_create(n, b, ctypes.byref(handle)))
         return handle
-    entry = _irfft_plans.get((n, b, str(spectrum.device)), create)
-    plan = entry[0]
-    nbytes = int(_lib_().ddspp_irfft_workspace_bytes(plan))
-    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=spectrum.device)
-    out = torch.empty((b, n), dtype=torch.float32, device=spectrum.device)
-    with entry[1]:
-        _lib.check(_lib_().ddspp_irfft_execute(plan, _ptr(spectrum), _ptr(out), _ptr(ws), nbytes, _stream()))
+    entry = _irfft_plans.get((n, b, str(spectrum.device)), create, pin=True)
+    try:
+        plan = entry[0]
+        nbytes = int(_lib_().ddspp_irfft_workspace_bytes(plan))
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=spectrum.device)
+        out = torch.empty((b, n), dtype=torch.float32, device=spectrum.device)
+        with entry[1]:
+            _lib.check(_lib_().ddspp_irfft_execute(plan, _ptr(spectrum), _ptr(out), _ptr(ws), nbytes, _stream()))
+    finally:
+        _irfft_plans.pin(entry, -1)
     return out
 
 

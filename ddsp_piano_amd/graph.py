@@ -50,6 +50,20 @@ class CapturedGroup:
         self._stream = torch.cuda.Stream(device=dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         self._noise = None
+        # Every rocFFT plan the warm-up and the capture touch is pinned in the library's plan caches for the life of this
+        # object: replay() re-executes them without going through the caches, whose LRU policy would otherwise destroy
+        # a captured plan (and free its twiddle / work buffers) once enough other shapes have been used.
+        from . import effects
+        self._plan_caches = (core._plan_cache, effects._irfft_plans)
+        recs = [c.record() for c in self._plan_caches]
+        self._pinned = [r.__enter__() for r in recs]
+        try:
+            self._capture(group, dev, warmup)
+        finally:
+            for r in recs:
+                r.__exit__(None, None, None)
+
+    def _capture(self, group, dev, warmup):
         with torch.cuda.stream(self._stream):
             probe = group(self._in, return_outputs_dict=False)                  # shapes; also builds tables and plans
             if self._noise_procs:
@@ -63,6 +77,13 @@ class CapturedGroup:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, stream=self._stream):
             self._out = self._run()
+
+    def __del__(self):
+        try:
+            for cache, entries in zip(getattr(self, '_plan_caches', ()), getattr(self, '_pinned', ())):
+                cache.unpin_all(entries)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _run(self):
         kw = {'noise': self._noise} if self._noise is not None else {}

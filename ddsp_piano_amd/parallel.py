@@ -42,6 +42,13 @@ def shard_features(features, world_size, rank, batch_axis=0, global_batch=None):
     return out
 
 
+class _Done:
+    """A finished collective (the host-staged gloo path is synchronous)."""
+
+    def wait(self):
+        return True
+
+
 def gather_audio(local_audio, out=None, group=None, async_op=False):
     """All-gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order).
 
@@ -52,6 +59,13 @@ def gather_audio(local_audio, out=None, group=None, async_op=False):
     if out is None:
         out = torch.empty((world * local_audio.shape[0],) + tuple(local_audio.shape[1:]),
                           dtype=local_audio.dtype, device=local_audio.device)
+    if local_audio.is_cuda and dist.get_backend(group) == 'gloo':
+        # gloo has no device all-gather: stage through the host.  Only met when several ranks share ONE GPU (RCCL refuses
+        # that), i.e. the multi-rank tests and bench.py's dry run on a single-GPU box; on the node the backend is RCCL.
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather(list(host.chunk(world, dim=0)), local_audio.cpu(), group=group)
+        out.copy_(host)
+        return (out, _Done()) if async_op else out
     try:
         work = dist.all_gather_into_tensor(out, local_audio, group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):

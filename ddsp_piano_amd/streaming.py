@@ -11,7 +11,9 @@ internally between two samples.  For this path that is exactly:
     every shipped sample rate); plus ONE frame of look-ahead, because frame t is interpolated towards frame t + 1;
     plus the piece's ABSOLUTE sample position: the reference's bilinear resize forms float32(n) * (T / N) and takes
     its fractional part as the interpolation weight, which rounds differently at n = 12000 and n = 1212000
-    (core.linear_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128;
+    (core.linear_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128.  That
+    only holds while the product does not round ACROSS a frame boundary: core.linear_exact_frames(U) frames (8.7 min
+    at 24 kHz), past which push() raises;
   * FilteredNoise: the time-varying FIR reaches Lw - 1 - delay samples back and `delay` samples forward: the piece is
     filtered with ceil((Lw - 1 - delay) / U) frames of context behind it and ceil(delay / U) frames ahead
     (``noise_reach``: one frame each way at 16 / 24 kHz, two at ENSTDkCl's 8 kHz with 64 bands) and cropped.  Noise
@@ -119,6 +121,11 @@ class StreamingSynthesizer:
         have = next(iter(self._buf.values())).shape[1]
         back, _ = self._reach()
         look = min(self._lookahead(), have - nb)     # fewer only at the end of the signal: nothing follows there
+        limit = core.linear_exact_frames(U)
+        if self.frame + nb + look > limit:
+            raise ValueError(f'streaming stops at frame {limit} ({limit * U} samples): past it float32(n) * (T / N) of the '
+                             'reference\'s bilinear resize rounds across a frame boundary and a piece can no longer equal '
+                             'the one-call render (core.linear_exact_frames); render such a file in one call')
         sl = slice(0, nb + look)
         amp, vm = self._rows(self.akeys[0], sl)
         hd, _ = self._rows(self.akeys[1], sl, vm)
@@ -177,9 +184,10 @@ class StreamingSynthesizer:
             return (z.transpose(0, 1) if vm else z).contiguous().reshape(R, n)
         seed = getattr(self.noise, 'seed', 0)
         pos = self.frame * self.U
+        if n % 4 or pos % 4:
+            raise ValueError('the library noise stream is addressed in blocks of 4 samples: the hop must be a multiple of 4')
         out = torch.empty((R, n), dtype=torch.float32, device=dev)
-        for r in range(R):
-            out[r] = core.uniform_noise((n,), seed=seed, offset=(r << 34) + pos // 4, device=dev)
+        _lib.check(_lib_().ddspp_uniform_noise_rows(_ptr(out), R, n, int(seed) & (2 ** 64 - 1), pos // 4, 1 << 34, _stream()))
         return out
 
     def _reverb(self, dry):

@@ -281,6 +281,10 @@ int ddspp_noise_bands(const float* amplitudes, const float* noise_bands, const i
 /* stand-in for the reference's unseeded tf.random.uniform([B, N], -1, 1)
  * (filtered_noise_synth.py:39-40): Philox4x32-10, counter = offset + i / 4, key = seed. */
 int ddspp_uniform_noise(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t stream);
+/* the same generator for out[R, n], row r from the counters offset + r * row_stride + i / 4: a stream keyed by
+ * (row, position) for piecewise rendering (a piece draws the numbers of its absolute position). */
+int ddspp_uniform_noise_rows(float* out, int R, size_t n, uint64_t seed, uint64_t offset, uint64_t row_stride,
+                             hipStream_t stream);
 
 /* ---- reverb ---------------------------------------------------------------------------------- */
 

@@ -88,3 +88,96 @@ def test_bench_distributed_branch_runs():
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])        # the JSON line must be the LAST line
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['steps'] == 2
+
+
+_WORKER2 = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ['DDSPP_ROOT'], 'tests')); sys.path.insert(0, os.environ['DDSPP_ROOT'])
+from util import synth_controls, synth_ir
+import ddsp_piano_amd as dp
+from ddsp_piano_amd import parallel, streaming
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+sr, P, H, K, L = 24000, 3, 64, 96, 3000
+KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'], noise_controls=['magnitudes'],
+            reverb_controls=['reverb_ir'])
+def procs():
+    return (dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+            dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr, seed=3), dp.Reverb(name='reverb'))
+def feats_of(B, T, seed):
+    rng = np.random.default_rng(seed)                       # the same on every rank
+    f = {}
+    for i in range(P):
+        for k, v in synth_controls(rng, B, T, H, S=1, K=K, silent_frac=0.0).items():
+            f[f'{k}_{i}'] = torch.as_tensor(v, device='cuda')
+    f['reverb_ir'] = torch.as_tensor(synth_ir(rng, B, L), device='cuda')
+    noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * 96]).astype(np.float32), device='cuda')
+    return f, noise
+res = {}
+for name, B in (('even', 4), ('uneven', 3)):
+    feats, noise = feats_of(B, 40, 5 + B)
+    pg = dp.ProcessorGroup(dp.polyphonic_dag(*procs(), n_synths=P, **KEYS))
+    ref = pg(feats, noise=noise)
+    class Local:                                            # the shard's rows of the explicit noise go with its controls
+        def __call__(self, f):
+            lo, hi = parallel.shard_range(B, world, rank)
+            return dp.ProcessorGroup(dp.polyphonic_dag(*procs(), n_synths=P, **KEYS))(f, noise=noise[lo:hi])
+    out = parallel.synthesize_sharded(Local(), feats)
+    res[name] = [list(out.shape) == list(ref.shape), float((out - ref).abs().max() / ref.abs().max())]
+# one file, time sharded: 5 blocks of 125 frames -> 3 + 2 (the 25 remainder frames go to the last rank)
+feats, noise = feats_of(1, 650, 9)
+ref = dp.ProcessorGroup(dp.polyphonic_dag(*procs(), n_synths=P, **KEYS))(feats, noise=noise)
+make = lambda: streaming.StreamingSynthesizer(*procs(), n_synths=P)
+out = parallel.synthesize_time_sharded(make, feats, noise=noise)
+res['time'] = [list(out.shape) == list(ref.shape), float((out - ref).abs().max() / ref.abs().max())]
+res['ranges'] = [list(parallel.time_shard_range(650, world, r, 125)) for r in range(world)]
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(res))
+"""
+
+
+def test_two_ranks_on_one_gpu_shard_batch_and_time():
+    """multi-rank evidence that runs on a 1-GPU box.  Two processes share cuda:0 (gloo: RCCL refuses
+    two ranks on one device; the gather is staged through the host) and drive the REAL ProcessorGroup through
+    parallel.synthesize_sharded -- even and uneven batch -- and parallel.synthesize_time_sharded; every rank must hold
+    the unsharded render."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = _env(port)
+        env.update({'RANK': str(rank), 'WORLD_SIZE': '2', 'LOCAL_RANK': str(rank)})
+        procs.append(subprocess.Popen([sys.executable, '-c', _WORKER2], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    for so, _ in outs:
+        res = json.loads([l for l in so.splitlines() if l.startswith('RESULT ')][-1][len('RESULT '):])
+        assert res["ranges"] == [[0, 375], [375, 650]]
+        for k in ('even', 'uneven'):
+            assert res[k][0] and res[k][1] < 1e-6, (k, res[k])            # rows do not depend on the batch they are in
+        assert res['time'][0] and res['time'][1] < 3e-5, res['time']     # FFT sizes / summation order differ, nothing else
+
+
+def test_bench_two_rank_launcher_flow_on_one_gpu():
+    """`python bench.py --gpus 2` end to end: the script spawns its two ranks (torch.distributed.run), they shard, gather and
+    rank 0 prints ONE JSON line.  On this one-GPU box the ranks share the device and the backend is gloo -- the line says
+    so; with 2+ GPUs and no overrides the same flow runs over RCCL."""
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'DDSPP_BENCH_SHARE_GPU': '1', 'DDSPP_BENCH_BACKEND': 'gloo'})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '4', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['shared_gpu'] is True and line['backend'] == 'gloo'
+    assert line['config']['global_batch'] == 8 and line['value'] > 0 and line['steps'] == 3
+    assert line['allgather']['bytes_received_per_rank'] == 4 * 72000 * 4

@@ -251,6 +251,9 @@ def test_bench_launcher_logic(monkeypatch):
     assert cmd[-4:] == ['--gpus', '8', '--steps', '3'] and '127.0.0.1' in cmd
     args = bench.parse(['--gpus', '2', '--no-single-stream'])
     assert args.no_extras and args.call_form == 'outputs_dict'
+    # the dry run of the multi-rank flow on a box with fewer GPUs is explicit (and marked in the JSON line)
+    cmd = bench.launcher_command(2, {'DDSPP_BENCH_SHARE_GPU': '1'}, ['--gpus', '2'], 1)
+    assert cmd is not None and '--nproc-per-node=2' in cmd
 
 
 def test_plan_cache_is_bounded_and_respects_pins(monkeypatch):
@@ -276,3 +279,51 @@ def test_plan_cache_is_bounded_and_respects_pins(monkeypatch):
     assert len(cache) == 0 and set(destroyed) == {'A', 'B', 'C', 'D'}
     monkeypatch.setattr(core, '_lib_', lambda: (_ for _ in ()).throw(RuntimeError('gone')))
     cache.clear()                                   # no exception at interpreter exit
+
+
+def test_plan_cache_pins_what_a_capture_recorded():
+    """a captured HIP graph replays rocFFT executions without calling the plan cache again, so the plans it
+    used must not be LRU-evicted; get(pin=True) closes the window between look-up and use."""
+    from ddsp_piano_amd import core
+    cache = core._PlanCache('ddspp_irfft_plan_destroy', maxsize=2)      # handles are NULL: destroy is a no-op
+    created = []
+
+    def make(tag):
+        def create():
+            created.append(tag)
+            return None
+        return create
+    with cache.record() as used:
+        e1 = cache.get('k1', make('k1'))
+    assert used == [e1] and e1[2] == 1                                  # pinned once by the recorder
+    for k in ('k2', 'k3', 'k4'):
+        cache.get(k, make(k))
+    assert set(cache._entries) == {'k1', 'k4'}                          # k1 stays although it is the oldest
+    cache.unpin_all(used)
+    cache.get('k5', make('k5'))
+    assert set(cache._entries) == {'k4', 'k5'}
+    e = cache.get('k6', make('k6'), pin=True)
+    assert e[2] == 1
+    cache.get('k7', make('k7'))
+    cache.get('k8', make('k8'))
+    assert set(cache._entries) == {'k6', 'k8'}                          # in use: not evictable
+    cache.pin(e, -1)
+    cache.get('k9', make('k9'))
+    assert set(cache._entries) == {'k8', 'k9'}
+    assert created == ['k1', 'k2', 'k3', 'k4', 'k5', 'k6', 'k7', 'k8', 'k9']
+
+
+def test_linear_exact_frames_bound():
+    """past this many frames float32(n) * float32(1 / U) rounds across a frame boundary; streaming refuses."""
+    import numpy as np
+    from ddsp_piano_amd import core
+    f = core.linear_exact_frames(96)
+    assert 2 ** 17 <= f <= 2 ** 17 + 8
+    scale = np.float32(1.0) / np.float32(96)
+    k = np.arange(1, f, dtype=np.int64)
+    assert (np.floor((k * 96).astype(np.float32) * scale) == k).all()
+    assert (np.floor((k * 96 - 1).astype(np.float32) * scale) == k - 1).all()
+    bad_first = np.floor(np.float32(f * 96) * scale) != f
+    bad_last = np.floor(np.float32(f * 96 - 1) * scale) != f - 1
+    assert bad_first or bad_last
+    assert core.linear_exact_frames(32) > core.linear_exact_frames(96) >= core.linear_exact_frames(192)

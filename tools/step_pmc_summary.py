@@ -74,7 +74,10 @@ def main(out):
     if tot:
         import json
         trans = sum(ctr[k].get('SQ_INSTS_VALU_TRANS_F32', 0.0) for k in add_kernels)
-        json.dump({'valu_wave_instructions_per_call': tot, 'valu_trans_wave_instructions_per_call': trans,
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from ddsp_piano_amd import _lib
+        json.dump({'csrc_hash': _lib.source_hash(),
+                   'valu_wave_instructions_per_call': tot, 'valu_trans_wave_instructions_per_call': trans,
                    'kernels': {k: ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels},
                    'source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_TRANS_F32 over bench.py --steps 3 --warmup 1 (tools/step_pmc.sh), '
                              'per-launch averages of the kernels of ddspp_polyphonic_additive at BASELINE config 3'},
