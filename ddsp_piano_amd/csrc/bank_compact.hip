@@ -25,62 +25,33 @@ namespace {
 
 constexpr float INV_P = 0x1.45f306p-3f;      // RN(1 / (2 pi))
 
-// One wavefront per workgroup: slots past the audible set exit at once and give their place to the next workgroup.
+// What a wavefront slot knows before it starts: which (segment, span) it works for, where its region of the packed
+// oscillator list lies, and the first oscillator it carries.
+struct SlotCtx {
+    int lane, row, span, cw_all;
+    int n_begin, n_end;
+    int qlo, qhi, total, first;       // sub-rows of the region, audible oscillators in it, first oscillator of this slot
+};
+
+// The walk of one slot with VPL oscillators per lane (64 VPL oscillators from `first`).  A slot of the VPL = 2 kernel
+// that has 64 or fewer oscillators left -- the last slot of a segment half the time, and always the slot(s) of the
+// last voice when the caller wants that voice's stem on its own -- runs the VPL = 1 body: half the instructions.
 template <int VPL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-bank_compact_kernel(const OscParams p) {
-    extern __shared__ float lds_dyn[];
-    float* tile = lds_dyn;                                   // [TILE][TSTRIDE]
-    const int lane = threadIdx.x & 63;
-    // workgroup index = slot major, (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so
-    // every XCD gets the same mix of busy (low slots) and idle workgroups and the busy ones are dispatched first
-    const int nbs = p.R * p.spans;
-    const int cw_all = blockIdx.x / nbs;
-    const int bs = blockIdx.x - cw_all * nbs;
-    const int row = bs / p.spans;                            // segment b
-    const int span = bs - row * p.spans;
-    const int c0 = span * p.cps, c1 = min(c0 + p.cps, p.nchunks);
+__device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const SlotCtx& c) {
+    const int lane = c.lane, row = c.row, span = c.span, cw_all = c.cw_all;
+    const int n_begin = c.n_begin, n_end = c.n_end, qlo = c.qlo, qhi = c.qhi, total = c.total;
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S;
     typedef const __attribute__((address_space(4))) float* cfloat_p;     // wave-uniform tables -> scalar loads
     const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
     const cfloat_p whann_c = (cfloat_p)(uintptr_t)p.whann;
-    const int n_begin = c0 * DDSPP_CHUNK, n_end = min(c1 * DDSPP_CHUNK, N);
     const float nyq = p.nyq, sr = p.sr, rsr = p.rsr;
-
-    // ---- which oscillators this slot carries ------------------------------------------------------------------
-    // The audible oscillators of the segment's (voice, sub-string) rows are packed back to back: sub-row q
-    // contributes its first nk harmonics.  Region A = voices [0, P - split_last), region B = the last voice.
-    const int Q = p.P * S, Qa = (p.P - p.split_last) * S;
-    const bool in_b = cw_all >= p.wmax_a;
-    const int cw = in_b ? cw_all - p.wmax_a : cw_all;
-    const int len = lane < Q ? p.nk[((size_t)row * p.spans + span) * p.P + lane / S] : 0;
-    int incl = len;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    const int total_a = Qa > 0 ? __shfl(incl, Qa - 1) : 0;
-    const int total_b = __shfl(incl, 63) - total_a;
-    if (cw_all == 0 && lane == 0) {
-        int* wc = p.wcount + ((size_t)row * p.spans + span) * 2;
-        wc[0] = (total_a + 64 * VPL - 1) / (64 * VPL);
-        wc[1] = (total_b + 64 * VPL - 1) / (64 * VPL);
-    }
-    const int total = in_b ? total_b : total_a;
-    if (64 * VPL * cw >= total) return;                      // nothing audible left for this slot
-    const int qlo = in_b ? Qa : 0, qhi = in_b ? Q : Qa, base = in_b ? total_a : 0;
-    int* offs = reinterpret_cast<int*>(tile);                // exclusive offsets of the sub-rows, via LDS
-    offs[lane] = incl - len - base;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int* offs = reinterpret_cast<const int*>(tile);    // exclusive offsets of the sub-rows (written by the kernel)
     int vk[VPL], vs[VPL], lrow[VPL], vidx[VPL];
     bool valid[VPL];
     float kmul[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        const int g = 64 * VPL * cw + lane + 64 * j;
+        const int g = c.first + lane + 64 * j;
         const int gc = min(g, total - 1);
         int q = qlo;                                         // last sub-row of the region whose offset is <= gc
 #pragma unroll
@@ -131,9 +102,12 @@ bank_compact_kernel(const OscParams p) {
             q_hd[j] = p.hd[fr * H + vk[j]];
         }
     };
+    float r_f0[VPL], r_sh[VPL];                    // the raw values x1 was formed from (held-note test at a frame boundary)
     auto frame_finish = [&](float* xf, float* xa) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
+            r_f0[j] = q_f0[j];
+            r_sh[j] = q_sh[j];
             float f = q_f0[j] * kmul[j];
             if (has_shifts) f = f * (1.0f + q_sh[j]);
             else if (from_inh) f = f * (1.0f + shift_from_inharm(q_sh[j], kmul[j]));     // get_inharmonic_freq, per lane and frame
@@ -366,16 +340,92 @@ bank_compact_kernel(const OscParams p) {
     if (r == U) {
         r = 0;
         ++t;
+        // A held note: the frame pair before was constant (x0 == x1 in every lane) and the next frame's raw f0_hz and
+        // inharm_coef (or shifts) are the very same numbers -> the new pair is the old one.  Only the amplitudes move:
+        // no per-lane square root (shift_from_inharm), no classification, om_c / fast / need_mask stay.
+        bool same = const_freq;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-            x0[j] = x1[j];
-            a0[j] = a1[j];
+        for (int j = 0; j < VPL; ++j) same = same && (q_f0[j] == r_f0[j]) && (q_sh[j] == r_sh[j]);
+        if (__all(same) && p.held_skip) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                a0[j] = a1[j];
+                const float a = q_amp[j] * q_hd[j];
+                a1[j] = valid[j] ? a : 0.0f;
+                const bool gone = x0[j] >= nyq;
+                am0[j] = gone ? 0.0f : a0[j];
+                da[j] = gone ? 0.0f : a1[j] - a0[j];
+            }
+            frame_request(min(t + 2, T - 1));
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                x0[j] = x1[j];
+                a0[j] = a1[j];
+            }
+            frame_finish(x1, a1);                    // raw values requested one frame ago
+            frame_request(min(t + 2, T - 1));
+            classify_frame();
         }
-        frame_finish(x1, a1);                        // raw values requested one frame ago
-        frame_request(min(t + 2, T - 1));
-        classify_frame();
     }
     }
+}
+
+// One wavefront per workgroup: slots past the audible set exit at once and give their place to the next workgroup.
+template <int VPL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bank_compact_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
+    float* tile = lds_dyn;                                   // [TILE][TSTRIDE]
+    SlotCtx c;
+    c.lane = threadIdx.x & 63;
+    // workgroup index = slot major, (segment, span) minor: consecutive workgroups go round-robin to the 8 XCDs, so
+    // every XCD gets the same mix of busy (low slots) and idle workgroups and the busy ones are dispatched first
+    const int nbs = p.R * p.spans;
+    c.cw_all = blockIdx.x / nbs;
+    const int bs = blockIdx.x - c.cw_all * nbs;
+    c.row = bs / p.spans;                                    // segment b
+    c.span = bs - c.row * p.spans;
+    const int c0 = c.span * p.cps, c1 = min(c0 + p.cps, p.nchunks);
+    c.n_begin = c0 * DDSPP_CHUNK;
+    c.n_end = min(c1 * DDSPP_CHUNK, p.N);
+    const int lane = c.lane, S = p.S;
+
+    // ---- which oscillators this slot carries ------------------------------------------------------------------
+    // The audible oscillators of the segment's (voice, sub-string) rows are packed back to back: sub-row q
+    // contributes its first nk harmonics.  Region A = voices [0, P - split_last), region B = the last voice.
+    const int Q = p.P * S, Qa = (p.P - p.split_last) * S;
+    const bool in_b = c.cw_all >= p.wmax_a;
+    const int cw = in_b ? c.cw_all - p.wmax_a : c.cw_all;
+    const int len = lane < Q ? p.nk[((size_t)c.row * p.spans + c.span) * p.P + lane / S] : 0;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int total_a = Qa > 0 ? __shfl(incl, Qa - 1) : 0;
+    const int total_b = __shfl(incl, 63) - total_a;
+    if (c.cw_all == 0 && lane == 0) {
+        int* wc = p.wcount + ((size_t)c.row * p.spans + c.span) * 2;
+        wc[0] = (total_a + 64 * VPL - 1) / (64 * VPL);
+        wc[1] = (total_b + 64 * VPL - 1) / (64 * VPL);
+    }
+    c.total = in_b ? total_b : total_a;
+    c.first = 64 * VPL * cw;
+    if (c.first >= c.total) return;                          // nothing audible left for this slot
+    c.qlo = in_b ? Qa : 0;
+    c.qhi = in_b ? Q : Qa;
+    const int base = in_b ? total_a : 0;
+    int* offs = reinterpret_cast<int*>(tile);                // exclusive offsets of the sub-rows, via LDS
+    offs[lane] = incl - len - base;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
+        bank_slot<2>(p, tile, c);
+    else
+        bank_slot<1>(p, tile, c);
 }
 
 // audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic); with split_last the last

@@ -36,6 +36,8 @@ struct OscParams {
     // compacted bank (bank_compact.hip): slots [0, wmax_a) carry the audible oscillators of voices [0, P - split_last),
     // slots [wmax_a, wmax) those of the last voice (split_last = 1: the caller wants that voice's stem on its own)
     int split_last, wmax_a;
+    int half_slots;                    // a 128-oscillator slot with <= 64 oscillators left runs the 64-oscillator body (DDSPP_OSC_HALF_SLOTS)
+    int held_skip;                     // frame boundaries of held notes skip the frequency / classification work (DDSPP_OSC_HELD_SKIP)
     float* __restrict__ out_last;      // [B, N] the last voice's stem (split_last = 1), `out` then holds the other voices' sum
     // streaming: the float32 running sum of chunk end phases (ddsp.core.angular_cumsum's cumsum over chunks) each
     // oscillator starts from, [rows, V]; null = 0 (a signal that starts here)

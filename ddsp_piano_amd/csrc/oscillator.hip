@@ -1471,6 +1471,8 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     //    exit at once (cheap: slot-major workgroup order)
     p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = wmax; p.vmajor = voice_major ? 1 : 0;
     p.split_last = split_last; p.wmax_a = wmax_a;
+    p.half_slots = env_int("DDSPP_OSC_HALF_SLOTS", 1);
+    p.held_skip = env_int("DDSPP_OSC_HELD_SKIP", 1);
     p.nk = nk; p.wcount = wcount; p.out = partial;
     launch_bank_compact(p, vpl_c, stream);
     // 4. slots -> audio (with audio_last: voices [0, P - 1) -> audio, the last voice -> audio_last)

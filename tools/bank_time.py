@@ -22,11 +22,14 @@ kw = {'headline': {}, 'moving': dict(vibrato=0.002),
 _, base = bench.make_features(B, P, T, H, K, S, L, dev, seed=20240, **kw)
 R, N = B * P, T * 96
 add = dp.MultiInharmonic(sample_rate=sr, inference=True)
+from_inh = os.environ.get('FROM_SHIFTS') != '1'          # the batched group's route: shifts formed in the kernels from inharm_coef
 ctl = add._controls(base['amplitudes'].reshape(R, T, 1), base['harmonic_distribution'].reshape(R, T, H),
-                    base['inharm_coef'].reshape(R, T, 1), base['f0_hz'].reshape(R, T, S), want_counts=True)
+                    base['inharm_coef'].reshape(R, T, 1), base['f0_hz'].reshape(R, T, S), want_counts=True,
+                    want_shifts=not from_inh)
 split = os.environ.get('SPLIT_LAST') == '1'
 fn = lambda: core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],  # noqa: E731
-                                      ctl['harmonic_shifts'], B, N, sr, audible=ctl['_audible'], split_last=split)
+                                      None if from_inh else ctl['harmonic_shifts'], B, N, sr, audible=ctl['_audible'],
+                                      inharm_coef=ctl['_inharm_coef'].reshape(R, T) if from_inh else None, split_last=split)
 ts = bench.event_times(fn, reps, warmup=3)
 print(f'{case} ablate={os.environ.get("DDSPP_BANK_ABLATE", "0")} split={int(split)}: polyphonic_additive '
       f'median {np.median(ts):.3f} ms min {np.min(ts):.3f} ms')
