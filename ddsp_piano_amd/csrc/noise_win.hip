@@ -276,9 +276,12 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
     }
     __syncthreads();
     float vsum[NPASS][OPL];
+    const int tstride = TRACE ? max(dbg >> 8, 1) : 1;            // TRACE: every tstride-th workgroup is recorded
     auto mark = [&](int unit, int k) {
-        if (TRACE && (int)blockIdx.x < WIN_TRACE_WGS && unit - u_begin < WIN_TRACE_UNITS && lane == 0)
-            trace[(((size_t)blockIdx.x * WIN_TRACE_UNITS + (unit - u_begin)) * 4 + wib) * WIN_TRACE_MARKS + k] = clock64();
+        if (TRACE && (int)blockIdx.x % tstride == 0 && (int)blockIdx.x / tstride < WIN_TRACE_WGS &&
+            unit - u_begin < WIN_TRACE_UNITS && lane == 0)
+            trace[(((size_t)(blockIdx.x / tstride) * WIN_TRACE_UNITS + (unit - u_begin)) * 4 + wib) * WIN_TRACE_MARKS + k] =
+                wall_clock64();
     };
     for (int unit = u_begin; unit < u_end; ++unit) {
         const int task = unit / vq, iv = unit - task * vq;
@@ -287,6 +290,7 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
         mark(unit, 0);
         // ---- 1. E / O blocks on the matrix cores; tap weights -> frame images (lane holds E, O of the frames
         // 4 kq .. 4 kq + 3 of the tile at column 16 jt + col)
+        if (dbg & 4) __builtin_amdgcn_s_setprio(3);
         if (designer && !(dbg & 2)) {
             load_taps();
             for (int t = tg; t < D / 16; t += TW) {
@@ -315,6 +319,7 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
         __syncthreads();
         mark(unit, 2);
         fetch_m(unit + 1);               // in flight during the walk (the design alone is too short to hide the latency)
+        if (dbg & 4) __builtin_amdgcn_s_setprio(0);
         // ---- 2. the walk: NPASS passes of 8 phases
         const int orow = task / g.wpr;
         const bool lastv = out_last != nullptr && iv == vq - 1 && (orow % pq) == pq - 1;
@@ -354,6 +359,7 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
             }
         }
         mark(unit, 3);
+        if (dbg & 4) __builtin_amdgcn_s_setprio(3);
         store_m();                       // M has been free since the design
         mark(unit, 4);
         __syncthreads();                 // G and Xs are free; M holds the next unit's magnitudes
@@ -479,7 +485,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
                      hipStream_t stream) {
     const long long tasks = (long long)(R / vq) * g.wpr;
     DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
-    const size_t lds = win_lds_bytes(g, K);
+    const size_t lds = win_lds_bytes(g, K) + (size_t)ddspp_option("DDSPP_WIN_LDS_PAD", 0);     // pad: fewer workgroups per CU (A/B)
     // About eight (window, voice) units per workgroup: the set-up (zeroed images, table fragments) is paid once per
     // eight, and there are several times more workgroups than the chip holds at once, so the last round of a launch
     // is spread over all CUs by the dispatcher instead of leaving a fixed assignment's stragglers.

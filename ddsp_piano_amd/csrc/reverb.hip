@@ -15,11 +15,17 @@
 #include <mutex>
 
 #include "ddspp_common.h"
+#include "reverb_part.h"
 
 namespace ddspp {
 
 struct FftConvPlan {
     int B, B_ir, N, L, nfft;
+    // partitioned overlap-save route (reverb_part.hip): used when the signal spans several 4096-sample blocks
+    bool part = false;
+    PartPlan pp{};
+    float2* tables = nullptr;            // device: W then U (the only device memory the plan owns: 64 KB)
+    size_t off_xspec = 0, off_hspec = 0;
     rocfft_plan fwd_audio = nullptr, fwd_ir = nullptr, inv = nullptr;
     rocfft_execution_info info = nullptr;
     size_t rocfft_work_bytes = 0;
@@ -149,9 +155,37 @@ int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan*
                   "Batch size of audio (%d) and impulse response (%d) must be the same.", B, B_ir);
     const int nfft = fast_fft_size(N, L);
     DDSPP_REQUIRE(nfft >= 8, "fftconv_plan_create: fft size out of range");
-    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     FftConvPlan* pl = new FftConvPlan();
     pl->B = B; pl->B_ir = B_ir; pl->N = N; pl->L = L; pl->nfft = nfft;
+    // Route: partitioned overlap-save with LDS-resident 8192-point transforms when the convolution spans at least a few
+    // blocks (DDSPP_FFT_PARTITIONED=0: always the whole-signal rocFFT route; =2: always partitioned).
+    const int part_opt = ddspp_option("DDSPP_FFT_PARTITIONED", 1);
+    if (part_opt == 2 || (part_opt == 1 && (long long)N + L >= 6 * REVERB_PART_BLOCK)) {
+        pl->part = true;
+        pl->pp.Pn = (L + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK;
+        pl->pp.nbx = (N + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK + 1;
+        const size_t tbytes = (size_t)2 * REVERB_PART_BLOCK * sizeof(float2);
+        float* host = new float[4 * REVERB_PART_BLOCK];
+        reverb_part_tables_host(host, host + 2 * REVERB_PART_BLOCK);
+        hipError_t e = hipMalloc((void**)&pl->tables, tbytes);
+        if (e == hipSuccess) e = hipMemcpy(pl->tables, host, tbytes, hipMemcpyHostToDevice);
+        delete[] host;
+        if (e != hipSuccess) {
+            ddspp_set_error("fftconv_plan_create: twiddle tables: %s", hipGetErrorString(e));
+            if (pl->tables) (void)hipFree(pl->tables);
+            delete pl;
+            return DDSPP_EHIP;
+        }
+        pl->pp.W = pl->tables;
+        pl->pp.U = pl->tables + REVERB_PART_BLOCK;
+        size_t off = 0;
+        pl->off_xspec = off; off = align256(off + (size_t)B * pl->pp.nbx * REVERB_PART_BLOCK * sizeof(float2));
+        pl->off_hspec = off; off = align256(off + (size_t)B_ir * pl->pp.Pn * REVERB_PART_BLOCK * sizeof(float2));
+        pl->total_bytes = off;
+        *out_plan = pl;
+        return DDSPP_OK;
+    }
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     const size_t lengths[1] = {(size_t)nfft};
     DDSPP_FFT_CHECK(rocfft_plan_create(&pl->fwd_audio, rocfft_placement_notinplace,
                                        rocfft_transform_type_real_forward, rocfft_precision_single, 1,
@@ -190,6 +224,7 @@ int ddspp_fftconv_plan_destroy(ddspp_fftconv_plan* pl) {
     if (pl->fwd_ir) rocfft_plan_destroy(pl->fwd_ir);
     if (pl->inv) rocfft_plan_destroy(pl->inv);
     if (pl->info) rocfft_execution_info_destroy(pl->info);
+    if (pl->tables) (void)hipFree(pl->tables);
     delete pl;
     return DDSPP_OK;
 }
@@ -213,6 +248,8 @@ int ddspp_fftconv_transform_ir(ddspp_fftconv_plan* pl, const float* ir, int mask
                   workspace_bytes, pl->total_bytes);
     DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "fftconv_transform_ir: workspace must be 256-byte aligned");
     char* ws = (char*)workspace;
+    if (pl->part)
+        return reverb_part_transform_ir(pl->pp, ir, pl->B_ir, pl->L, mask_dry, (float2*)(ws + pl->off_hspec), stream);
     float* ir_p = (float*)(ws + pl->off_ir_p);
     float2* ir_f = (float2*)(ws + pl->off_ir_f);
     const int nfft = pl->nfft;
@@ -244,6 +281,9 @@ int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* pl, const float* audio, i
                   pl->nfft);
     DDSPP_REQUIRE(!add_dry || out_len <= pl->N, "fftconv_execute: add_dry needs out_len <= n_samples");
     char* ws = (char*)workspace;
+    if (pl->part)
+        return reverb_part_execute(pl->pp, audio, audio_stride, pl->B, pl->B_ir, pl->N, (float2*)(ws + pl->off_xspec),
+                                   (const float2*)(ws + pl->off_hspec), out, out_len, start, add_dry, stream);
     float* audio_p = (float*)(ws + pl->off_audio_p);
     float2* audio_f = (float2*)(ws + pl->off_audio_f);
     float2* ir_f = (float2*)(ws + pl->off_ir_f);

@@ -469,6 +469,11 @@ class MultiAdd(Processor):
         return out
 
 
+def multi_add(signals):
+    """MultiAdd()(s0, s1, ...) (inharm_synth.py:296-309): python `sum` over the controls' values, left to right."""
+    return MultiAdd()(*signals)
+
+
 class Add(Processor):
     """ddsp.processors.Add (used by default_model.py:56-74)."""
 

@@ -68,6 +68,30 @@ def recalled_cases(B_):
     out['phase'] = B_.angular_cumsum(omega)                                                    # angular_cumsum
     out['exp_sigmoid'] = B_.exp_sigmoid(x)                                                     # exp_sigmoid constants
     out['noise_controls'] = B_.FilteredNoise(frame_rate=250, sample_rate=24000).get_controls(raw_mag)['magnitudes']
+    # ---- not switches, but recalled all the same: one run on a TF host settles these too
+    # framed fft_convolve whose audio length is NOT a multiple of the frame count (frame = ceil(1000 / 7) = 143, padded)
+    fc_audio = rng.uniform(-1, 1, [1, 1000]).astype(np.float32)
+    fc_ir = (rng.normal(0, 1, [1, 7, 33]) * np.hanning(33)[None, None, :]).astype(np.float32)
+    out.update(fc_audio=fc_audio, fc_ir=fc_ir)
+    out['fc_same'] = B_.fft_convolve(fc_audio, fc_ir, 'same', -1)
+    out['fc_valid_delay0'] = B_.fft_convolve(fc_audio, fc_ir, 'valid', 0)
+    # ddsp.effects.Reverb: the dry tap ir[:, 0] is masked, add_dry adds the input back (and add_dry=False does not)
+    rv_audio = rng.normal(0, 0.1, [2, 700]).astype(np.float32)
+    rv_ir = (rng.normal(0, 1, [2, 300]) * np.exp(-np.arange(300) / 60.0)[None, :]).astype(np.float32)
+    rv_ir[:, 0] = 5.0
+    out.update(rv_audio=rv_audio, rv_ir=rv_ir)
+    out['rv_wet_dry'] = B_.Reverb(add_dry=True).get_signal(audio=rv_audio, ir=rv_ir)
+    out['rv_wet'] = B_.Reverb(add_dry=False).get_signal(audio=rv_audio, ir=rv_ir)
+    # upsample_with_windows: both ends of a short sequence (the added end point, the cropped half windows)
+    up_in = rng.normal(0, 1, [1, 5, 3]).astype(np.float32)
+    out['up_in'] = up_in
+    out['up_window'] = B_.resample(up_in, 5 * 32, method='window')
+    # the reference's own exp_tanh (inharm_synth.py:13-17) and MultiAdd's summation order (inharm_synth.py:296-309)
+    out['exp_tanh'] = B_.exp_tanh(x)
+    ma = np.stack([np.full([1, 64], 3.0e7, np.float32), rng.normal(0, 1, [1, 64]).astype(np.float32),
+                   np.full([1, 64], -3.0e7, np.float32), rng.normal(0, 1, [1, 64]).astype(np.float32)])
+    out['ma_in'] = ma
+    out['ma_sum'] = B_.multi_add(list(ma))
     return {k: np.asarray(v, np.float32) for k, v in out.items()}
 
 
@@ -94,6 +118,13 @@ def report_recalled(cases):
     rows.append(('exp_sigmoid', str(O.RECALLED['exp_sigmoid']), err(O.exp_sigmoid(cases['x']), cases['exp_sigmoid'])))
     rows.append(('initial_bias', str(O.RECALLED['initial_bias']),
                  err(O.FilteredNoise().get_controls(cases['raw_mag'])['magnitudes'], cases['noise_controls'])))
+    rows.append(('framed fft_convolve, N % T != 0', "'same', auto delay", err(O.fft_convolve(cases['fc_audio'], cases['fc_ir'], 'same', -1), cases['fc_same'])))
+    rows.append(('framed fft_convolve, N % T != 0', "'valid', delay 0", err(O.fft_convolve(cases['fc_audio'], cases['fc_ir'], 'valid', 0), cases['fc_valid_delay0'])))
+    rows.append(('Reverb dry mask, add_dry=True', '-', err(O.Reverb(add_dry=True).get_signal(cases['rv_audio'], cases['rv_ir']), cases['rv_wet_dry'])))
+    rows.append(('Reverb dry mask, add_dry=False', '-', err(O.Reverb(add_dry=False).get_signal(cases['rv_audio'], cases['rv_ir']), cases['rv_wet'])))
+    rows.append(('upsample_with_windows end points', '-', err(O.resample(cases['up_in'], 5 * 32, method='window'), cases['up_window'])))
+    rows.append(('exp_tanh', '-', err(O.exp_tanh(cases['x']), cases['exp_tanh'])))
+    rows.append(('MultiAdd order', '((s0+s1)+s2)+s3', err(O.multi_add(list(cases['ma_in'])), cases['ma_sum'])))
     print('recalled detail                      oracle setting        rms error vs backend output')
     for name, rule, e in rows:
         print(f'{name:36s} {rule:20s} {e:.3e}' + ('   <-- matches' if e < 1e-5 else ''))

@@ -135,3 +135,16 @@ class TFBackend:
 
     def exp_sigmoid(self, x):
         return _to_np(self.ddsp.core.exp_sigmoid(self.tf.convert_to_tensor(x)))
+
+    def fft_convolve(self, audio, impulse_response, padding='same', delay_compensation=-1):
+        t = self.tf.convert_to_tensor
+        return _to_np(self.ddsp.core.fft_convolve(t(audio), t(impulse_response), padding=padding,
+                                                  delay_compensation=delay_compensation))
+
+    def exp_tanh(self, x):
+        return _to_np(self.inharm.exp_tanh(self.tf.convert_to_tensor(x)))
+
+    def multi_add(self, signals):
+        """The reference's MultiAdd processor on the given signals (inharm_synth.py:296-309)."""
+        t = self.tf.convert_to_tensor
+        return _to_np(self.inharm.MultiAdd()(*[t(np.asarray(s, np.float32)) for s in signals]))

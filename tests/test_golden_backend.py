@@ -68,7 +68,8 @@ def test_oracle_reproduces_small_config2():
 
 
 @pytest.mark.parametrize('detail', ['auto_delay', 'window_crop', 'resize', 'angular_cumsum', 'exp_sigmoid',
-                                    'initial_bias'])
+                                    'initial_bias', 'framed_fft_convolve', 'reverb_dry_mask', 'window_end_points',
+                                    'exp_tanh', 'multi_add_order'])
 def test_recalled_details_match(detail):
     """One single-operator case per recalled ddsp detail: with TF goldens a failure here names the detail whose
     default in oracle.RECALLED (and ddsp_piano_amd.core.RECALLED) is the wrong recollection."""
@@ -88,6 +89,22 @@ def test_recalled_details_match(detail):
         return
     elif detail == 'exp_sigmoid':
         got, want = O.exp_sigmoid(g['x']), g['exp_sigmoid']
+    elif detail == 'framed_fft_convolve':          # n_samples % n_frames != 0: frame = ceil(N / F), the last frame padded
+        got, want = O.fft_convolve(g['fc_audio'], g['fc_ir'], 'same', -1), g['fc_same']
+        assert got.shape == want.shape == (1, 1000)
+        v = O.fft_convolve(g['fc_audio'], g['fc_ir'], 'valid', 0)
+        assert v.shape == g['fc_valid_delay0'].shape and rms_err(v, g['fc_valid_delay0']) < tol
+    elif detail == 'reverb_dry_mask':
+        got, want = O.Reverb(add_dry=True).get_signal(g['rv_audio'], g['rv_ir']), g['rv_wet_dry']
+        wet = O.Reverb(add_dry=False).get_signal(g['rv_audio'], g['rv_ir'])
+        assert rms_err(wet, g['rv_wet']) < tol and rms_err(got - wet, g['rv_audio']) < 1e-6      # ir[:, 0] = 5 is masked
+    elif detail == 'window_end_points':
+        got, want = O.resample(g['up_in'], 5 * 32, method='window'), g['up_window']
+    elif detail == 'exp_tanh':
+        got, want = O.exp_tanh(g['x']), g['exp_tanh']
+    elif detail == 'multi_add_order':
+        got, want = O.multi_add(list(g['ma_in'])), g['ma_sum']
+        assert np.array_equal(got, want) or _tol() > 1e-5           # ((s0 + s1) + s2) + s3 in float32: order matters at 3e7
     else:
         got, want = O.FilteredNoise().get_controls(g['raw_mag'])['magnitudes'], g['noise_controls']
     assert rms_err(got, want) < tol, f'recalled detail {detail!r}: oracle default disagrees with the {_backends()} golden'

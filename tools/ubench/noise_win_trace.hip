@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
     const int delay = (Lw - 1) / 2 - 1;
     WinGeom g;
     if (!win_fused_supported(N, T, K, Lw, delay, &g)) return 1;
-    const size_t lds = win_lds_bytes(g, K);
+    const size_t lds = win_lds_bytes(g, K) + (argc > 3 ? (size_t)atoi(argv[3]) : 0);       // argv[3]: LDS pad -> fewer workgroups per CU
     printf("geometry: W %d gs %d padl %d nsteps %d lds %zu B\n", g.W, g.gs, g.padl, g.nsteps, lds);
     float *x, *mags, *CE, *CO, *we, *wo, *out, *out_last;
     int* ti;
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((noise_win_fused_kernel<48, 3, 12, 24, true>), grid, block, lds, 0, x, mags, CE, CO, ti, we, wo, out,
-                           vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw, 0, trace);
+                           vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw, (int)((grid.x / WIN_TRACE_WGS) << 8), trace);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -89,6 +89,21 @@ int main(int argc, char** argv) {
             tot += acc[k] / (cnt ? cnt : 1);
         }
         printf("  | total %.0f\n", tot);
+    }
+    // when did the recorded workgroups (every (grid / 64)-th) run?  wall_clock64 ticks at 100 MHz
+    {
+        long long t0 = -1;
+        for (int b = 0; b < WIN_TRACE_WGS; ++b) {
+            const long long m = h[(((size_t)b * WIN_TRACE_UNITS) * 4) * WIN_TRACE_MARKS];
+            if (m && (t0 < 0 || m < t0)) t0 = m;
+        }
+        printf("recorded workgroups: start .. end in us after the first start (one per line: index, start, end, per-unit us)\n");
+        for (int b = 0; b < WIN_TRACE_WGS; b += 3) {
+            const long long s0 = h[(((size_t)b * WIN_TRACE_UNITS) * 4) * WIN_TRACE_MARKS];
+            const long long e0 = h[(((size_t)b * WIN_TRACE_UNITS + WIN_TRACE_UNITS - 1) * 4) * WIN_TRACE_MARKS + 6];
+            printf("  wg %4d: %8.1f .. %8.1f  (%.2f us per unit)\n", b * (int)(grid.x / WIN_TRACE_WGS), (s0 - t0) * 0.01, (e0 - t0) * 0.01,
+                   (e0 - s0) * 0.01 / WIN_TRACE_UNITS);
+        }
     }
     // one workgroup in full
     for (int b : {0, 17}) {
