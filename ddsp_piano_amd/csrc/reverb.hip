@@ -25,7 +25,7 @@ struct FftConvPlan {
     bool part = false;
     PartPlan pp{};
     float2* tables = nullptr;            // device: W then U (the only device memory the plan owns: 64 KB)
-    size_t off_xspec = 0, off_hspec = 0;
+    size_t off_xspec = 0, off_hspec = 0, off_yspec = 0;
     rocfft_plan fwd_audio = nullptr, fwd_ir = nullptr, inv = nullptr;
     rocfft_execution_info info = nullptr;
     size_t rocfft_work_bytes = 0;
@@ -164,6 +164,7 @@ int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan*
         pl->part = true;
         pl->pp.Pn = (L + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK;
         pl->pp.nbx = (N + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK + 1;
+        pl->pp.nbo = (int)(((long long)nfft + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK);       // crops stay inside [0, nfft)
         const size_t tbytes = (size_t)2 * REVERB_PART_BLOCK * sizeof(float2);
         float* host = new float[4 * REVERB_PART_BLOCK];
         reverb_part_tables_host(host, host + 2 * REVERB_PART_BLOCK);
@@ -181,6 +182,7 @@ int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan*
         size_t off = 0;
         pl->off_xspec = off; off = align256(off + (size_t)B * pl->pp.nbx * REVERB_PART_BLOCK * sizeof(float2));
         pl->off_hspec = off; off = align256(off + (size_t)B_ir * pl->pp.Pn * REVERB_PART_BLOCK * sizeof(float2));
+        pl->off_yspec = off; off = align256(off + (size_t)B * pl->pp.nbo * REVERB_PART_BLOCK * sizeof(float2));
         pl->total_bytes = off;
         *out_plan = pl;
         return DDSPP_OK;
@@ -283,7 +285,8 @@ int ddspp_fftconv_execute_prepared(ddspp_fftconv_plan* pl, const float* audio, i
     char* ws = (char*)workspace;
     if (pl->part)
         return reverb_part_execute(pl->pp, audio, audio_stride, pl->B, pl->B_ir, pl->N, (float2*)(ws + pl->off_xspec),
-                                   (const float2*)(ws + pl->off_hspec), out, out_len, start, add_dry, stream);
+                                   (const float2*)(ws + pl->off_hspec), (float2*)(ws + pl->off_yspec), out, out_len, start,
+                                   add_dry, stream);
     float* audio_p = (float*)(ws + pl->off_audio_p);
     float2* audio_f = (float2*)(ws + pl->off_audio_f);
     float2* ir_f = (float2*)(ws + pl->off_ir_f);

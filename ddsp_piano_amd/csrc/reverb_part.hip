@@ -7,13 +7,14 @@
 // 163 840-point transform per row whose passes, paddings, product and crop cross HBM thirteen times (0.97 GB moved for
 // 55 MB of audio, impulse response and output).  A linear convolution does not care how it is cut:
 //   y[i Bs + t] = sum_p (x window i - p) (*) (h partition p),     Bs = 4096,
-// with 8192-point real transforms that fit the LDS of a CU.  Three launches:
+// with 8192-point real transforms that fit the LDS of a CU.  Four launches:
 //   part_fwd_kernel<IR>   : h partitions -> spectra H[row, p, :]           (on the caller's side stream, early)
 //   part_fwd_kernel<AUDIO>: x windows    -> spectra X[row, j, :]           (reads the dry mix once, from HBM / L2)
-//   part_mac_inv_kernel   : Y_i = sum_p X[i - p] H[p] in registers, inverse transform in LDS, crop, + dry -> out
-// HBM sees the audio, the impulse responses, the two sets of spectra once each way and the output: about 4x the
-// algorithmic bytes instead of 17x; the re-reads of the spectra by the product stage (i + 1 pairs for output block i)
-// are served by L2 / the Infinity Cache (a row's spectra are 1.2 MB).
+//   part_mac_kernel       : Y[row, i, :] = sum_p X[i - p] H[p], bin-major: a thread owns a bin, eight output blocks'
+//                           accumulators and a sliding window of X in registers (one X and one H load per 8 products)
+//   part_inv_kernel       : Y -> inverse transform in LDS, crop, + dry -> out
+// HBM sees the audio, the impulse responses, the output and three sets of spectra written once and read back a few
+// times (mostly from L2): a fraction of the traffic of the whole-signal route.
 //
 // The 8192-point real transform is a 4096-point complex one on (even, odd) sample pairs plus an unpack step; the
 // 4096-point transform is three radix-16 Stockham passes by 256 threads (one 16-point butterfly per thread and pass),
@@ -72,25 +73,36 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     }
 }
 
+// Twiddles of passes 2 and 3 for thread j: fetched at kernel start (they do not depend on the data), so that the passes
+// do not wait for the table.  W = exp(-2 pi i e / 4096).
+struct Twiddles {
+    float2 w2[15], w3[15];
+};
+__device__ __forceinline__ void load_twiddles(Twiddles& t, const float2* __restrict__ W, int j) {
+    const int k = j & 15;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+        t.w2[r - 1] = W[16 * k * r];           // W_256^(k r)
+        t.w3[r - 1] = W[j * r];                // W_4096^(j r)
+    }
+}
+
 // The three Stockham passes.  On entry v[r] = input[j + 256 r] (registers); on exit the transform sits in `buf`
-// (padded, natural order) and the workgroup is synchronised.  W = exp(-2 pi i e / 4096).
+// (padded, natural order) and the workgroup is synchronised.
 template <bool INV>
-__device__ __forceinline__ void fft4096(float2 (&v)[16], float2* __restrict__ buf, const float2* __restrict__ W, int j) {
+__device__ __forceinline__ void fft4096(float2 (&v)[16], float2* __restrict__ buf, const Twiddles& tw, int j) {
     // pass 1: Ns = 1, no twiddles; out[16 j + r]
     dft16<INV>(v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[pidx(16 * j + r)] = v[r];
     __syncthreads();
-    // pass 2: Ns = 16, twiddle W_256^(k r) = W[16 k r]
+    // pass 2: Ns = 16
     {
         const int k = j & 15;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = buf[pidx(j + 256 * r)];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            const float2 w = W[16 * k * r];
-            v[r] = cmul(v[r], INV ? cconj(w) : w);
-        }
+        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], INV ? cconj(tw.w2[r - 1]) : tw.w2[r - 1]);
         dft16<INV>(v);
         __syncthreads();
         const int base = (j >> 4) * 256 + k;
@@ -98,15 +110,12 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2* __restrict__ bu
         for (int r = 0; r < 16; ++r) buf[pidx(base + 16 * r)] = v[r];
         __syncthreads();
     }
-    // pass 3: Ns = 256, twiddle W_4096^(j r); out[j + 256 r]
+    // pass 3: Ns = 256; out[j + 256 r]
     {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = buf[pidx(j + 256 * r)];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            const float2 w = W[j * r];
-            v[r] = cmul(v[r], INV ? cconj(w) : w);
-        }
+        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], INV ? cconj(tw.w3[r - 1]) : tw.w3[r - 1]);
         dft16<INV>(v);
         __syncthreads();
 #pragma unroll
@@ -126,6 +135,8 @@ __global__ void __launch_bounds__(PTH) part_fwd_kernel(const float* __restrict__
     const int row = blockIdx.x / nblk, b = blockIdx.x - row * nblk;
     const float* s = src + (size_t)row * src_stride;
     const long long lo = IR ? (long long)b * PM : ((long long)b - 1) * PM;
+    Twiddles tw;
+    load_twiddles(tw, W, j);
     float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -139,7 +150,7 @@ __global__ void __launch_bounds__(PTH) part_fwd_kernel(const float* __restrict__
         }
         v[r] = make_float2(a, c);
     }
-    fft4096<false>(v, buf, W, j);
+    fft4096<false>(v, buf, tw, j);
     // unpack: bins k and M - k from Z[k], Z[M - k]
     float2* out = spec + ((size_t)row * nblk + b) * PM;
 #pragma unroll
@@ -162,51 +173,75 @@ __global__ void __launch_bounds__(PTH) part_fwd_kernel(const float* __restrict__
     }
 }
 
-// Output block i of one row per workgroup: product-accumulate over the partitions, inverse transform, crop, + dry.
-__global__ void __launch_bounds__(PTH) part_mac_inv_kernel(const float2* __restrict__ X, const float2* __restrict__ H,
-                                                         const float* __restrict__ dry, int dry_stride,
-                                                         float* __restrict__ out, int out_len, int start, int nbx,
-                                                         int Pn, int hrow_stride_blocks, int i0, int nbo, int jmax,
-                                                         const float2* __restrict__ W, const float2* __restrict__ U) {
+// Y[row, i, :] = sum_p X[row, i - p, :] H[row, p, :] for a chunk of MAC_CH consecutive output blocks and 256 bins per
+// workgroup.  A thread owns one bin: the chunk's accumulators and a sliding window of the X spectra stay in registers,
+// a step of the p loop loads ONE new X value and ONE H value for MAC_CH products -- every spectrum is read (8 + Pn) / 8
+// times per chunk instead of once per output block (the first version of this file read 0.65 GB here).
+constexpr int MAC_CH = 8;
+__global__ void __launch_bounds__(256) part_mac_kernel(const float2* __restrict__ X, const float2* __restrict__ H,
+                                                     float2* __restrict__ Y, int nbx, int Pn, int hrow_stride_blocks, int i0,
+                                                     int nbo, int jmax, int nchunks) {
+    const int tiles = PM / 256;
+    int id = blockIdx.x;
+    const int tile = id % tiles; id /= tiles;
+    const int chunk = id % nchunks;
+    const int row = id / nchunks;
+    const int bin = tile * 256 + threadIdx.x;
+    const int ic = i0 + chunk * MAC_CH;                       // first output block of the chunk
+    const float2* xrow = X + (size_t)row * nbx * PM + bin;
+    const float2* hrow = H + (size_t)row * hrow_stride_blocks * PM + bin;
+    auto xload = [&](int jb) {                                // X_j is zero outside [0, jmax]
+        return (jb >= 0 && jb <= jmax) ? xrow[(size_t)jb * PM] : make_float2(0.0f, 0.0f);
+    };
+    float2 acc[MAC_CH], win[MAC_CH];
+#pragma unroll
+    for (int c = 0; c < MAC_CH; ++c) {
+        acc[c] = make_float2(0.0f, 0.0f);
+        win[c] = xload(ic + c);                               // p = 0: X_{ic + c}
+    }
+    const bool packed = bin == 0;                             // bin 0 holds (DC, Nyquist): two real products
+    const int p_end = min(Pn - 1, ic + MAC_CH - 1);           // beyond, i - p < 0 for every i of the chunk
+    for (int p0 = 0; p0 <= p_end; p0 += MAC_CH) {
+#pragma unroll
+        for (int u = 0; u < MAC_CH; ++u) {
+            const int p = p0 + u;
+            if (p > p_end) break;
+            const float2 h = hrow[(size_t)p * PM];
+            // window slot (c - u) mod MAC_CH holds X_{ic + c - p}
+#pragma unroll
+            for (int c = 0; c < MAC_CH; ++c) {
+                const float2 x = win[(c - u + MAC_CH) % MAC_CH];
+                if (packed) {
+                    acc[c].x = __builtin_fmaf(x.x, h.x, acc[c].x);
+                    acc[c].y = __builtin_fmaf(x.y, h.y, acc[c].y);
+                } else {
+                    acc[c] = cadd(acc[c], cmul(x, h));
+                }
+            }
+            // next p: every slot's block index drops by one; the slot that held X_{ic + MAC_CH - 1 - p} takes X_{ic - p - 1}
+            win[(MAC_CH - 1 - u + MAC_CH) % MAC_CH] = xload(ic - p - 1);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAC_CH; ++c) {
+        const int i = ic + c;
+        if (i < i0 + nbo) Y[((size_t)row * nbo + (i - i0)) * PM + bin] = acc[c];
+    }
+}
+
+// Output block i of one row per workgroup: Y -> inverse transform in LDS, crop, + dry.
+__global__ void __launch_bounds__(PTH) part_inv_kernel(const float2* __restrict__ Y, const float* __restrict__ dry,
+                                                     int dry_stride, float* __restrict__ out, int out_len, int start, int i0,
+                                                     int nbo, const float2* __restrict__ W, const float2* __restrict__ U) {
     __shared__ float2 buf[PLDS];
     const int j = threadIdx.x;
-    const int row = blockIdx.x / nbo, i = i0 + (blockIdx.x - row * nbo);
-    const int p_lo = max(0, i - jmax), p_hi = min(i, Pn - 1);
+    const int row = blockIdx.x / nbo, ib = blockIdx.x - row * nbo, i = i0 + ib;
+    Twiddles tw;
+    load_twiddles(tw, W, j);
+    const float2* yrow = Y + ((size_t)row * nbo + ib) * PM;
     float2 acc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.0f, 0.0f);
-    const float2* xrow = X + (size_t)row * nbx * PM + j;
-    const float2* hrow = H + (size_t)row * hrow_stride_blocks * PM + j;
-    float2 xa[16], ha[16];
-    if (p_lo <= p_hi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            xa[r] = xrow[(size_t)(i - p_lo) * PM + 256 * r];
-            ha[r] = hrow[(size_t)p_lo * PM + 256 * r];
-        }
-    }
-    for (int p = p_lo; p <= p_hi; ++p) {
-        float2 xn[16], hn[16];
-        const int pn = min(p + 1, p_hi);                     // the next partition's spectra are in flight during this product
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            xn[r] = xrow[(size_t)(i - pn) * PM + 256 * r];
-            hn[r] = hrow[(size_t)pn * PM + 256 * r];
-        }
-        if (j == 0) {                                        // bin 0 holds (DC, Nyquist): two real products
-            acc[0].x = __builtin_fmaf(xa[0].x, ha[0].x, acc[0].x);
-            acc[0].y = __builtin_fmaf(xa[0].y, ha[0].y, acc[0].y);
-        } else {
-            acc[0] = cadd(acc[0], cmul(xa[0], ha[0]));
-        }
-#pragma unroll
-        for (int r = 1; r < 16; ++r) acc[r] = cadd(acc[r], cmul(xa[r], ha[r]));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            xa[r] = xn[r];
-            ha[r] = hn[r];
-        }
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = yrow[j + 256 * r];
     // Y -> Z' = E + i O,  E = (Y[k] + conj Y[M - k]) / 2,  O = (Y[k] - conj Y[M - k]) / 2 * conj U[k]
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[pidx(j + 256 * r)] = acc[r];
@@ -228,7 +263,7 @@ __global__ void __launch_bounds__(PTH) part_mac_inv_kernel(const float2* __restr
         v[r] = make_float2(e.x - o.y, e.y + o.x);            // e + i o
     }
     __syncthreads();
-    fft4096<true>(v, buf, W, j);
+    fft4096<true>(v, buf, tw, j);
     // the last Bs of the 2 Bs outputs: complex n in [M / 2, M) -> real samples 2 (n - M / 2), + 1 of block i
     const float scale = 1.0f / (float)PM;
     const float* drow = dry ? dry + (size_t)row * dry_stride : nullptr;
@@ -264,7 +299,7 @@ int reverb_part_transform_ir(const PartPlan& pp, const float* ir, int B_ir, int 
 }
 
 int reverb_part_execute(const PartPlan& pp, const float* audio, int audio_stride, int B, int B_ir, int N, float2* Xspec,
-                        const float2* Hspec, float* out, int out_len, int start, int add_dry, hipStream_t stream) {
+                        const float2* Hspec, float2* Yspec, float* out, int out_len, int start, int add_dry, hipStream_t stream) {
     const int nbo_all = (start + out_len + PM - 1) / PM;           // output blocks 0 .. nbo_all - 1 cover y[0, start + out_len)
     const int i0 = start / PM;
     int jmax = (N + PM - 1) / PM;                                  // X_j is zero for j > ceil(N / Bs)
@@ -274,9 +309,13 @@ int reverb_part_execute(const PartPlan& pp, const float* audio, int audio_stride
                        N, Xspec, jmax + 1, 0, pp.W, pp.U);
     DDSPP_LAUNCH_CHECK();
     const int nbo = nbo_all - i0;
-    hipLaunchKernelGGL(part_mac_inv_kernel, dim3((unsigned)(B * nbo)), dim3(PTH), 0, stream, Xspec, Hspec,
-                       add_dry ? audio : nullptr, audio_stride, out, out_len, start, jmax + 1, pp.Pn, B_ir == 1 ? 0 : pp.Pn, i0,
-                       nbo, jmax, pp.W, pp.U);
+    DDSPP_REQUIRE(nbo <= pp.nbo, "fft_convolve (partitioned): %d output blocks exceed the plan's %d", nbo, pp.nbo);
+    const int nchunks = (nbo + MAC_CH - 1) / MAC_CH;
+    hipLaunchKernelGGL(part_mac_kernel, dim3((unsigned)(B * nchunks * (PM / 256))), dim3(256), 0, stream, Xspec, Hspec, Yspec,
+                       jmax + 1, pp.Pn, B_ir == 1 ? 0 : pp.Pn, i0, nbo, jmax, nchunks);
+    DDSPP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(part_inv_kernel, dim3((unsigned)(B * nbo)), dim3(PTH), 0, stream, Yspec, add_dry ? audio : nullptr,
+                       audio_stride, out, out_len, start, i0, nbo, pp.W, pp.U);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
