@@ -235,8 +235,11 @@ class Options:
         env = os.environ
         self.voice_sums = int(env.get('DDSPP_VOICE_SUMS', 0))            # voices summed per noise row (0: pick)
         self.no_voice_sums = env.get('DDSPP_NO_VOICE_SUMS') == '1'
+        # noise branch on a side stream: opt-in since round 3 (DDSPP_SIDE_STREAM=1).  Both branches are bound by the same
+        # VALU issue slots; same-box A/B at batch 64: 1.96 ms with one stream against 1.99 ms with two
+        self.side_stream = env.get('DDSPP_SIDE_STREAM') == '1'
         self.side_stream_min = int(env.get('DDSPP_SIDE_STREAM_MIN', 1 << 24))
-        self.no_side_stream = env.get('DDSPP_NO_SIDE_STREAM') == '1'
+        self.no_side_stream = env.get('DDSPP_NO_SIDE_STREAM') == '1' or not self.side_stream
         self.no_early_ir = env.get('DDSPP_NO_EARLY_IR') == '1'
         if _library and _lib is not None:
             _lib.ddspp_reload_options()

@@ -128,7 +128,9 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
     }
     if (rc == DDSPP_OK && c.ir_length > 0)
         rc = ddspp_fftconv_plan_create(B, c.ir_batch ? c.ir_batch : B, N, c.ir_length, &g->plan);
-    if (rc == DDSPP_OK && (long long)R * N >= (long long)ddspp_option("DDSPP_SIDE_STREAM_MIN", 1 << 24) &&
+    // a side stream for the noise branch is opt-in (DDSPP_SIDE_STREAM=1): both branches want the same VALU issue slots
+    if (rc == DDSPP_OK && ddspp_option("DDSPP_SIDE_STREAM", 0) &&
+        (long long)R * N >= (long long)ddspp_option("DDSPP_SIDE_STREAM_MIN", 1 << 24) &&
         !ddspp_option("DDSPP_NO_SIDE_STREAM", 0)) {
         hipError_t e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);

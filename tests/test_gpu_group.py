@@ -469,7 +469,7 @@ def test_side_stream_route_gives_the_same_audio(monkeypatch):
     feats = {k: torch.as_tensor(v, device='cuda') for k, v in _features(rng, B, P, T, H, K, S, L).items()}
     outs = []
     for side in (False, True):
-        set_option(monkeypatch, 'DDSPP_NO_SIDE_STREAM', '0' if side else '1')
+        set_option(monkeypatch, 'DDSPP_SIDE_STREAM', '1' if side else '0')
         set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', '1')
         for _ in range(3):                                   # a few calls in a row: buffers are recycled across streams
             dag, gnoise = _build(dp, P, sr)

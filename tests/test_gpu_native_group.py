@@ -102,11 +102,13 @@ def test_native_group_side_stream(monkeypatch):
     """The noise branch and the impulse-response transform on the group's own stream (what large batches get), forced on
     at a small size; several calls back to back re-use the workspace across the fork / join."""
     from util import set_option
+    set_option(monkeypatch, 'DDSPP_SIDE_STREAM', 1)
     set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', 1)
     dp, group, feats, _, noise, sr = _setup(21, 4, 16, 125, 128, 96, 1, 96, False, 5000)
     z = torch.as_tensor(noise, device='cuda')
     nat = dp.NativeGroup(group(), feats)
     set_option(monkeypatch, 'DDSPP_SIDE_STREAM_MIN', None)
+    set_option(monkeypatch, 'DDSPP_SIDE_STREAM', None)
     want = group()(feats, return_outputs_dict=True, noise=z)
     for _ in range(3):
         got = nat(feats, return_outputs_dict=True, noise=z)
