@@ -91,17 +91,21 @@ __device__ __forceinline__ float fast_pow(float b, float e) {      // b >= 0
     return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(b));
 }
 
+// sigmoid(y) ** p = exp(-p log(1 + exp(-y))): three transcendentals (exp2, log2, exp2) instead of the four of
+// rcp + pow (round 3: a quarter of the get_controls kernel's issue slots were these), and one rounding less.
+__device__ __forceinline__ float sigmoid_pow(float y, float p) {
+    return __builtin_amdgcn_exp2f(-p * __builtin_amdgcn_logf(1.0f + fast_exp(-y)));
+}
+
 __device__ __forceinline__ float apply_scale(const ScaleFn& s, float x) {
     if (s.kind == SCALE_EXP_SIGMOID) {
         // max_value * sigmoid(x) ** log(exponent) + threshold          (ddsp.core.exp_sigmoid)
-        const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-x));
-        return s.max_value * fast_pow(sg, s.log_exponent) + s.threshold;
+        return s.max_value * sigmoid_pow(x, s.log_exponent) + s.threshold;
     }
     if (s.kind == SCALE_EXP_TANH) {
         // max_value * (0.5 * (tanh(gain * x) + 1)) ** log(exponent) + threshold   (inharm_synth.py:13-17)
         // 0.5 * (tanh(y) + 1) == sigmoid(2 y)
-        const float pt = __builtin_amdgcn_rcpf(1.0f + fast_exp(-2.0f * (s.gain * x)));
-        return s.max_value * fast_pow(pt, s.log_exponent) + s.threshold;
+        return s.max_value * sigmoid_pow(2.0f * (s.gain * x), s.log_exponent) + s.threshold;
     }
     return x;
 }

@@ -228,7 +228,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         forked = true;
     }
     if (g->plan && g->side) {
-        rc = ddspp_fftconv_transform_ir(g->plan, reverb_ir, 1, ws + g->o_fft, g->fft_bytes, zs);
+        rc = ddspp_fftconv_transform_ir(g->plan, reverb_ir, c.reverb_keep_dry_tap ? 0 : 1, ws + g->o_fft, g->fft_bytes, zs);
         if (rc != DDSPP_OK) return leave(rc);
     }
     const float* z = noise;
@@ -330,14 +330,15 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         }
     }
 
-    // ---- reverb (ddsp.effects.Reverb.get_signal: mask the dry tap, FFT convolution, + dry) -------------------------------
+    // ---- reverb (ddsp.effects.Reverb.get_signal: mask the dry tap, FFT convolution, + dry; or, reverb_keep_dry_tap,
+    //      FeedbackDelayNetwork.get_signal, fdn_reverb.py:407-410: the FFT convolution alone) ---------------------------
     if (g->plan) {
-        // _mask_dry_ir + fft_convolve(padding='same', delay_compensation=0) + dry
+        // [_mask_dry_ir +] fft_convolve(padding='same', delay_compensation=0) [+ dry]
         if (g->side)
             rc = ddspp_fftconv_execute_prepared(g->plan, dry, N, audio, N, 0, c.reverb_add_dry ? 1 : 0, ws + g->o_fft, g->fft_bytes,
                                                 stream);
         else
-            rc = ddspp_fftconv_execute(g->plan, dry, N, reverb_ir, audio, N, 0, 1, c.reverb_add_dry ? 1 : 0, ws + g->o_fft,
+            rc = ddspp_fftconv_execute(g->plan, dry, N, reverb_ir, audio, N, 0, c.reverb_keep_dry_tap ? 0 : 1, c.reverb_add_dry ? 1 : 0, ws + g->o_fft,
                                        g->fft_bytes, stream);
         if (rc != DDSPP_OK) return rc;
     } else if (dry != audio) {             // no reverb node: the group's signal is the dry mix

@@ -5,8 +5,8 @@ table look-ups -- 0.25 ms of host time per call, hidden behind the GPU at batch 
 ``NativeGroup`` does the same sequence inside the library: one call, one workspace.  Same kernels, same arguments: the
 results equal the batched Python route's to the last bits (the two Hann table builders differ by an ulp in a few
 entries; tests/test_gpu_native_group.py).  It takes the polyphonic_dag
-shape with the library's own scale functions and a ddsp.effects.Reverb (or no reverb); anything else stays with
-ProcessorGroup.
+shape with the library's own scale functions and, as its last node, a ddsp.effects.Reverb, a FeedbackDelayNetwork that holds its
+parameters (the ENSTDkCl configurations) or nothing; anything else stays with ProcessorGroup.
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ import torch
 
 from . import _lib, core
 from .core import _lib_, _ptr, _stream
-from .effects import Reverb
+from .effects import FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb
 from .polyphonic import _stack_voices, noise_rows, recognise
 from .synths import InHarmonic
 
@@ -30,7 +30,8 @@ class _Config(ctypes.Structure):
                 ('window_size', ctypes.c_int), ('noise_scale_kind', ctypes.c_int)] + \
                [(n, ctypes.c_float) for n in ('noise_bias', 'noise_exponent', 'noise_max_value', 'noise_threshold',
                                               'noise_gain')] + \
-               [('delay_compensation', ctypes.c_int), ('resize_rule', ctypes.c_int), ('noise_seed', ctypes.c_uint64)]
+               [('delay_compensation', ctypes.c_int), ('resize_rule', ctypes.c_int), ('noise_seed', ctypes.c_uint64),
+                ('reverb_keep_dry_tap', ctypes.c_int), ('reserved_', ctypes.c_int)]
 
 
 class _Outputs(ctypes.Structure):
@@ -49,8 +50,18 @@ class NativeGroup:
         add, nz, rv = plan.additive, plan.noise, plan.reverb
         if not isinstance(add, InHarmonic) or not add.inference:
             raise ValueError('NativeGroup needs the inference oscillator (angular cumsum)')
-        if rv is not None and (type(rv) is not Reverb or len(plan.reverb_keys) != 1):
-            raise ValueError('NativeGroup takes ddsp.effects.Reverb with the impulse response as a control, or no reverb')
+        # the last node: ddsp.effects.Reverb with the impulse response as a control; a FeedbackDelayNetwork that holds its
+        # parameters (reverb_controls = [], configs/ENSTDkCl-8kHz.gin:85-104: its impulse response is computed once, here);
+        # the apply step of one whose impulse response is a control; or nothing
+        self._fdn = rv is not None and isinstance(rv, (FeedbackDelayNetwork, FeedbackDelayNetworkApply))
+        if self._fdn:
+            if isinstance(rv, FeedbackDelayNetwork) and not (rv.trainable and len(plan.reverb_keys) == 0):
+                raise ValueError('NativeGroup takes a FeedbackDelayNetwork that holds its parameters (trainable=True, reverb_controls=[])')
+            if isinstance(rv, FeedbackDelayNetworkApply) and len(plan.reverb_keys) != 1:
+                raise ValueError('FeedbackDelayNetworkApply needs its impulse response as the one reverb control')
+        elif rv is not None and (type(rv) is not Reverb or len(plan.reverb_keys) != 1):
+            raise ValueError('NativeGroup takes ddsp.effects.Reverb with the impulse response as a control, a FeedbackDelayNetwork '
+                             'that holds its parameters, or no reverb')
         ak, zk = core.scale_kind(add.scale_fn), (nz.raw_scale() if nz.scale_fn is not None else (-1, 0.0, core.scale_kind(None)[1]))
         if ak is None or zk is None:
             raise ValueError('NativeGroup needs the library\'s scale functions (exp_sigmoid, exp_tanh, None)')
@@ -65,10 +76,11 @@ class NativeGroup:
         c = _Config()
         c.n_segments, c.n_voices, c.n_frames, c.n_harmonics, c.n_substrings, c.n_bands = B, P, T, H, S, K
         c.upsampling = add.upsampling
-        ir = features[plan.reverb_keys[0]] if rv is not None else None
+        ir = self._impulse_response(features, hd0.device)
         c.ir_length = int(ir.shape[-1]) if ir is not None else 0
         c.ir_batch = (1 if (ir.dim() == 1 or ir.shape[0] == 1) else B) if ir is not None else 0
-        c.reverb_add_dry = int(rv._add_dry) if rv is not None else 1
+        c.reverb_add_dry = 0 if self._fdn else (int(rv._add_dry) if rv is not None else 1)
+        c.reverb_keep_dry_tap = 1 if self._fdn else 0
         c.voice_major = int(self._vm)
         c.sample_rate, c.min_frequency = float(add.sample_rate), float(add.min_frequency)
         c.scale_kind = ak[0]
@@ -103,6 +115,15 @@ class NativeGroup:
             except Exception:  # noqa: BLE001  (interpreter teardown)
                 pass
 
+    def _impulse_response(self, features, dev):
+        plan = self.plan
+        rv = plan.reverb
+        if rv is None:
+            return None
+        if isinstance(rv, FeedbackDelayNetwork):        # parameters held by the layer (it keeps the impulse response until
+            return rv.get_controls(torch.empty(0, device=dev))['ir']       # load_parameters replaces them): one for all rows
+        return features[plan.reverb_keys[0]]
+
     def _layout(self, features):
         plan = self.plan
         ctl = [[features[k[j]] for k in plan.additive_keys] for j in range(4)]
@@ -121,9 +142,9 @@ class NativeGroup:
             raise ValueError('features do not have the shapes this NativeGroup was created for')
         dev = hd.device
         plan = self.plan
-        ir = None
-        if plan.reverb is not None:
-            ir = core.tf_float32(features[plan.reverb_keys[0]])
+        ir = self._impulse_response(features, dev)
+        if ir is not None:
+            ir = core.tf_float32(ir)
             ir = (ir[None, :] if ir.dim() == 1 else ir).contiguous()
         z = noise_rows(noise, B, P, N, vm) if noise is not None else None
         audio = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -160,7 +181,8 @@ class NativeGroup:
         outputs[mix.name] = {'signal': outs['dry'], 'controls': addc}
         module = outputs[mix.name]
         if plan.reverb is not None:
-            module = {'signal': audio, 'controls': {'audio': outs['dry'], 'ir': features[plan.reverb_keys[0]]}}
+            ir_ctl = self._impulse_response(features, dev)
+            module = {'signal': audio, 'controls': {'audio': outs['dry'], 'ir': ir_ctl}}
             outputs[plan.reverb.name] = module
         outputs['out'] = module
         return {'signal': module['signal'], 'controls': outputs}

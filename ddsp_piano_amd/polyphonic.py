@@ -39,8 +39,6 @@ def recognise(dag):
     additive, noise, add = dag[0][0], dag[1][0], dag[2][0]
     if not (isinstance(additive, InHarmonic) and isinstance(noise, FilteredNoise) and isinstance(add, MultiAdd)):
         return None
-    if add.name != 'add' and p > 1:
-        pass
     additive_keys, noise_keys = [], []
     for i in range(p):
         a, z, m = dag[3 * i], dag[3 * i + 1], dag[3 * i + 2]

@@ -376,7 +376,9 @@ int ddspp_midi_conditioning_run_f32(ddspp_midi_state* state, const float* roll, 
  * Rows: every control tensor is [R, T, .] with R = n_segments * n_voices rows, segment major ([B, P]) or voice major
  * ([P, B], what the reference's Parallelizer.unparallelize hands over, sub_modules.py:586-592).
  * Takes the shapes the compacted bank and the even/odd FIR design take (U % 8 == 0, P * S <= 64, K in {32, 64, 96, 128}
- * with the full-length window); FilteredNoise runs fused when its kernel fits the shape, in the two-call form otherwise. */
+ * with the full-length window); FilteredNoise runs fused when its kernel fits the shape, in the two-call form otherwise.
+ * The last node is ddsp.effects.Reverb, or (reverb_keep_dry_tap = 1, reverb_add_dry = 0) the apply step of a
+ * FeedbackDelayNetwork whose impulse response the caller computed (ddspp_fdn_transfer + ddspp_irfft_* + ddspp_fdn_add_early). */
 typedef struct ddspp_group ddspp_group;
 typedef struct {
     int n_segments, n_voices, n_frames, n_harmonics, n_substrings, n_bands, upsampling;
@@ -394,6 +396,9 @@ typedef struct {
     int delay_compensation;        /* frequency_filter: DDSPP_DELAY_AUTO / DDSPP_DELAY_AUTO_HALF / >= 0 */
     int resize_rule;               /* bilinear rule of ddspp_resample_tables_host (0) */
     uint64_t noise_seed;           /* the library's Philox stream when ddspp_group_run gets noise = NULL */
+    int reverb_keep_dry_tap;       /* 0: ddsp.effects.Reverb (ir[:, 0] masked); 1: FeedbackDelayNetwork.get_signal (fdn_reverb.py:407-410:
+                                    * the impulse response as it is; use with reverb_add_dry = 0) -- the ENSTDkCl configurations */
+    int reserved_;                 /* keep 0 */
 } ddspp_group_config;
 /* What the reference's outputs dictionary holds besides the audio; every pointer may be NULL (not wanted).  The DAG
  * re-uses one additive and one noise processor for all voices, so the dictionary keeps the LAST voice's stems and

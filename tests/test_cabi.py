@@ -171,8 +171,12 @@ def test_options_are_read_once_and_reloadable(monkeypatch):
     lib.ddspp_reload_options()
     assert lib.ddspp_option(b'DDSPP_TEST_OPTION', 1) == 1
     assert lib.ddspp_set_option(None, 1) == _lib.DDSPP_EINVAL
-    monkeypatch.setenv('DDSPP_NO_SIDE_STREAM', '1')
-    assert _lib.options.no_side_stream is False                      # not re-read per call
+    _lib.options.reload()
+    monkeypatch.setenv('DDSPP_SIDE_STREAM', '1')                     # the second stream is opt-in
+    assert _lib.options.side_stream is False                         # not re-read per call
+    _lib.options.reload()
+    assert _lib.options.side_stream is True and _lib.options.no_side_stream is False
+    monkeypatch.delenv('DDSPP_SIDE_STREAM')
     _lib.options.reload()
     assert _lib.options.no_side_stream is True
 
@@ -203,7 +207,8 @@ def test_group_driver_argument_errors(lib):
     assert lib.ddspp_group_run(None, None, None, None, None, None, None, None, None, None, None, 0, None) == _lib.DDSPP_EINVAL
     assert lib.ddspp_group_workspace_bytes(None) == 0 and lib.ddspp_group_n_samples(None) == -1
     lib.ddspp_group_destroy(None)                                                                   # a no-op
-    # 11 ints, 2 floats, 1 int, 4 floats, 4 ints, 5 floats, 2 ints, (pad), uint64 -- as include/ddspp.h declares them
-    assert ctypes.sizeof(_Config) == 29 * 4 + 4 + 8 and _Config.noise_seed.offset == 120
+    # 11 ints, 2 floats, 1 int, 4 floats, 4 ints, 5 floats, 2 ints, (pad), uint64, 2 ints -- as include/ddspp.h declares them
+    assert ctypes.sizeof(_Config) == 29 * 4 + 4 + 8 + 8 and _Config.noise_seed.offset == 120
+    assert _Config.reverb_keep_dry_tap.offset == 128
     assert ctypes.sizeof(_Config) == lib.ddspp_group_config_bytes()
     assert ctypes.sizeof(_Outputs) == lib.ddspp_group_outputs_bytes() == 8 * ctypes.sizeof(ctypes.c_void_p)

@@ -128,3 +128,58 @@ def test_native_group_32khz_and_captured():
     got = fast(feats, noise=z)
     _close(got['signal'], py(feats, noise=z), 'graph replay')
     _close(fast(feats, noise=z)['controls']['add']['signal'], py(feats, return_outputs_dict=True, noise=z)['controls']['add']['signal'])
+
+
+@pytest.mark.parametrize('sr,H,K,lines,apply_only', [(8000, 48, 32, 6, False), (16000, 96, 64, 8, False), (16000, 96, 64, 8, True)])
+def test_native_group_with_a_feedback_delay_network_last(sr, H, K, lines, apply_only):
+    """The ENSTDkCl DAG (configs/ENSTDkCl-8kHz.gin:85-104, ENSTDkCl-16kHz.gin): exp_tanh, no renormalisation after the
+    Nyquist cut, and a FeedbackDelayNetwork that holds its parameters as the last node (reverb_controls = []) -- through
+    the one-call driver (reverb_keep_dry_tap = 1, reverb_add_dry = 0) against the Python route; also the apply step alone
+    with the impulse response as a control.  New parameters reach the driver on the next call."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(sr + lines)
+    B, P, T, S = 3, 4, 50, 1
+    U = sr // 250
+    raw = musical_controls(rng, B * P, T, H, S, sr)
+    raw['magnitudes'] = rng.normal(0.0, 1.5, [B * P, T, K]).astype(np.float32)
+    feats = {}
+    for k, v in raw.items():
+        dev = torch.as_tensor(v.reshape(B, P, T, v.shape[-1]), device='cuda')
+        for i in range(P):
+            feats[f'{k}_{i}'] = dev[:, i]
+    z = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * U]).astype(np.float32), device='cuda')
+    fdn = dp.FeedbackDelayNetwork(trainable=True, delay_trainable=True, delay_lines=lines, sampling_rate=sr, name='fdn', seed=5)
+    rk = []
+    if apply_only:
+        feats['reverb_ir'] = fdn.get_controls(z[:, 0])['ir'].clone()
+        rk = ['reverb_ir']
+
+    def group():
+        return dp.ProcessorGroup(dp.polyphonic_dag(
+            dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True, scale_fn=dp.exp_tanh,
+                               normalize_after_nyquist_cut=False),
+            dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr, scale_fn=dp.exp_tanh),
+            dp.FeedbackDelayNetworkApply(name='fdn') if apply_only else fdn, n_synths=P, reverb_controls=rk, **KEYS))
+
+    py, nat = group(), dp.NativeGroup(group(), feats)
+    want = py(feats, return_outputs_dict=True, noise=z)
+    got = nat(feats, return_outputs_dict=True, noise=z)
+    assert want['controls']['fdn']['controls']['ir'].shape == (2 * sr,)
+    _same(got, want)
+    _close(nat(feats, noise=z), want['signal'], 'audio only')
+    wet, dry = want['signal'], want['controls']['add']['signal']
+    assert (wet - dry).abs().max().item() > 1e-3 * float(dry.abs().max())          # the reverb did something
+    if not apply_only:
+        fdn.load_parameters({'time_rev_0_sec': 0.25})
+        again = py(feats, noise=z)
+        assert (again - wet).abs().max().item() > 1e-4 * float(wet.abs().max())
+        _close(nat(feats, noise=z), again, 'after load_parameters')
+        fast = dp.CapturedGroup(nat, feats)
+        _close(fast(feats, noise=z), again, 'graph replay')
+    with pytest.raises(ValueError):
+        dp.NativeGroup(dp.ProcessorGroup(dp.polyphonic_dag(
+            dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+            dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr),
+            dp.FeedbackDelayNetwork(sampling_rate=sr, name='fdn'), n_synths=P,
+            reverb_controls=['input_gain', 'output_gain', 'gain_allpass', 'delays_allpass', 'time_rev_0_sec', 'alpha_tone',
+                             'early_ir'], **KEYS)), feats)
