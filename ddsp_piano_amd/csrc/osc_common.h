@@ -20,6 +20,8 @@ struct OscParams {
     const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)
     float* __restrict__ out;           // [R, N] (sum) or [R, N, V]
     float* __restrict__ ework;         // [R, npre, VP]  chunk end phase mod 2pi
+    float* __restrict__ echunk;        // sectioned memo pre-pass: [R, npre, VP] chunk end phases (ework then is astart)
+    int nsec;                          // ... and its sections per (row, group)
     const float* __restrict__ astart;  // [R, spans, VP] running offset sum at span start
     float* __restrict__ partial;       // [R, groups, N] per-group audio when groups > 1
     int R, N, T, U, H, S, V, VP;

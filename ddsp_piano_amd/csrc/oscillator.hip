@@ -466,11 +466,14 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 // scanned sample by sample.  Output: astart[row, span, v] = e[0] + ... + e[c0(span) - 1] accumulated
 // sequentially in float32 -- exactly what the pre-pass + offset-scan kernels produce.
 //
-// PARTS > 1: the PARTS wavefronts of a workgroup share one (row, group); each walks a contiguous run of the chunks (its
-// own memo, its own change detector started at its first frame), leaves the end phases e[c] in LDS, and wavefront 0
-// adds them up in chunk order -- the same float32 sums in the same order.  A row whose frequencies move in every
-// frame (vibrato, glides) costs 72 sample-by-sample chunk scans: one wavefront took 10 ms for them at batch 64, four
-// at twice the occupancy take 0.3 ms; rows of held notes cost what they did (one memoised scan per wavefront).
+// PARTS > 1: a workgroup is one SECTION of a (row, group): its PARTS wavefronts each walk a short contiguous run of the
+// row's chunks (own memo, own change detector started at the run's first frame) and leave the end phases e[c] in
+// p.echunk [R, npre, VP]; osc_offset_scan_groups_kernel then adds them up in chunk order -- the same float32 sums in the
+// same order.  Why sections: a (row, group) whose frequencies move in every frame (vibrato, glides) costs 72
+// sample-by-sample chunk scans, one whose notes are held or silent nearly nothing, and which is which is the input's
+// business: with one workgroup per (row, group) (round 2) all 2048 workgroups were resident at once, a CU that drew seven
+// moving ones worked 1.8x the average and the chip waited for it (VALU issue fraction 0.43).  Five sections are 10240
+// workgroups of a sixth of the length, handed out as earlier ones finish.
 // BLK samples of the phase scan `ph += omega(x0 + (x1 - x0) * w[i])` for one oscillator per lane, in stages that keep
 // BLK independent chains in flight: interpolate all BLK frequencies, scale them all, divide them all, and only then
 // the BLK dependent adds.  Written sample after sample the compiler funnels every omega through the same two
@@ -512,23 +515,44 @@ __device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value
     return v;
 }
 
+// max over the frames of a row of the per-frame audible-harmonic counts (low 16 bits of `audible`), twelve loads in
+// flight per lane: a wavefront that starts with this pays one memory latency for a 3 s row, not twelve
+__device__ __forceinline__ int row_audible_max(const int* __restrict__ aud, int T, int lane) {
+    int amax = 0;
+    for (int t0 = 0; t0 < T; t0 += 768) {
+        int a[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int tt = t0 + u * 64 + lane;
+            a[u] = aud[min(tt, T - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) amax = max(amax, a[u] & 0xffff);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
+    return amax;
+}
+
 constexpr int PRE_W = 256;              // floats of LDS per wavefront: the interpolation weights of the next PRE_W samples
 template <int VPL, int PARTS>
 __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
     const int lane = threadIdx.x & 63;
     const int part = wave_uniform(threadIdx.x >> 6);
-    const int task = PARTS > 1 ? (int)blockIdx.x : wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (PARTS == 1 && task >= p.R * p.groups) return;
+    const int unit = PARTS > 1 ? (int)blockIdx.x : wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (PARTS == 1 && unit >= p.R * p.groups) return;
     // group-major task order: consecutive workgroups (which go round-robin to the 8 XCDs) are consecutive ROWS.  With the
     // groups of a row next to each other, group 1 of 2 (partials 65..128: above Nyquist for most notes, no work) took
-    // every odd XCD and the four even ones did all the scanning.
-    const int grp = task / p.R, row = task - grp * p.R;
+    // every odd XCD and the four even ones did all the scanning.  PARTS > 1: unit = (group, section, row).
+    const int nsec = PARTS > 1 ? p.nsec : 1;
+    const int gs = unit / p.R, row = unit - gs * p.R;
+    const int grp = gs / nsec, sec = gs - grp * nsec;
     const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
     const int vbase = grp * p.vgrp, vlast = min(vbase + p.vgrp, p.V) - 1;
     typedef const __attribute__((address_space(4))) float* cfloat_p;
-    // LDS: [npre][VPL][64] chunk end phases (PARTS > 1), then one PRE_W-float weight buffer per wavefront
-    float* wlds = lds_dyn + (PARTS > 1 ? (size_t)p.npre * VPL * 64 : 0) + (size_t)(threadIdx.x >> 6) * PRE_W;
+    // LDS: one PRE_W-float weight buffer per wavefront
+    float* wlds = lds_dyn + (size_t)(threadIdx.x >> 6) * PRE_W;
 
     int vk[VPL], vs[VPL], vidx[VPL];
     bool valid[VPL];
@@ -552,10 +576,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
 #pragma unroll
     for (int j = 0; j < VPL; ++j) need[j] = true;
     if (p.audible && !p.need_all) {
-        int amax = 0;
-        for (int t0 = lane; t0 < T; t0 += 64) amax = max(amax, p.audible[(size_t)row * T + t0] & 0xffff);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
+        const int amax = row_audible_max(p.audible + (size_t)row * T, T, lane);
         bool any_needed = false;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
@@ -598,9 +619,10 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     // Streaming change detector over the frames: last_change = largest t <= t_checked with
     // hf(t) != hf(t - 1) in some lane.  Frames are fetched 32 at a time with independent loads, so
     // a wavefront pays one memory latency per 32 frames, not per frame.
-    constexpr int FB = VPL <= 2 ? 32 : (VPL <= 4 ? 16 : 8);
+    constexpr int FB = PARTS > 1 ? 8 : (VPL <= 2 ? 32 : (VPL <= 4 ? 16 : 8));     // (a section's run is a few dozen frames)
+    const bool by_flags = p.audible && !p.dbg_noflags;
     float x_prev[VPL];
-    hf_of(0, x_prev);
+    if (!by_flags) hf_of(0, x_prev);
     int t_checked = 0, last_change = 0;
     // With the per-frame flags of the get_controls kernel (bit 16 of p.audible: frequencies may have moved) the
     // detector reads one int per frame, 64 frames per load, instead of streaming the [T, V] controls.
@@ -625,7 +647,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         t_checked = max(t_checked, t_need);
     };
     auto check_upto = [&](int t_need) {
-        if (p.audible && !p.dbg_noflags) {
+        if (by_flags) {
             flagged_upto(t_need);
             return;
         }
@@ -659,8 +681,8 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     }
     int memo_t = -1;                   // first frame of the chunk the memo was taken from (-1: none)
     // this wavefront's run of chunks
-    const int per_part = (p.npre + PARTS - 1) / PARTS;
-    const int c_begin = PARTS > 1 ? min(part * per_part, p.npre) : 0;
+    const int per_part = (p.npre + nsec * PARTS - 1) / (nsec * PARTS);
+    const int c_begin = PARTS > 1 ? min((sec * PARTS + part) * per_part, p.npre) : 0;
     const int c_end = PARTS > 1 ? min(c_begin + per_part, p.npre) : p.npre;
     if (PARTS > 1 && c_begin > 0) {    // the change detector starts at this run's first frame
         const int t0 = (c_begin * DDSPP_CHUNK) / U;
@@ -668,7 +690,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         last_change = t0;
         fl_base = t0 + 1;
         fl_before = t0;
-        hf_of(t0, x_prev);
+        if (!by_flags) hf_of(t0, x_prev);
     }
     auto emit_start = [&](int c) {     // astart of the span that begins at chunk c (if one does)
         if (c % p.cps == 0) {
@@ -790,18 +812,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
             for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + e[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) lds_dyn[((size_t)c * VPL + j) * 64 + lane] = e[j];
-        }
-    }
-    if (PARTS > 1) {
-        __syncthreads();
-        if (part == 0) {
-            for (int c = 0; c <= p.npre; ++c) {
-                emit_start(c);
-                if (c == p.npre) break;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) asum[j] = asum[j] + lds_dyn[((size_t)c * VPL + j) * 64 + lane];
-            }
+            for (int j = 0; j < VPL; ++j) p.echunk[((size_t)row * p.npre + c) * p.VP + vidx[j]] = e[j];
         }
     }
 }
@@ -1011,6 +1022,49 @@ __global__ void __launch_bounds__(256) osc_offset_scan_short_kernel(const float*
     }
 }
 
+// The scan behind the sectioned memo pre-pass (osc_prepass_fused_kernel<.., 4>): one wavefront per (row, 64 oscillators),
+// the sixty-fours the pre-pass left out (no partial of theirs audible anywhere in the call, same test) left out here
+// too -- nothing reads their start phases.
+__global__ void __launch_bounds__(256) osc_offset_scan_groups_kernel(const float* __restrict__ echunk,
+                                                                   float* __restrict__ astart, OscParams p) {
+    const int lane = threadIdx.x & 63;
+    const int task = wave_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int cols = p.VP / 64;
+    if (task >= p.R * cols) return;
+    const int row = task / cols;
+    const int v = (task - row * cols) * 64 + lane;
+    if (p.audible && !p.need_all) {
+        const int amax = row_audible_max(p.audible + (size_t)row * p.T, p.T, lane);
+        if (!__any(v < p.V && v % p.H < amax)) return;
+    }
+    constexpr int NB = 40;
+    const int npre = p.npre;
+    const float* src = echunk + (size_t)row * npre * p.VP + v;
+    float e[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) e[u] = src[(size_t)min(u, max(npre - 1, 0)) * p.VP];
+    float a = (p.state_in && v < p.V) ? p.state_in[(size_t)row * p.V + v] : 0.0f;
+    int span = 0;
+    for (int c0 = 0; c0 <= npre; c0 += NB) {
+        float en[NB];
+        if (c0 + NB <= npre) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) en[u] = src[(size_t)min(c0 + NB + u, npre - 1) * p.VP];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u;
+            if (c <= npre && c == span * p.cps && span < p.spans) {
+                astart[((size_t)row * p.spans + span) * p.VP + v] = a;
+                ++span;
+            }
+            if (c < npre) a = a + e[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) e[u] = en[u];
+    }
+}
+
 static int env_int(const char* name, int dflt);
 
 static void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
@@ -1169,17 +1223,27 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
     return pl;
 }
 
-// Launch of the memoised pre-pass: `tasks` (row, group) pairs.  Four wavefronts per pair (PARTS = 4) whenever the
-// chunk end phases of a row fit in LDS; one wavefront per pair otherwise (very long rows).
-static void launch_memo_prepass(int vpl, const OscParams& q, int tasks, hipStream_t stream) {
+// Launch of the memoised pre-pass: `tasks` (row, group) pairs, start offsets into q.ework (= astart).  In sections
+// (workgroups of four wavefronts, PARTS = 4, chunk end phases through `echunk` [R, npre, VP] and the group scan) when the
+// task is at most 128 oscillators wide and there are chunks enough to share out; one wavefront per pair otherwise.
+static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* echunk, hipStream_t stream) {
     const size_t ldsw = (size_t)4 * PRE_W * sizeof(float);              // weight buffers of the four wavefronts
-    const size_t lds4 = (size_t)q.npre * vpl * 64 * sizeof(float);
-    const bool parts4 = vpl <= 2 && q.npre >= 8 && lds4 + ldsw <= 64 * 1024 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
+    const bool parts4 = vpl <= 2 && echunk && q0.npre >= 8 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
     if (parts4) {
-        if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks), dim3(256), lds4 + ldsw, stream, q);
-        else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks), dim3(256), lds4 + ldsw, stream, q);
+        OscParams q = q0;
+        // runs of about six chunks per wavefront: short enough to balance, long enough that the held-note case (one
+        // memoised scan of 1000 dependent adds and four memory latencies per wavefront, whatever its run) stays cheap:
+        // 3 s rows, runs of 3 / 6 / 9 chunks: held notes 62 / 41 / 35 us, every frame moving 0.90 / 0.94 / 0.98 ms
+        const int per_wave = max(env_int("DDSPP_OSC_PREPASS_RUN", 6), 1);
+        q.nsec = max((q.npre + 4 * per_wave - 1) / (4 * per_wave), 1);
+        q.echunk = echunk;
+        if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
+        else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
+        hipLaunchKernelGGL(osc_offset_scan_groups_kernel, dim3((q.R * (q.VP / 64) + 3) / 4), dim3(256), 0, stream, echunk,
+                           q.ework, q);
         return;
     }
+    const OscParams& q = q0;
     const dim3 grid((tasks + 3) / 4), blk(256);
     switch (vpl) {
         case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 1>), grid, blk, ldsw, stream, q); break;
@@ -1205,7 +1269,7 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
         if (p.spans > 1 && memo) {
             OscParams q = p;
             q.ework = const_cast<float*>(p.astart);      // the memo pre-pass writes astart directly
-            launch_memo_prepass(VPL, q, p.R * p.groups, stream);
+            launch_memo_prepass(VPL, q, p.R * p.groups, p.ework, stream);
         } else if (p.spans > 1) {
             const int nblk_pre = p.R * p.npre;
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PREPASS, true>), dim3(nblk_pre), blk, lds,
@@ -1267,7 +1331,7 @@ static void span_starts(const OscParams& p, int R, int V, int vpl_pre, float* as
             q.groups = V / 64;
             q.vgrp = 64;
         }
-        launch_memo_prepass(split ? 1 : vpl_pre, q, tasks, stream);
+        launch_memo_prepass(split ? 1 : vpl_pre, q, tasks, ework, stream);
         return;
     }
     q.ework = ework;
