@@ -6,7 +6,7 @@ One "step" = one pass of the polyphonic ProcessorGroup in the reference's call f
 get_controls -> inharmonic oscillator bank -> FilteredNoise -> add chain -> reverb, plus the outputs
 dictionary the reference builds (dry mix, last voice's stems and controls), over one batch of synthetic
 control envelopes that already sit in HBM, plus -- when more than one GPU takes part -- the final RCCL
-all-gather of the audio.
+gather of the audio to rank 0 (DDSPP_BENCH_GATHER=all: to every rank).
 
 Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments x 3 s, poly=16,
 24 kHz, 250 Hz controls, maestro-v2 dims (H=128 harmonics, K=96 noise bands, S=1), 3 s reverb IR;
@@ -19,7 +19,7 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
   * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
                      TF/ddsp reference here) and an op-by-op torch-CPU version on all cores, timed on this host;
   * value          : global batch x samples / MEDIAN of the per-step device times (every step bracketed by HIP events
-                     on the launch stream and synchronised; with N > 1 the step includes its all-gather, max over ranks)
+                     on the launch stream and synchronised; with N > 1 the step includes its gather, max over ranks)
                      -- SURVEY.md 8(d)'s definition.  `pipelined` holds the wall clock of K back-to-back steps (barrier +
                      synchronize on both sides, max over ranks), where the side stream / the gather of one step overlap
                      the next;
@@ -476,7 +476,10 @@ def main():
     feats, base = make_features(B, P, T, H, K, S, L, device, seed=20240 + rank)
     pg = build_group(dp, P, sr)
     want_dict = args.call_form == 'outputs_dict'
-    # the all-gather of step i runs on RCCL's stream while step i + 1 synthesises (two landing buffers)
+    # the final gather: to rank 0 (the reference's strategy.gather(outputs, axis=0), evaluate_model.py:45 -- one program
+    # holds the batch; DDSPP_BENCH_GATHER=all: an all-gather, every rank gets it).  In `pipelined` the gather of step i runs
+    # on RCCL's stream while step i + 1 synthesises (two landing buffers)
+    gather_dst = None if os.environ.get('DDSPP_BENCH_GATHER', 'rank0') == 'all' else 0
     gathered = [torch.empty((world * B, N), dtype=torch.float32, device=device) for _ in range(2)] if use_dist else None
     state = {'work': None, 'k': 0}
 
@@ -494,7 +497,7 @@ def main():
         audio = call(pg, feats)
         if use_dist:
             drain()
-            _, state['work'] = parallel.gather_audio(audio, gathered[state['k'] & 1], async_op=True)
+            _, state['work'] = parallel.gather_audio(audio, gathered[state['k'] & 1], async_op=True, dst=gather_dst)
             state['k'] += 1
         return audio
 
@@ -502,12 +505,12 @@ def main():
         call(pg, feats)
     torch.cuda.synchronize()
     # (1) W warm-up steps, then EXACTLY K steps, each bracketed by HIP events on the launch stream and synchronised: no step
-    #     overlaps its neighbours.  With N > 1 a step includes its own all-gather (synchronous).  value = global samples /
+    #     overlaps its neighbours.  With N > 1 a step includes its own gather (synchronous).  value = global samples /
     #     the MEDIAN step time, max over ranks ("device-synchronised, median of >= 20 runs").
     def sync_step():
         audio = call(pg, feats)
         if use_dist:
-            parallel.gather_audio(audio, gathered[0])
+            parallel.gather_audio(audio, gathered[0], dst=gather_dst)
         return audio
 
     for _ in range(args.warmup):
@@ -544,21 +547,22 @@ def main():
         if share_gpu:
             extra['shared_gpu'] = True           # a dry run of the multi-rank flow, not a multi-GPU measurement
     if use_dist:
-        # the collective by itself (synchronous), max over ranks: what the overlap has to hide
+        # the collectives by themselves (synchronous), max over ranks: what the overlap has to hide
         audio = call(pg, feats)
-        ts = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            parallel.gather_audio(audio, gathered[0])
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        tg = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=device)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        extra['allgather'] = {'ms': float(tg.item()) * 1e3, 'bytes_received_per_rank': (world - 1) * B * N * 4,
-                              'note': 'synchronous all_gather_into_tensor alone (median of 5, max over ranks); in the timed '
-                                      'steps it runs on RCCL\'s stream under the next step\'s kernels'}
+        extra['gather'] = 'all ranks (all_gather_into_tensor)' if gather_dst is None else 'to rank 0 (dist.gather)'
+        for name, dst in (('gather_to_rank0', 0), ('allgather', None)):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                parallel.gather_audio(audio, gathered[0], dst=dst)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            tg = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=device)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            extra[name] = {'ms': float(tg.item()) * 1e3, 'bytes_received': (world - 1) * B * N * 4,
+                           'note': 'the collective alone, synchronous (median of 5, max over ranks)'}
     if rank == 0:
         extra['step_ms'] = ms_summary(step_ts)   # the timed steps themselves (this rank)
     if rank == 0 and not args.no_extras:
@@ -659,7 +663,7 @@ def main():
                        'call_form': 'processor_group(features, return_outputs_dict=True) (piano_model.py:160)'
                                     if want_dict else 'processor_group(features)',
                        'global_batch': world * B, 'segment_samples': N, 'parallelism': f'batch-shard x{world}'
-                                                                                       + (' + one all-gather of the audio per step (inside the timed step; overlapped with the next step in `pipelined`)' if world > 1 else '')},
+                                                                                       + (' + one gather of the audio per step (inside the timed step; overlapped with the next step in `pipelined`)' if world > 1 else '')},
             'roofline': roof, 'roofline_step': roof_step, 'cpu_baseline': cpu,
             'counters_stale': (any(bool(x) for x in stale) if stale else None),
         }

@@ -4,8 +4,8 @@
 // (ddsp_piano/modules/inharm_synth.py:167-219, :254-270), get_inharmonic_freq (:20-46),
 // ddsp.synths.FilteredNoise.get_controls, the scale functions ddsp.core.exp_sigmoid and exp_tanh
 // (inharm_synth.py:13-17) and MultiAdd.get_signal (:308-309).
-// One wavefront conditions one (row, frame): lanes run over harmonics (coalesced 256-byte reads of
-// harmonic_distribution[row, t, :]), the normalisation sum is a wavefront reduction.
+// One DPP row of 16 lanes conditions one (row, frame): its lanes run over the harmonics in steps of 16 (64-byte pieces
+// of harmonic_distribution[row, t, :]), the normalisation sum is a reduction over the row.
 #include "ddspp_common.h"
 
 namespace ddspp {
@@ -46,146 +46,198 @@ struct InharmParams {
     ScaleFn scale;
 };
 
-// One wavefront conditions CTL_FPW consecutive frames of a row-major [R*T] frame list: all loads of the
-// batch are issued before the first use (short-lived one-frame wavefronts were latency bound at 2.9 TB/s).
-constexpr int CTL_FPW = 4;
+// A frame is conditioned by ONE DPP ROW (16 lanes), lane i of the row taking harmonics i, i + 16, i + 32, ...; a
+// wavefront takes CTL_PASS x 4 consecutive frames of the row-major [R * T] frame list, four at a time (CTL_PASS = 2 up
+// to 128 harmonics, 1 above: registers).  Against round 2's
+// "64 lanes run over the harmonics of one frame": (i) the per-frame scalar work (the amplitude's scale function, the
+// row sum, the audible count) is issued once per four frames; (ii) get_controls cuts every harmonic at or above Nyquist
+// (:200-208), and a group of 16 harmonics whose FIRST is already there is cut whole whatever its raw values (the
+// frequencies grow with the harmonic number, the inharmonicity factor is >= 1): with the cut before the normalisation
+// (the default flags) such a group contributes nothing to the sum either, so its raw values are never READ and its
+// scale function, square root and division are skipped when the four frames agree (they are neighbours on a note).
+// A piano has about a third of its partials below Nyquist; groups of 64 could only ever skip harmonics 65..128.
+// The division by the frame's sum is one IEEE reciprocal per frame and Markstein's correction step per element (q =
+// x * r, q + fma(-q, d, x) * r: the correctly rounded quotient but for rare last-bit cases; the sum itself is added up in
+// another order than numpy's or TensorFlow's).
+// All loads of the wavefront are issued before the first use: the scalars of its 8 frames, then (they decide what is
+// read) the raw distributions.
 
-template <int HPL>
-__global__ void __launch_bounds__(256) inharmonic_controls_kernel(const InharmParams p) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ float row_sum(float v) {          // over the 16 lanes of a DPP row, every lane gets it
+    v += dpp_take<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_take<0x141>(v);       // row_half_mirror
+    v += dpp_take<0x140>(v);       // row_mirror
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_take_int(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int row_max(int v) {
+    v = max(v, dpp_take_int<0xB1>(v));
+    v = max(v, dpp_take_int<0x4E>(v));
+    v = max(v, dpp_take_int<0x141>(v));
+    v = max(v, dpp_take_int<0x140>(v));
+    return v;
+}
+
+template <int NJ, int CTL_PASS>
+__device__ __forceinline__ void inharmonic_controls_body(const InharmParams& p) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, rowi = lane >> 4;
     const size_t nframes = (size_t)p.R * p.T;
-    // wave-uniform by construction: saying so keeps the frame bookkeeping and the row base addresses in scalar registers
-    const size_t frame0 = ((size_t)blockIdx.x * 4 + (size_t)wave_uniform(threadIdx.x >> 6)) * CTL_FPW;
-    if (frame0 >= nframes) return;
+    const size_t wave0 = ((size_t)blockIdx.x * 4 + (size_t)wave_uniform(threadIdx.x >> 6)) * (4 * CTL_PASS);
+    if (wave0 >= nframes) return;
     const int H = p.H;
-    float raw_hd[CTL_FPW][HPL], raw_f0[CTL_FPW], raw_in[CTL_FPW], raw_amp[CTL_FPW];
+    const bool cut_first = p.normalize_below_nyquist && p.normalize_after_nyquist_cut;
+    float raw_f0[CTL_PASS], raw_in[CTL_PASS], raw_amp[CTL_PASS];
 #pragma unroll
-    for (int u = 0; u < CTL_FPW; ++u) {
-        const size_t fr = min(frame0 + u, nframes - 1);
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t fr = min(wave0 + 4 * u + rowi, nframes - 1);
         raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
         raw_in[u] = p.inharm_coef[fr];
         raw_amp[u] = p.amplitudes[fr];
-#pragma unroll
-        for (int j = 0; j < HPL; ++j) raw_hd[u][j] = p.harmonic_distribution[fr * H + min(lane + 64 * j, H - 1)];
     }
-    // shifts_last only: where the wavefront's first frame sits (32-bit arithmetic, R * T < 2^31 checked by the host; a
-    // row has at least CTL_FPW frames or the rows simply advance by more than one -- handled by the generic division)
+    // (row, frame in row) of this lane's frames -- only the last voice's shifts are kept when shifts_out is null.  32-bit
+    // arithmetic (R * T < 2^31 checked by the host), one division per wavefront.
     unsigned row0 = 0, tt0 = 0, last_lo = 0;
     if (p.shifts_last) {
-        row0 = (unsigned)frame0 / (unsigned)p.T;
-        tt0 = (unsigned)frame0 - row0 * (unsigned)p.T;
+        row0 = (unsigned)wave0 / (unsigned)p.T;
+        tt0 = (unsigned)wave0 - row0 * (unsigned)p.T;
         last_lo = (unsigned)(p.R / p.P) * (unsigned)(p.P - 1);          // voice major: first row of the last voice
     }
+    unsigned dead[CTL_PASS];           // bit j: harmonics 16 j .. 16 j + 15 of the lane's frame are cut whole
+    float raw_hd[CTL_PASS][NJ];
 #pragma unroll
-    for (int u = 0; u < CTL_FPW; ++u) {
-        const size_t frame = frame0 + u;
-        if (frame >= nframes) break;
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t frame = wave0 + 4 * u + rowi;
+        unsigned d = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (cut_first && raw_f0[u] * (float)(16 * j + 1) >= p.nyquist) d |= 1u << j;
+        if (frame >= nframes) d = ~0u;
+        dead[u] = d;
+        const float* src = p.harmonic_distribution + min(frame, nframes - 1) * H;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = sub + 16 * j;
+            raw_hd[u][j] = (k < H && !((d >> j) & 1)) ? src[k] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t frame = wave0 + 4 * u + rowi;
+        const bool live = frame < nframes;
         const float f0 = raw_f0[u];
         const float inharm = fmaxf(raw_in[u], 0.0f);                    // :183
         float amp = apply_scale(p.scale, raw_amp[u]);                   // :185
-        float hd[HPL], shift[HPL], freq[HPL];
-        float sum = 0.0f;
-        // Where this frame sits (only the last voice's shifts are kept when shifts_out is null)
         bool is_last = false;
-        unsigned row = row0, tt = tt0 + (unsigned)u;
-        if (p.shifts_last) {       // (row, frame-in-row) from the wavefront's first frame: one division per wavefront
-            if (tt >= (unsigned)p.T) {
+        unsigned row = row0, tt = tt0 + 4 * (unsigned)u + (unsigned)rowi;
+        if (p.shifts_last) {
+            while (tt >= (unsigned)p.T) {
                 tt -= (unsigned)p.T;
                 ++row;
             }
-            is_last = p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1;
+            is_last = live && (p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1);
         }
-        const bool want_shift = p.shifts_out != nullptr || is_last;                    // wave-uniform
-        // A 64-harmonic group whose FIRST harmonic is already at or above Nyquist is cut to zero whatever its raw
-        // values (:200-208; the frequencies grow with the harmonic number and the inharmonicity factor is >= 1, so
-        // f0 * (64 j + 1) >= nyquist settles it for the whole group): with the cut before the normalisation (the
-        // default flags) the group contributes nothing to the sum either, and its scale function, square roots and
-        // divisions are skipped.  For a piano, harmonics 65..128 are above Nyquist for every note above F#3.
-        const bool cut_first = p.normalize_below_nyquist && p.normalize_after_nyquist_cut;
-        bool dead_grp[HPL];
+        const bool want_shift = live && (p.shifts_out != nullptr || is_last);
+        float hd[NJ], shift[NJ];
+        unsigned above = 0;                                                   // bit j: freq[j] >= nyquist
+        float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < HPL; ++j) {
-            const int k = lane + 64 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int k = sub + 16 * j;
+            const bool dj = (dead[u] >> j) & 1;
             hd[j] = 0.0f;
             shift[j] = 0.0f;
-            freq[j] = 0.0f;
-            const bool dead = cut_first && f0 * (float)(64 * j + 1) >= p.nyquist;     // wave-uniform
-            dead_grp[j] = dead;
-            if (dead && !want_shift) continue;
-            if (k < H) {
+            if (__all(dj && !want_shift)) continue;                           // nothing to do for the four frames
+            if (k < H && (!dj || want_shift)) {
                 const float m = (float)(k + 1);
                 float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
                 g = g * inharm + 1.0f;                 //                                        :38
                 g = sqrtf(g);                          //                                        :39
                 shift[j] = g - 1.0f;                   //                                        :44  (= osc_common.h shift_from_inharm)
-                if (!dead) {
+                if (!dj) {
                     hd[j] = apply_scale(p.scale, raw_hd[u][j]);                             // :186
-                    freq[j] = (f0 * m) * g;            // f0_hz * int_multiplier * inharm_factor :42
+                    const float freq = (f0 * m) * g;   // f0_hz * int_multiplier * inharm_factor :42
+                    if (freq >= p.nyquist) above |= 1u << j;
                     sum += hd[j];
                 }
             }
         }
         if (!p.normalize_after_nyquist_cut) {                                // :194-198
-            const float tot = wave_sum(sum);
+            const float tot = row_sum(sum);
             const float den = tot == 0.0f ? 1e-7f : tot;                     // core.safe_divide
+            const float rden = 1.0f / den;
+            const bool tame = __all(den > 1e-30f && den < 1e30f);           // (else: the IEEE division, whatever it gives)
             sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < HPL; ++j) {
-                hd[j] = hd[j] / den;
+            for (int j = 0; j < NJ; ++j) {
+                hd[j] = tame ? div_const(hd[j], den, rden) : hd[j] / den;
                 sum += hd[j];
             }
         }
         if (p.normalize_below_nyquist) {                                     // :200-208
             sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < HPL; ++j) {
-                if (freq[j] >= p.nyquist) hd[j] = 0.0f;                      // core.remove_above_nyquist
+            for (int j = 0; j < NJ; ++j) {
+                if ((above >> j) & 1) hd[j] = 0.0f;                          // core.remove_above_nyquist
                 sum += hd[j];
             }
             amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
         }
         if (p.normalize_after_nyquist_cut) {                                 // :210-214
-            const float tot = wave_sum(sum);
+            const float tot = row_sum(sum);
             const float den = tot == 0.0f ? 1e-7f : tot;
+            const float rden = 1.0f / den;
+            const bool tame = __all(den > 1e-30f && den < 1e30f);
 #pragma unroll
-            for (int j = 0; j < HPL; ++j)
-                if (!dead_grp[j]) hd[j] = hd[j] / den;                       // (a cut group stays 0)
-        }
-        amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
-#pragma unroll
-        for (int j = 0; j < HPL; ++j) {
-            const int k = lane + 64 * j;
-            if (k < H) {
-                p.hd_out[frame * H + k] = hd[j];
-                if (p.shifts_out) p.shifts_out[frame * H + k] = shift[j];    // null: the oscillator kernels form them from inharm_coef
+            for (int j = 0; j < NJ; ++j) {
+                if (__all((dead[u] >> j) & 1)) continue;
+                if (!((dead[u] >> j) & 1)) hd[j] = tame ? div_const(hd[j], den, rden) : hd[j] / den;   // (a cut group stays 0)
             }
         }
-        if (p.shifts_last) {       // what the outputs dictionary of the reference's DAG keeps: the last voice's controls
-            if (is_last) {
+        amp = amp / p.n_substrings;                                          // :269 (1.0 for InHarmonic)
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = sub + 16 * j;
+                if (k < H) {
+                    p.hd_out[frame * H + k] = hd[j];
+                    if (p.shifts_out) p.shifts_out[frame * H + k] = shift[j];    // null: the oscillator kernels form them from inharm_coef
+                }
+            }
+            if (is_last) {             // what the outputs dictionary of the reference's DAG keeps: the last voice's controls
                 const unsigned b = p.vmajor ? row - last_lo : row / (unsigned)p.P;
 #pragma unroll
-                for (int j = 0; j < HPL; ++j) {
-                    const int k = lane + 64 * j;
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = sub + 16 * j;
                     if (k < H) p.shifts_last[((size_t)b * p.T + tt) * H + k] = shift[j];
                 }
             }
+            if (sub == 0) p.amp_out[frame] = amp;
         }
-        if (lane == 0) p.amp_out[frame] = amp;
         if (p.count_out) {
             // 1 + index of the last harmonic whose sample-rate amplitude amp * hd is not zero in this frame
             // (what ddspp_polyphonic_additive needs to know to skip the silent top of the harmonic range)
-            int last = 0;                                      // wave-uniform: one ballot per 64 harmonics, no shuffles
+            int last = 0;
 #pragma unroll
-            for (int j = 0; j < HPL; ++j) {
-                const int k = lane + 64 * j;
-                const unsigned long long live = __ballot(k < H && amp * hd[j] != 0.0f);
-                if (live) last = 64 * j + 64 - __builtin_clzll(live);
+            for (int j = 0; j < NJ; ++j) {
+                const int k = sub + 16 * j;
+                if (k < H && amp * hd[j] != 0.0f) last = k + 1;
             }
-            if (lane == 0) p.count_out[frame] = last;        // bit 16 is added by frames_moved_kernel
+            last = row_max(last);
+            if (live && sub == 0) p.count_out[frame] = last;        // bit 16 is added by frames_moved_kernel
         }
     }
 }
 
+// (93 registers, five wavefronts per SIMD: held to 64 registers / eight wavefronts the compiler spreads the loads out
+// between the uses and the kernel takes 370 us instead of 195; three or four passes per wavefront 215 / 250 us)
+template <int NJ, int CTL_PASS>
+__global__ void __launch_bounds__(256)
+inharmonic_controls_kernel(const InharmParams p) {
+    inharmonic_controls_body<NJ, CTL_PASS>(p);
+}
 // Bit 16 of the per-frame info word: the frame's frequencies may differ from the previous frame's (some f0 sub-string
 // or the clamped inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
 // frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.  A kernel of
@@ -319,7 +371,7 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
     p.amp_out = amplitudes_out; p.hd_out = harmonic_distribution_out; p.shifts_out = harmonic_shifts_out;
     p.count_out = audible_out;
-    DDSPP_REQUIRE(!shifts_last_out || (n_voices >= 1 && R % n_voices == 0 && (long long)R * T < (1ll << 31) && T >= CTL_FPW),
+    DDSPP_REQUIRE(!shifts_last_out || (n_voices >= 1 && R % n_voices == 0 && (long long)R * T < (1ll << 31)),
                   "inharmonic_controls: %d rows are not a whole number of %d-voice segments (or too many frames)", R, n_voices);
     p.shifts_last = shifts_last_out; p.P = n_voices; p.vmajor = voice_major;
     p.R = R; p.T = T; p.H = H; p.S = S;
@@ -328,12 +380,14 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     p.normalize_below_nyquist = normalize_below_nyquist;
     p.scale = ScaleFn{scale_kind, logf(exponent), max_value, threshold, gain};
     const size_t frames = (size_t)R * T;
-    const dim3 grid((unsigned)((frames + 4 * CTL_FPW - 1) / (4 * CTL_FPW))), block(256);
-    const int hpl = (H + 63) / 64;
-    if (hpl <= 1) hipLaunchKernelGGL(inharmonic_controls_kernel<1>, grid, block, 0, stream, p);
-    else if (hpl <= 2) hipLaunchKernelGGL(inharmonic_controls_kernel<2>, grid, block, 0, stream, p);
-    else if (hpl <= 4) hipLaunchKernelGGL(inharmonic_controls_kernel<4>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(inharmonic_controls_kernel<8>, grid, block, 0, stream, p);
+    const int nj = (H + 15) / 16;
+    const size_t per_wg = (size_t)4 * 4 * (nj <= 8 ? 2 : 1);            // four wavefronts of 4 * CTL_PASS frames
+    const dim3 grid((unsigned)((frames + per_wg - 1) / per_wg)), block(256);
+    if (nj <= 4) hipLaunchKernelGGL((inharmonic_controls_kernel<4, 2>), grid, block, 0, stream, p);
+    else if (nj <= 6) hipLaunchKernelGGL((inharmonic_controls_kernel<6, 2>), grid, block, 0, stream, p);
+    else if (nj <= 8) hipLaunchKernelGGL((inharmonic_controls_kernel<8, 2>), grid, block, 0, stream, p);
+    else if (nj <= 16) hipLaunchKernelGGL((inharmonic_controls_kernel<16, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((inharmonic_controls_kernel<32, 1>), grid, block, 0, stream, p);
     if (audible_out)
         hipLaunchKernelGGL(frames_moved_kernel, dim3(stream_grid(frames)), dim3(256), 0, stream, f0_hz, inharm_coef,
                            audible_out, R, T, S);

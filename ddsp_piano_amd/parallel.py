@@ -2,8 +2,8 @@
 
 Segments (batch rows) are independent units, so the 8 x MI355X node is used data-parallel: one process
 per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), rank r synthesises the contiguous block
-of rows shard_range(B, world, r), and the only collective is the final all-gather of the [B/G, N]
-float32 audio (18.4 MB per GPU at batch 64 x 3 s).  This mirrors what the reference does with
+of rows shard_range(B, world, r), and the only collective is the final gather of the [B/G, N]
+float32 audio (18.4 MB per GPU at batch 64 x 3 s) -- to one rank (dst) or to all of them.  This mirrors what the reference does with
 tf.distribute.MirroredStrategy + ``strategy.gather(outputs, axis=0)``
 (train_single_phase.py:88-102, evaluate_model.py:32-46) without any gradient traffic.
 """
@@ -49,23 +49,42 @@ class _Done:
         return True
 
 
-def gather_audio(local_audio, out=None, group=None, async_op=False):
-    """All-gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order).
+def gather_audio(local_audio, out=None, group=None, async_op=False, dst=None):
+    """Gather equally sized [B_local, N] audio blocks into [world * B_local, N] (rank order).
+
+    dst=None: an all-gather, every rank gets the whole batch.  dst=r: the reference's ``strategy.gather(outputs,
+    axis=0)`` (evaluate_model.py:45: ONE program holds the result) -- only rank r receives (7 x 18 MB over its seven
+    xGMI links at batch 64 x 3 s, every other rank just sends its block) and the other ranks get None.
 
     async_op=True returns (out, work): the collective runs on RCCL's own stream, so the next segment's kernels
     overlap with it; call work.wait() (a stream-level wait) before reading ``out``."""
     world = dist.get_world_size(group)
     local_audio = local_audio.contiguous()
-    if out is None:
+    receives = dst is None or dist.get_rank(group) == dst
+    if dst is not None and not 0 <= dst < world:
+        raise ValueError(f'dst={dst} outside world of size {world}')
+    if out is None and receives:
         out = torch.empty((world * local_audio.shape[0],) + tuple(local_audio.shape[1:]),
                           dtype=local_audio.dtype, device=local_audio.device)
+    if not receives:
+        out = None
     if local_audio.is_cuda and dist.get_backend(group) == 'gloo':
-        # gloo has no device all-gather: stage through the host.  Only met when several ranks share ONE GPU (RCCL refuses
+        # gloo has no device collectives: stage through the host.  Only met when several ranks share ONE GPU (RCCL refuses
         # that), i.e. the multi-rank tests and bench.py's dry run on a single-GPU box; on the node the backend is RCCL.
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather(list(host.chunk(world, dim=0)), local_audio.cpu(), group=group)
-        out.copy_(host)
+        if dst is None:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather(list(host.chunk(world, dim=0)), local_audio.cpu(), group=group)
+        else:
+            host = torch.empty(out.shape, dtype=out.dtype) if receives else None
+            dist.gather(local_audio.cpu(), list(host.chunk(world, dim=0)) if receives else None, dst=_global_rank(dst, group),
+                        group=group)
+        if receives:
+            out.copy_(host)
         return (out, _Done()) if async_op else out
+    if dst is not None:
+        work = dist.gather(local_audio, list(out.chunk(world, dim=0)) if receives else None, dst=_global_rank(dst, group),
+                           group=group, async_op=async_op)
+        return (out, work) if async_op else out
     try:
         work = dist.all_gather_into_tensor(out, local_audio, group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):
@@ -74,14 +93,20 @@ def gather_audio(local_audio, out=None, group=None, async_op=False):
     return (out, work) if async_op else out
 
 
-def gather_audio_uneven(local_audio, global_batch, group=None):
-    """All-gather when global_batch % world != 0: pad to the largest shard, gather, drop the padding."""
+def _global_rank(rank_in_group, group):
+    return rank_in_group if group is None else dist.get_global_rank(group, rank_in_group)
+
+
+def gather_audio_uneven(local_audio, global_batch, group=None, dst=None):
+    """Gather when global_batch % world != 0: pad to the largest shard, gather, drop the padding."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     biggest = max(shard_range(global_batch, world, r)[1] - shard_range(global_batch, world, r)[0]
                   for r in range(world))
     pad = biggest - local_audio.shape[0]
     x = torch.nn.functional.pad(local_audio, (0, 0, 0, pad)) if pad else local_audio
-    full = gather_audio(x, group=group)
+    full = gather_audio(x, group=group, dst=dst)
+    if full is None:
+        return None
     rows = []
     for r in range(world):
         lo, hi = shard_range(global_batch, world, r)
@@ -89,8 +114,9 @@ def gather_audio_uneven(local_audio, global_batch, group=None):
     return torch.cat(rows, dim=0)
 
 
-def synthesize_sharded(processor_group, features, group=None):
-    """features hold the GLOBAL batch on every rank; returns the global audio on every rank."""
+def synthesize_sharded(processor_group, features, group=None, dst=None):
+    """features hold the GLOBAL batch on every rank; returns the global audio on every rank (dst=None) or on rank
+    ``dst`` only (None elsewhere)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = {v.shape[0] for v in features.values() if isinstance(v, torch.Tensor) and v.dim() >= 3}
     if len(sizes) != 1:
@@ -98,8 +124,8 @@ def synthesize_sharded(processor_group, features, group=None):
     global_batch = sizes.pop()
     local = processor_group(shard_features(features, world, rank, global_batch=global_batch))
     if global_batch % world == 0:
-        return gather_audio(local, group=group)
-    return gather_audio_uneven(local, global_batch, group=group)
+        return gather_audio(local, group=group, dst=dst)
+    return gather_audio_uneven(local, global_batch, group=group, dst=dst)
 
 
 # ---- one long file over several GPUs: shard TIME (ddsp_piano synthesize_midi_file.py renders one file per call) -------

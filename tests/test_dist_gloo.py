@@ -42,6 +42,9 @@ def _worker(rank, world, port, global_batch, q):
         out2, work = parallel.gather_audio(local, buf2, async_op=True)
         work.wait()
         ok = ok and out2 is buf2 and torch.allclose(buf2, full_ref)
+    # the final gather to ONE rank (strategy.gather): rank 1 gets the batch, rank 0 only sends
+    one = parallel.synthesize_sharded(FakeGroup(), feats, dst=1)
+    ok = ok and ((one is None) if rank != 1 else (one.shape == full_ref.shape and torch.allclose(one, full_ref)))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))

@@ -54,9 +54,12 @@ out = parallel.synthesize_sharded(group(), feats)
 buf = torch.empty_like(ref)
 parallel.gather_audio(ref, buf)
 uneven = parallel.gather_audio_uneven(ref, B)
+to_one, work = parallel.gather_audio(ref, dst=0, async_op=True)      # dist.gather over RCCL
+work.wait()
 dist.barrier()
 torch.cuda.synchronize()
-res = {'same': bool(torch.equal(out, ref)), 'gather': bool(torch.equal(buf, ref)), 'uneven': bool(torch.equal(uneven, ref)),
+res = {'same': bool(torch.equal(out, ref)), 'gather': bool(torch.equal(buf, ref)) and bool(torch.equal(to_one, ref)),
+       'uneven': bool(torch.equal(uneven, ref)),
        'finite': bool(torch.isfinite(out).all()), 'shape': list(out.shape)}
 dist.destroy_process_group()
 print('RESULT ' + json.dumps(res))
@@ -126,6 +129,8 @@ for name, B in (('even', 4), ('uneven', 3)):
             return dp.ProcessorGroup(dp.polyphonic_dag(*procs(), n_synths=P, **KEYS))(f, noise=noise[lo:hi])
     out = parallel.synthesize_sharded(Local(), feats)
     res[name] = [list(out.shape) == list(ref.shape), float((out - ref).abs().max() / ref.abs().max())]
+    one = parallel.synthesize_sharded(Local(), feats, dst=world - 1)          # the final gather to one rank
+    res[name][0] = res[name][0] and ((one is None) if rank != world - 1 else bool(torch.equal(one, out)))
 # one file, time sharded: 5 blocks of 125 frames -> 3 + 2 (the 25 remainder frames go to the last rank)
 feats, noise = feats_of(1, 650, 9)
 ref = dp.ProcessorGroup(dp.polyphonic_dag(*procs(), n_synths=P, **KEYS))(feats, noise=noise)
@@ -180,4 +185,5 @@ def test_bench_two_rank_launcher_flow_on_one_gpu():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['shared_gpu'] is True and line['backend'] == 'gloo'
     assert line['config']['global_batch'] == 8 and line['value'] > 0 and line['steps'] == 3
-    assert line['allgather']['bytes_received_per_rank'] == 4 * 72000 * 4
+    assert line['allgather']['bytes_received'] == 4 * 72000 * 4 and line['gather_to_rank0']['ms'] > 0
+    assert line['gather'].startswith('to rank 0')
