@@ -308,8 +308,8 @@ def test_compacted_additive_equals_voice_stems():
 
 def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
     """Every frame's frequencies move (vibrato + glide, some partials gliding through Nyquist): the memoised pre-pass
-    scans every chunk sample by sample, four wavefronts per (row, 64 oscillators) sharing the chunks.  Same start
-    phases bit for bit as one wavefront walking the whole row, and the audio matches the oracle -- also with
+    scans every chunk sample by sample, sections of four wavefronts per (row, 64 oscillators) sharing the chunks.  Same start
+    phases bit for bit as one wavefront walking the whole row (whatever the section length), and the audio matches the oracle -- also with
     normalize_below_nyquist=False, where a partial above Nyquist keeps its amplitude in the controls and only the
     sample-rate mask of cos_oscillator_bank (inharm_synth.py:65-67) silences it."""
     import ddsp_piano_amd as dp
@@ -335,6 +335,10 @@ def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
         one = core.polyphonic_additive(*args, audible=ctl['_audible'])
         set_option(monkeypatch, 'DDSPP_OSC_PREPASS_ONE_WAVE')
         assert torch.equal(mix, one), nbn
+        for run in ('1', '2'):                         # 11 chunks in sections of 4 / 8: three and two workgroups per (row, group)
+            set_option(monkeypatch, 'DDSPP_OSC_PREPASS_RUN', run)
+            assert torch.equal(core.polyphonic_additive(*args, audible=ctl['_audible']), one), (nbn, run)
+        set_option(monkeypatch, 'DDSPP_OSC_PREPASS_RUN')
         stems = core.harmonic_synthesis_fused(*args[:4], N, sr, True).reshape(B, P, N)
         assert (mix - stems.sum(dim=1)).abs().max().item() < 5e-6, nbn
         rows = [0, 7, R - 1]                          # the oracle on a few voice rows

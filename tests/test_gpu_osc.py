@@ -191,6 +191,43 @@ def test_inharmonic_get_controls(scale, na, nb):
         np.testing.assert_allclose(got[k].cpu().numpy(), ref[k], rtol=2e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize('H,T,B,S', [(1, 1, 1, 1), (15, 3, 2, 1), (16, 9, 5, 2), (17, 7, 3, 1), (48, 26, 4, 1), (96, 13, 6, 2),
+                                      (100, 5, 2, 1), (129, 11, 3, 1), (200, 6, 2, 2), (300, 4, 3, 1), (512, 2, 2, 1)])
+def test_inharmonic_get_controls_shapes_counts_and_last_voice(H, T, B, S):
+    """The get_controls kernel (one DPP row of 16 lanes per frame, harmonics in steps of 16, groups of 16 above Nyquist
+    skipped whole) over harmonic counts that are not multiples of 16, rows shorter than a wavefront's eight frames,
+    frame counts that leave the last wavefront half empty -- every flag combination against the oracle; the per-frame
+    audible counts against the definition (1 + the last harmonic whose amp * hd is not zero); and the group form:
+    harmonic_shifts of every segment's last voice only, both row layouts."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(H * 31 + T)
+    sr = 16000
+    raw = synth_controls(rng, B, T, H, S=S, midi_lo=30, midi_hi=108)
+    dev = {k: _dev(v) for k, v in raw.items()}
+    order = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    for na in (True, False):
+        for nb in (True, False):
+            kw = dict(sample_rate=sr, normalize_after_nyquist_cut=na, normalize_below_nyquist=nb)
+            ref = O.MultiInharmonic(scale_fn=O.exp_sigmoid, **kw).get_controls(**raw)
+            syn = dp.MultiInharmonic(scale_fn=dp.exp_sigmoid, **kw)
+            got = syn._controls(*[dev[k] for k in order], want_counts=True)
+            assert np.array_equal(got['harmonic_shifts'].cpu().numpy(), ref['harmonic_shifts'])
+            hd, amp = got['harmonic_distribution'].cpu().numpy(), got['amplitudes'].cpu().numpy()
+            np.testing.assert_allclose(hd, ref['harmonic_distribution'], rtol=2e-5, atol=1e-9)
+            np.testing.assert_allclose(amp, ref['amplitudes'], rtol=2e-5, atol=1e-9)
+            assert ((ref['harmonic_distribution'] == 0) == (hd == 0)).all()              # the cut is the reference's cut
+            live = (amp * hd) != 0
+            want = np.where(live.any(-1), H - np.argmax(live[..., ::-1], axis=-1), 0)
+            assert np.array_equal(got['_audible'].cpu().numpy() & 0xffff, want), (na, nb)
+            for P in (1, B):                            # rows = [B / P segments, P voices] (or voice major)
+                for vm in (False, True):
+                    grp = syn._controls(*[dev[k] for k in order], want_counts=True, want_shifts=False, last_voice_of=(P, vm))
+                    assert torch.equal(grp['harmonic_distribution'], got['harmonic_distribution'])
+                    assert torch.equal(grp['_audible'], got['_audible'])
+                    rows = np.arange(B).reshape(P, B // P)[-1] if vm else np.arange(B).reshape(B // P, P)[:, -1]
+                    assert np.array_equal(grp['_shifts_last'].cpu().numpy(), ref['harmonic_shifts'][rows]), (P, vm)
+
+
 def test_custom_python_scale_fn():
     import ddsp_piano_amd as dp
     rng = np.random.default_rng(8)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one bench input case a few times (for rocprofv3 --kernel-trace --stats).
-usage: python tools/trace_case.py [headline|moving|dense] [audio|dict] [reps]"""
+usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22] [audio|dict] [reps]"""
 import os
 import sys
 
@@ -16,7 +16,11 @@ form = sys.argv[2] if len(sys.argv) > 2 else 'dict'
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device('cuda', 0)
 B, P, T, H, K, S, L, sr = 64, 16, 750, 128, 96, 1, 72000, 24000
-kw = {'headline': {}, 'moving': dict(vibrato=0.002),
+if case == 'c5':            # BASELINE config 5's per-GPU share (bench.py: c5_per_gpu_share)
+    B, P, H, K, S, sr, L = 32, 32, 128, 96, 1, 48000, 480000
+elif case == 'dafx22':      # configs/dafx22.gin dims (bench.py: dafx22_dims)
+    B, P, H, K, S, sr, L = 64, 16, 96, 64, 2, 16000, 24000
+kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {},
       'dense': dict(silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)}[case]
 feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
 pg = bench.build_group(dp, P, sr)
