@@ -16,6 +16,8 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
                      [rows, N, H] envelopes of the same workload, against 8 TB/s;
   * roofline_step  : the timed step's own dominant call (the compacted oscillator bank, VALU bound): live
                      HIP-event time against the VALU issue ceiling, instruction counts from profiles/;
+  * roofline_noise : the step's second large call, FilteredNoise: live time against the issue time of its useful
+                     multiply-adds (samples x taps) and of all its VALU instructions (counts from profiles/);
   * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
                      TF/ddsp reference here) and an op-by-op torch-CPU version on all cores, timed on this host;
   * value          : global batch x samples / MEDIAN of the per-step device times (every step bracketed by HIP events
@@ -334,6 +336,51 @@ def measure_roofline_step(dp, base, args, T, U, device):
     return out
 
 
+def measure_roofline_noise(dp, base, args, T, U, device):
+    """The step's second large kernel, FilteredNoise (the fused design + time-varying FIR kernel: VALU bound).  Live HIP-
+    event time of the call as the batched group makes it (voice sums of 8, the last voice kept apart, scale_fn inside),
+    against the issue time of (a) its USEFUL multiply-adds -- samples x taps of the windowed impulse response, what any
+    direct-form implementation has to issue -- and (b) every VALU instruction the kernel executes (profiles/step_valu.json,
+    dropped when that file describes another build)."""
+    from ddsp_piano_amd import core
+    B, P = base['f0_hz'].shape[:2]
+    K = base['magnitudes'].shape[-1]
+    N, R = T * U, B * P
+    synth = dp.DynamicSizeFilteredNoise(sample_rate=args.sample_rate, frame_rate=250)
+    mags = base['magnitudes'].reshape(R, T, K)
+    x = core.uniform_noise((R, N), seed=7, device=device)
+    vq = next(v for v in (8, 4, 2, 1) if P % v == 0)
+    rs = synth.raw_scale()
+
+    def launch():
+        if vq > 1 and core.frequency_filter_voice_sums(x, mags, synth.window_size, rs, P, vq, False, split_last=True) is not None:
+            return
+        core.frequency_filter(x, mags, window_size=synth.window_size, raw_scale=rs)
+
+    ts = event_times(launch, 10, warmup=2)
+    t = float(np.median(ts)) * 1e-3
+    taps = 2 * (K - 1) if synth.window_size <= 0 else min(synth.window_size, 2 * (K - 1))        # windowed impulse response
+    useful = R * N * float(taps) / 64.0                                   # wave64 FMAs
+    peak = N_SIMDS * MAX_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
+    out = {'bound': 'valu', 'call': 'FilteredNoise: frequency_filter over all voices (fused design + time-varying FIR)',
+           'ms_per_call': t * 1e3, 'ms_min': float(np.min(ts)), 'unit': 'wave64 VALU instructions/s', 'peak': peak,
+           'peak_note': '1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction',
+           'useful_fma_wave_instructions': useful, 'taps': int(taps), 'frac_useful': useful / t / peak}
+    pf = os.path.join(ROOT, 'profiles', 'step_valu.json')
+    if os.path.exists(pf):
+        try:
+            prof = json.load(open(pf))
+            out['counters_stale'] = prof.get('csrc_hash') != dp._lib.source_hash()
+            nz = prof.get('noise')
+            if nz and not out['counters_stale']:
+                out.update({'valu_wave_instructions': nz['valu'], 'fma_wave_instructions': nz['fma'],
+                            'mfma_mops': nz.get('mfma_mops'), 'lds_instructions': nz.get('lds'),
+                            'achieved': nz['valu'] / t, 'frac': nz['valu'] / t / peak, 'kernels': nz.get('kernels')})
+        except Exception:  # noqa: BLE001
+            pass
+    return out
+
+
 def measure_cpu_baseline(args, T, U):
     """The oracle (float32-faithful numpy restatement of the TF/ddsp reference -- TF itself cannot be
     installed here) on a bounded sample of the same workload: whole 3 s, poly-16 segments, one
@@ -634,11 +681,12 @@ def main():
         extra['whole_file'] = {'workload': f'B=1 x {Tw / 250:g} s in one segment, poly={P}, 2 s IR',
                                'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
         del fw, pgw, f1, pg1
-    roof = roof_step = None
+    roof = roof_step = roof_noise = None
     if rank == 0 and not args.no_roofline:
         del feats
         torch.cuda.empty_cache()
         roof_step = measure_roofline_step(dp, base, args, T, U, device)
+        roof_noise = measure_roofline_noise(dp, base, args, T, U, device)
         roof = measure_roofline(dp, base, args, T, U, device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -646,7 +694,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    stale = [r.get('counters_stale') for r in (roof, roof_step) if r]
+    stale = [r.get('counters_stale') for r in (roof, roof_step, roof_noise) if r]
     if rank == 0:
         line = {
             'metric': 'audio samples/sec synthesized (24 kHz, poly=16), full chain; real-time factor in rtf',
@@ -664,7 +712,7 @@ def main():
                                     if want_dict else 'processor_group(features)',
                        'global_batch': world * B, 'segment_samples': N, 'parallelism': f'batch-shard x{world}'
                                                                                        + (' + one gather of the audio per step (inside the timed step; overlapped with the next step in `pipelined`)' if world > 1 else '')},
-            'roofline': roof, 'roofline_step': roof_step, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_step': roof_step, 'roofline_noise': roof_noise, 'cpu_baseline': cpu,
             'counters_stale': (any(bool(x) for x in stale) if stale else None),
         }
         line.update(extra)

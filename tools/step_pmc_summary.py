@@ -76,9 +76,16 @@ def main(out):
         trans = sum(ctr[k].get('SQ_INSTS_VALU_TRANS_F32', 0.0) for k in add_kernels)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from ddsp_piano_amd import _lib
+        # ... and of the FilteredNoise kernel(s) (roofline_noise)
+        nz = [k for k in ctr if k.startswith(('noise_win_fused', 'noise_fir_fused', 'tv_fir', 'fir_design'))]
+        noise = {name: sum(ctr[k].get(c, 0.0) for k in nz) for name, c in
+                 (('valu', 'SQ_INSTS_VALU'), ('fma', 'SQ_INSTS_VALU_FMA_F32'), ('trans', 'SQ_INSTS_VALU_TRANS_F32'),
+                  ('mfma_mops', 'SQ_INSTS_VALU_MFMA_MOPS_F32'), ('lds', 'SQ_INSTS_LDS'))}
+        noise['kernels'] = nz
         json.dump({'csrc_hash': _lib.source_hash(),
                    'valu_wave_instructions_per_call': tot, 'valu_trans_wave_instructions_per_call': trans,
                    'kernels': {k: ctr[k].get('SQ_INSTS_VALU', 0.0) for k in add_kernels},
+                   'noise': noise,
                    'source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_TRANS_F32 over bench.py --steps 3 --warmup 1 (tools/step_pmc.sh), '
                              'per-launch averages of the kernels of ddspp_polyphonic_additive at BASELINE config 3'},
                   open(os.path.join(out, 'step_valu.json'), 'w'), indent=1)
