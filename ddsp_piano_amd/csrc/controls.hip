@@ -10,23 +10,12 @@
 
 namespace ddspp {
 
-// Sum over the 64 lanes, the same value returned to all of them: four in-row steps on the DPP data path (quad swaps,
-// half-row and row mirrors) leave every lane with its row's sum, the four row sums are then read as scalars and added.
-// (Six ds_bpermute round trips -- what __shfl_xor compiles to -- were a dependent chain of LDS latencies in every
-// frame of this kernel.)
+// DPP data-path moves within a row of 16 lanes (quad swaps, half-row and row mirrors): four of them leave every lane of
+// a row with the row's sum.  (ds_bpermute round trips -- what __shfl_xor compiles to -- were a dependent chain of LDS
+// latencies in every frame of the get_controls kernel.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_take(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_take<0xB1>(v);        // quad_perm [1,0,3,2]
-    v += dpp_take<0x4E>(v);        // quad_perm [2,3,0,1]
-    v += dpp_take<0x141>(v);       // row_half_mirror
-    v += dpp_take<0x140>(v);       // row_mirror: every lane holds its row's sum
-    const int vi = __float_as_int(v);             // (the builtin takes an int: a float argument would be CONVERTED)
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
-    return (r0 + r1) + (r2 + r3);
 }
 
 struct InharmParams {

@@ -190,8 +190,6 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     DDSPP_REQUIRE(workspace_bytes >= g->total, "group_run: workspace too small (%zu < %zu)", workspace_bytes, g->total);
     DDSPP_REQUIRE((uintptr_t)workspace % 256 == 0, "group_run: workspace must be 256-byte aligned");
     DDSPP_REQUIRE(!g->plan == !reverb_ir, "group_run: reverb_ir %s", g->plan ? "is missing" : "given, but the group has no reverb");
-    DDSPP_REQUIRE(!(outputs && outputs->harmonic_shifts_last && g->c.n_frames < 4),
-                  "group_run: harmonic_shifts_last needs at least 4 frames");
     const ddspp_group_config& c = g->c;
     const int B = c.n_segments, P = c.n_voices, T = c.n_frames, H = c.n_harmonics, S = c.n_substrings, K = c.n_bands,
               U = c.upsampling, R = g->R, N = g->N, vm = c.voice_major ? 1 : 0, vpr = g->vpr;
@@ -260,7 +258,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     // ---- get_controls of the additive processor over all rows (inharm_synth.py:167-219, :254-270) -------------------
     float* shifts_last = want ? (outputs->harmonic_shifts_last ? outputs->harmonic_shifts_last : (float*)(ws + g->o_shl)) : nullptr;
     rc = ddspp_inharmonic_controls_group(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amp_c, hd_c,
-                                         (want && T >= 4) ? shifts_last : nullptr, aud, R, T, H, S, P, vm, c.sample_rate,
+                                         want ? shifts_last : nullptr, aud, R, T, H, S, P, vm, c.sample_rate,
                                          c.min_frequency, c.scale_kind, c.exponent, c.max_value, c.threshold, c.gain,
                                          c.normalize_after_nyquist_cut, c.normalize_below_nyquist, stream);
     if (rc != DDSPP_OK) return leave(rc);

@@ -550,7 +550,6 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     const int grp = gs / nsec, sec = gs - grp * nsec;
     const int T = p.T, U = p.U, H = p.H, S = p.S, N = p.N;
     const int vbase = grp * p.vgrp, vlast = min(vbase + p.vgrp, p.V) - 1;
-    typedef const __attribute__((address_space(4))) float* cfloat_p;
     // LDS: one PRE_W-float weight buffer per wavefront
     float* wlds = lds_dyn + (size_t)(threadIdx.x >> 6) * PRE_W;
 
@@ -1289,14 +1288,6 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, false>), dim3(nblk_main), blk, lds, stream,
                                p);
     }
-}
-
-static unsigned stream_grid(size_t total) {
-    size_t blocks = (total + 255) / 256;
-    const size_t cap = 256 * 16;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (unsigned)blocks;
 }
 
 template <bool FUSED>

@@ -154,7 +154,7 @@ class NativeGroup:
                 return torch.empty(shape, dtype=torch.float32, device=dev)
             outs = dict(dry=new(B, N), prev=new(B, N) if P > 1 else None, additive_last=new(B, N), noise_last=new(B, N),
                         amplitudes_last=new(B, T, 1), harmonic_distribution_last=new(B, T, H),
-                        harmonic_shifts_last=new(B, T, H) if T >= 4 else None, magnitudes_last=new(B, T, K))
+                        harmonic_shifts_last=new(B, T, H), magnitudes_last=new(B, T, K))
             o = _Outputs(**{k: (v.data_ptr() if v is not None else None) for k, v in outs.items()})
         _lib.check(self._lib.ddspp_group_run(self._h, _ptr(amp), _ptr(hd), _ptr(inh), _ptr(f0), _ptr(mags), _ptr(ir),
                                              _ptr(z), _ptr(audio), ctypes.byref(o) if o is not None else None,
@@ -167,8 +167,6 @@ class NativeGroup:
             return (x.reshape((P, B) + shape).transpose(0, 1) if vm else x.reshape((B, P) + shape))[:, last]
         add, nz, mix = plan.additive, plan.noise, plan.add
         shifts = outs['harmonic_shifts_last']
-        if shifts is None:
-            shifts = core.get_inharmonic_freq(voice(f0, (T, S))[..., :1], voice(inh, (T, 1)).clamp(min=0.0), H)[1]
         outputs = {'inputs': features}
         outputs.update(features)
         outputs[add.name] = {'signal': outs['additive_last'],

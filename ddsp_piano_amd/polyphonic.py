@@ -234,7 +234,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     # --- additive branch ------------------------------------------------------------------------
     # compacted route: harmonic_shifts are never written (the bank forms them from inharm_coef per lane and frame)
     ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
-                             last_voice_of=(P, vm) if (want_last and T >= 4) else None)
+                             last_voice_of=(P, vm) if want_last else None)
     additive_last = None
     if compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
@@ -301,8 +301,6 @@ def run(plan, inputs, noise=None, need_stems=True):
             lc = {k: voice(ctl[k], sh) for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
                                                      ('f0_hz', (T, S)))}
             lc['harmonic_shifts'] = ctl['_shifts_last']       # written by the get_controls kernel for the last voice only
-            if lc['harmonic_shifts'] is None:                 # (fewer than four frames: the same float32 ops through torch)
-                lc['harmonic_shifts'] = core.get_inharmonic_freq(lc['f0_hz'][..., :1], voice(inh, (T, 1)).clamp(min=0.0), H)[1]
             mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}

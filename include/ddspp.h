@@ -410,7 +410,7 @@ typedef struct {
     float* noise_last;                   /* [B, N]  noise/signal */
     float* amplitudes_last;              /* [B, T]    additive/controls/amplitudes */
     float* harmonic_distribution_last;   /* [B, T, H] additive/controls/harmonic_distribution */
-    float* harmonic_shifts_last;         /* [B, T, H] additive/controls/harmonic_shifts (T >= 4) */
+    float* harmonic_shifts_last;         /* [B, T, H] additive/controls/harmonic_shifts */
     float* magnitudes_last;              /* [B, T, K] noise/controls/magnitudes */
 } ddspp_group_outputs;
 /* sizeof the two structs above in this build of the library (a binding in another language checks its declaration) */

@@ -65,7 +65,8 @@ def _same(a, b, path=''):
     (3, 2, 3, 90, 96, 64, 2, 64, False, 3000, None), (4, 5, 3, 50, 96, 64, 1, 64, True, 0, None),
     (5, 4, 1, 40, 64, 32, 1, 128, False, 1000, None), (6, 2, 6, 75, 48, 32, 1, 32, False, 2000,
                                                        dict(scale='exp_tanh', normalize_after_nyquist_cut=False)),
-    (7, 17, 16, 33, 128, 96, 1, 96, True, 1500, None)])
+    (7, 17, 16, 33, 128, 96, 1, 96, True, 1500, None), (8, 2, 3, 3, 64, 32, 1, 128, False, 500, None),
+    (9, 3, 2, 2, 96, 96, 1, 96, True, 300, None)])          # (three frames, two frames: the last voice's harmonic_shifts too)
 def test_native_group_equals_the_python_route(seed, B, P, T, H, K, S, U, vm, L, flags):
     dp, group, feats, _, noise, sr = _setup(seed, B, P, T, H, K, S, U, vm, L, flags)
     z = torch.as_tensor(noise, device='cuda')
