@@ -139,6 +139,7 @@ __device__ __forceinline__ void inharmonic_controls_body(const InharmParams& p) 
             hd[j] = 0.0f;
             shift[j] = 0.0f;
             if (__all(dj && !want_shift)) continue;                           // nothing to do for the four frames
+            if (NJ > 8) __builtin_amdgcn_sched_barrier(0);                    // (wide rows: one group after the other, see below)
             if (k < H && (!dj || want_shift)) {
                 const float m = (float)(k + 1);
                 float g = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
@@ -375,6 +376,7 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     if (nj <= 4) hipLaunchKernelGGL((inharmonic_controls_kernel<4, 2>), grid, block, 0, stream, p);
     else if (nj <= 6) hipLaunchKernelGGL((inharmonic_controls_kernel<6, 2>), grid, block, 0, stream, p);
     else if (nj <= 8) hipLaunchKernelGGL((inharmonic_controls_kernel<8, 2>), grid, block, 0, stream, p);
+    else if (nj <= 12) hipLaunchKernelGGL((inharmonic_controls_kernel<12, 1>), grid, block, 0, stream, p);
     else if (nj <= 16) hipLaunchKernelGGL((inharmonic_controls_kernel<16, 1>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((inharmonic_controls_kernel<32, 1>), grid, block, 0, stream, p);
     if (audible_out)

@@ -137,9 +137,9 @@ __device__ __forceinline__ void win_store_x(float* __restrict__ Xs, int nblk, in
 // TRACE (tools/ubench/noise_win_trace.hip only): every wavefront of the first workgroups writes the clock at its phase
 // boundaries to `trace`.
 constexpr int WIN_TRACE_WGS = 64, WIN_TRACE_UNITS = 8, WIN_TRACE_MARKS = 8;
-template <int KH, int JT, int OPL, int BPF, bool TRACE = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
+template <int KH, int JT, int OPL, int BPF, bool TRACE>
+__device__ __forceinline__ void
+noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                        const float* __restrict__ mags,       // [R, T, 2 KH]
                        const float* __restrict__ CE, const float* __restrict__ CO,     // [KH, NJ]
                        const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
@@ -147,7 +147,7 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
                        float* __restrict__ out,              // [R / vq, N]
                        float* __restrict__ out_last,         // [R / n_voices, N] or null
                        int R, int N, int T, int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices,
-                       int vmajor, int tpw, int dbg, long long* __restrict__ trace = nullptr) {
+                       int vmajor, int tpw, int dbg, long long* __restrict__ trace) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int K = 2 * KH, KS = KH / 4, D = WIN_D, U = 4 * BPF, NP = U / OPL, NPASS = (NP + 7) / 8;
     constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
@@ -370,6 +370,28 @@ noise_win_fused_kernel(const float* __restrict__ x,          // [R, N] noise
     }
 }
 
+// Three workgroups per CU (168 registers) for the shapes whose LDS allows it; K = 128 (70 KB of LDS: two workgroups per CU)
+// gets the registers of two wavefronts per SIMD instead.
+#define DDSPP_WIN_KERNEL_ARGS                                                                                          \
+    const float* __restrict__ x, const float* __restrict__ mags, const float* __restrict__ CE,                         \
+    const float* __restrict__ CO, const int* __restrict__ tap_idx, const float* __restrict__ tap_we,                   \
+    const float* __restrict__ tap_wo, float* __restrict__ out, float* __restrict__ out_last, int R, int N, int T,     \
+    int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices, int vmajor, int tpw, int dbg,                 \
+    long long* __restrict__ trace
+template <int KH, int JT, int OPL, int BPF, bool TRACE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+noise_win_fused_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
+    noise_win_fused_body<KH, JT, OPL, BPF, TRACE>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias,
+                                                  scale, vq, n_voices, vmajor, tpw, dbg, trace);
+}
+template <int KH, int JT, int OPL, int BPF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+noise_win_fused_w2_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
+    noise_win_fused_body<KH, JT, OPL, BPF, false>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias,
+                                                  scale, vq, n_voices, vmajor, tpw, dbg, trace);
+}
+#undef DDSPP_WIN_KERNEL_ARGS
+
 // ------------------------------------------------------------------------------------------------
 // The two-call form's second half (impulse responses [R, T, Lw] from HBM): same layout, same walk.
 // ------------------------------------------------------------------------------------------------
@@ -431,6 +453,7 @@ static int ceildiv(int a, int b) { return -floordiv(-a, b); }
 
 int win_opl_for(int U) {
     switch (U) {
+        case 32: return 4;
         case 64: return 8;
         case 96: return 12;
         case 128: return 16;
@@ -473,8 +496,9 @@ bool win_fused_supported(int N, int T, int K, int Lw, int delay, WinGeom* g) {
     const int U = g->U;
     // (U = 192 at K = 96 -- two passes of eight phases, 24 noise registers -- does not fit the 168-register budget: the
     // round-2 kernel keeps that shape, as it keeps every hop this file has no instance for)
-    const bool inst = (K == 96 && U == 96) || (K == 64 && (U == 64 || U == 96)) || (K == 32 && U == 128);
-    return inst && win_lds_bytes(*g, K) <= 64 * 1024;
+    const bool inst = (K == 96 && U == 96) || (K == 64 && (U == 64 || U == 96)) || (K == 32 && (U == 128 || U == 32)) ||
+                      (K == 128 && U == 128);
+    return inst && win_lds_bytes(*g, K) <= 80 * 1024;          // (two workgroups per CU at least)
 }
 
 bool win_tvfir_supported(int N, int T, int Lw, int delay, WinGeom* g) {
@@ -503,6 +527,17 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     else if (K == 64 && U == 64) DDSPP_WIN_LAUNCH(32, 2, 8, 16);
     else if (K == 64 && U == 96) DDSPP_WIN_LAUNCH(32, 2, 12, 24);
     else if (K == 32 && U == 128) DDSPP_WIN_LAUNCH(16, 1, 16, 32);
+    else if (K == 32 && U == 32) DDSPP_WIN_LAUNCH(16, 1, 4, 8);                 // ENSTDkCl-8kHz.gin
+    else if (K == 128 && U == 128) {                                           // ENSTDkCl-32kHz.gin: 70 KB of LDS
+        static bool raised = false;
+        if (!raised) {
+            DDSPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&noise_win_fused_w2_kernel<64, 4, 16, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL((noise_win_fused_w2_kernel<64, 4, 16, 32>), grid, block, lds, stream, audio, magnitudes, CE, CO,
+                           tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw, dbg);
+    }
     else DDSPP_REQUIRE(false, "frequency_filter_eo: no windowed kernel for K=%d U=%d", K, U);
 #undef DDSPP_WIN_LAUNCH
     DDSPP_LAUNCH_CHECK();
@@ -518,6 +553,7 @@ int launch_win_tvfir(const float* audio, const float* ir, float* out, int R, int
 #define DDSPP_WIN_LAUNCH(OPL, BPF) \
     hipLaunchKernelGGL((tv_fir_win_kernel<OPL, BPF>), grid, block, lds, stream, audio, ir, out, R, N, T, Lw, g)
     switch (g.U) {
+        case 32: DDSPP_WIN_LAUNCH(4, 8); break;
         case 64: DDSPP_WIN_LAUNCH(8, 16); break;
         case 96: DDSPP_WIN_LAUNCH(12, 24); break;
         case 128: DDSPP_WIN_LAUNCH(16, 32); break;

@@ -69,7 +69,9 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     # shapes the fused FilteredNoise kernel takes / refuses (host-side geometry, no launch)
     assert lib.ddspp_frequency_filter_eo_supported(72000, 750, 96, 190, -1) == 1       # 24 kHz, maestro-v2
     assert lib.ddspp_frequency_filter_eo_supported(48000, 750, 64, 126, -1) == 1       # 16 kHz, dafx22 (round 3: the windowed kernel)
-    assert lib.ddspp_frequency_filter_eo_supported(24000, 750, 32, 62, -1) == 0        # 8 kHz: hop 32, two-call form
+    assert lib.ddspp_frequency_filter_eo_supported(24000, 750, 32, 62, -1) == 1        # 8 kHz, ENSTDkCl-8kHz (hop 32)
+    assert lib.ddspp_frequency_filter_eo_supported(96000, 750, 128, 254, -1) == 1      # 32 kHz, ENSTDkCl-32kHz (two workgroups per CU)
+    assert lib.ddspp_frequency_filter_eo_supported(30000, 750, 32, 62, -1) == 0        # hop 40: no instance, two-call form
     assert lib.ddspp_frequency_filter_eo_supported(72000, 750, 96, 100, -1) == 0       # cropped window
     assert lib.ddspp_frequency_filter_eo_supported(72001, 750, 96, 190, -1) == 0
     rc = lib.ddspp_frequency_filter_eo(null, one, one, one, one, one, one, one, 4, 72000, 750, 96, 190, 48, -1, 1,
@@ -78,7 +80,7 @@ def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     rc = lib.ddspp_frequency_filter_eo_voices(one, one, one, one, one, one, one, one, null, 32, 72000, 750, 96, 190, 48, -1,
                                               1, -5.0, 10.0, 2.0, 1e-7, 1.0, 16, 3, 0, null)      # 3 does not divide 16
     assert rc == _lib.DDSPP_EINVAL and b'voices' in lib.ddspp_last_error()
-    rc = lib.ddspp_frequency_filter_eo(one, one, one, one, one, one, one, one, 4, 24000, 750, 32, 62, 16, -1, 1,
+    rc = lib.ddspp_frequency_filter_eo(one, one, one, one, one, one, one, one, 4, 30000, 750, 32, 62, 16, -1, 1,
                                        -5.0, 10.0, 2.0, 1e-7, 1.0, null)
     assert rc == _lib.DDSPP_EINVAL and b'not supported' in lib.ddspp_last_error()
     assert lib.ddspp_fftconv_transform_ir(null, one, 1, one, 0, null) == _lib.DDSPP_EINVAL
