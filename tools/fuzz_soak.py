@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_gpu_fuzz as F  # noqa: E402
+import test_gpu_native_group as G  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -28,7 +29,7 @@ while time.time() - t0 < budget:
     B = int(rng.choice([1, 2, 3, 5, 16, 20]))
     T = int(rng.integers(8, 200)) if B * P > 64 else int(rng.integers(8, 600))
     seed = int(rng.integers(1, 1 << 30))
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
     try:
         if kind == 0:
             args = (seed, B, P, T, H, S, U, FLAGS[int(rng.integers(0, len(FLAGS)))])
@@ -37,6 +38,12 @@ while time.time() - t0 < budget:
             K = {32: 32, 64: 64, 96: 96, 128: 96, 192: 96}[U] if rng.random() < 0.7 else int(rng.choice([32, 64, 65, 96, 128]))
             args = (seed, min(B, 5), P, min(T, 200), H, K, S, U, bool(rng.integers(0, 2)))
             F.test_batched_group_equals_the_node_by_node_walk(*args)
+        elif kind == 3:                        # the one-call C driver against the Python route
+            K = int(rng.choice([32, 64, 96, 128]))
+            flags = None if rng.random() < 0.6 else dict(scale='exp_tanh', normalize_after_nyquist_cut=False)
+            args = (seed, min(B, 5), P, max(2, min(T, 150)), H, K, S, U, bool(rng.integers(0, 2)),
+                    int(rng.choice([0, 500, 3000, 9000])), flags)
+            G.test_native_group_equals_the_python_route(*args)
         else:
             K = {32: 32, 64: 64, 96: 96, 128: 96, 192: 96}[U]
             if U == 192:
