@@ -15,6 +15,7 @@ struct OscParams {
     const float* __restrict__ shifts;  // [R, T, H] (may be null: no shifts, or shifts from `inh`)
     const float* __restrict__ inh;     // [R, T] raw inharm_coef: with shifts == null the kernels form harmonic_shifts themselves
     const int* __restrict__ audible;   // [R, T] leading non-silent harmonics per frame (pre-pass: may be null)
+    const int* __restrict__ rowmax;    // [R] max over the frames of a row of `audible` (low 16 bits), or null: the kernels reduce it themselves
     int dbg_noflags;                   // DDSPP_OSC_NO_FLAGS=1: ignore bit 16 of audible, stream the controls instead (A/B switch)
     const float* __restrict__ wlin;    // [N]   legacy-bilinear interpolation weight per sample
     const float* __restrict__ whann;   // [2U]  tf.signal.hann_window(2U)

@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
 #pragma unroll
     for (int j = 0; j < VPL; ++j) need[j] = true;
     if (p.audible && !p.need_all) {
-        const int amax = row_audible_max(p.audible + (size_t)row * T, T, lane);
+        const int amax = p.rowmax ? p.rowmax[row] : row_audible_max(p.audible + (size_t)row * T, T, lane);
         bool any_needed = false;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
@@ -937,21 +937,52 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
     for (int j = 0; j < VPL; ++j) p.ework[((size_t)row * p.npre + chunk) * p.VP + vidx[j]] = mod_2pi(ph[j]);
 }
 
+// rowmax[row] = max over the frames of a row of the per-frame audible-harmonic counts: what the pre-pass and the scans
+// behind it ask before they touch a 64-oscillator group ("is any of it ever heard?").  One workgroup per row: asked by
+// every wavefront of a 136 s row (34 000 frames) it was 45 memory round trips each.
+__global__ void __launch_bounds__(256) osc_row_max_kernel(const int* __restrict__ audible, int* __restrict__ rowmax,
+                                                        int T) {
+    __shared__ int part[4];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int* aud = audible + (size_t)row * T;
+    int amax = 0;
+    for (int t0 = wib * 64 + lane; t0 < T; t0 += 256 * 16) {
+        int a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = aud[min(t0 + 256 * u, T - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) amax = max(amax, a[u] & 0xffff);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o));
+    if (lane == 0) part[wib] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) rowmax[row] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
 // Sequential (float32) scan of the chunk end phases: astart[row, span, v] = e[0] + ... + e[c0-1]
-// in exactly the order of `tf.cumsum(offsets, axis=1)` in ddsp.core.angular_cumsum.
-// The adds of one (row, oscillator) are a serial chain, the loads are not: a workgroup owns 64 oscillators of a
-// row, its four wavefronts fetch the next SCAN_CT chunks x 64 values into registers (all loads in flight) while
-// wavefront 0 adds up the current tile out of LDS.  (A thread per chain with its own loads took 0.38 ms for a
-// 136 s file: sixteen rows are twelve wavefronts, each paying the memory latency two hundred times.)
+// in exactly the order of `tf.cumsum(offsets, axis=1)` in ddsp.core.angular_cumsum -- for LONG rows (a whole file as one
+// segment: thousands of chunks).  The adds of one (row, oscillator) are a serial chain, the loads and stores are not: a
+// workgroup owns 64 oscillators of a row, its four wavefronts fetch the next SCAN_CT chunks x 64 values into registers
+// (all loads in flight) while wavefront 0 turns the current tile in LDS into running sums IN PLACE, and all four then
+// store the span starts of the tile.  (A thread per chain with its own loads took 0.38 ms for a 136 s file: sixteen rows
+// are twelve wavefronts, each paying the memory latency two hundred times; with wavefront 0 also issuing the 3 263 stores
+// of its chain one after the other, 0.24 ms.)  Groups no partial of which is audible anywhere in the call are left out
+// (p.audible / p.rowmax given, need_all not set): nothing reads their start phases.
 constexpr int SCAN_CT = 256;           // chunks per tile: 64 KB of LDS, 64 registers per thread
 __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __restrict__ ework,
-                                                            float* __restrict__ astart, int R,
-                                                            int npre, int VP, int spans, int cps,
-                                                            const float* __restrict__ state_in, int V) {
+                                                            float* __restrict__ astart, const OscParams p) {
     __shared__ float tile[SCAN_CT * 64];
+    const int R = p.R, npre = p.npre, VP = p.VP, spans = p.spans, cps = p.cps;
+    (void)R;
     const int groups = VP / 64;
     const int row = blockIdx.x / groups, v0 = (blockIdx.x - row * groups) * 64;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if (p.audible && !p.need_all) {
+        const int amax = p.rowmax ? p.rowmax[row] : row_audible_max(p.audible + (size_t)row * p.T, p.T, lane);
+        const int v = v0 + lane;
+        if (!__any(v < p.V && v % p.H < amax)) return;        // (the same for every wavefront of the workgroup)
+    }
     constexpr int PER = SCAN_CT / 4;                      // chunks each wavefront fetches per tile
     float pre[PER];
     auto fetch = [&](int c0) {
@@ -962,8 +993,7 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
         }
     };
     fetch(0);
-    float a = (state_in && v0 + lane < V) ? state_in[(size_t)row * V + v0 + lane] : 0.0f;
-    int span = 0, until = 0;                              // chunks left before the next span starts
+    float a = (p.state_in && v0 + lane < p.V) ? p.state_in[(size_t)row * p.V + v0 + lane] : 0.0f;
     float* dst = astart + (size_t)row * spans * VP + v0 + lane;
     for (int c0 = 0; c0 <= npre; c0 += SCAN_CT) {
 #pragma unroll
@@ -971,24 +1001,45 @@ __global__ void __launch_bounds__(256) osc_offset_scan_kernel(const float* __res
         __syncthreads();
         if (c0 + SCAN_CT <= npre) fetch(c0 + SCAN_CT);     // in flight while wavefront 0 scans
         if (wib == 0) {
-            for (int u0 = 0; u0 < SCAN_CT; u0 += 16) {
-                float e[16];
+            if (c0 + SCAN_CT <= npre) {                    // a full tile: no bound to test per chunk
+                for (int u0 = 0; u0 < SCAN_CT; u0 += 16) {
+                    float e[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) e[u] = tile[(u0 + u) * 64 + lane];
-                if (c0 + u0 > npre) break;
+                    for (int u = 0; u < 16; ++u) e[u] = tile[(u0 + u) * 64 + lane];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int c = c0 + u0 + u;
-                    if (until == 0 && span < spans && c <= npre) {      // c == span * cps
-                        *dst = a;
-                        dst += VP;
-                        ++span;
-                        until = cps;
+                    for (int u = 0; u < 16; ++u) {
+                        tile[(u0 + u) * 64 + lane] = a;                    // the sum BEFORE chunk c: where a span at c starts
+                        a = a + e[u];
                     }
-                    --until;
-                    if (c < npre) a = a + e[u];
+                }
+            } else {
+                for (int u0 = 0; u0 < SCAN_CT; u0 += 16) {
+                    if (c0 + u0 > npre) break;
+                    float e[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) e[u] = tile[(u0 + u) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        tile[(u0 + u) * 64 + lane] = a;
+                        if (c0 + u0 + u < npre) a = a + e[u];
+                    }
                 }
             }
+        }
+        __syncthreads();
+        // span starts of this tile, stored by all four wavefronts: span s starts at chunk s * cps
+        {
+            const int c_last = min(c0 + SCAN_CT - 1, npre);
+            const int s_end = min(spans, c_last / cps + 1);                // spans that start in this tile: [s_first, s_end)
+            int s_ = (c0 + cps - 1) / cps + wib;
+            for (; s_ + 28 < s_end; s_ += 32) {                            // eight LDS reads in flight, then eight stores
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tile[((s_ + 4 * k) * cps - c0) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[(size_t)(s_ + 4 * k) * VP] = v[k];
+            }
+            for (; s_ < s_end; s_ += 4) dst[(size_t)s_ * VP] = tile[(s_ * cps - c0) * 64 + lane];
         }
         __syncthreads();
     }
@@ -1033,7 +1084,7 @@ __global__ void __launch_bounds__(256) osc_offset_scan_groups_kernel(const float
     const int row = task / cols;
     const int v = (task - row * cols) * 64 + lane;
     if (p.audible && !p.need_all) {
-        const int amax = row_audible_max(p.audible + (size_t)row * p.T, p.T, lane);
+        const int amax = p.rowmax ? p.rowmax[row] : row_audible_max(p.audible + (size_t)row * p.T, p.T, lane);
         if (!__any(v < p.V && v % p.H < amax)) return;
     }
     constexpr int NB = 40;
@@ -1069,12 +1120,14 @@ static int env_int(const char* name, int dflt);
 static void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
                                hipStream_t stream, const float* state_in = nullptr, int V = 0) {
     const size_t nthr = (size_t)R * VP;
-    if (npre > SCAN_CT && !env_int("DDSPP_OSC_SHORT_SCAN", 0))
-        hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)(nthr / 64)), dim3(256), 0, stream, ework, astart, R,
-                           npre, VP, spans, cps, state_in, V);
-    else
+    if (npre > SCAN_CT && !env_int("DDSPP_OSC_SHORT_SCAN", 0)) {
+        OscParams q{};                     // (no audible counts on this path: every group is scanned)
+        q.R = R; q.npre = npre; q.VP = VP; q.spans = spans; q.cps = cps; q.state_in = state_in; q.V = V; q.H = V > 0 ? V : 1;
+        hipLaunchKernelGGL(osc_offset_scan_kernel, dim3((unsigned)(nthr / 64)), dim3(256), 0, stream, ework, astart, q);
+    } else {
         hipLaunchKernelGGL(osc_offset_scan_short_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                            ework, astart, R, npre, VP, spans, cps, state_in, V);
+    }
 }
 
 // nk[b, span, p] = number of leading harmonics of voice p that have a non-zero amplitude
@@ -1238,8 +1291,11 @@ static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* 
         q.echunk = echunk;
         if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
         else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
-        hipLaunchKernelGGL(osc_offset_scan_groups_kernel, dim3((q.R * (q.VP / 64) + 3) / 4), dim3(256), 0, stream, echunk,
-                           q.ework, q);
+        if (q.npre > SCAN_CT)              // long rows: tiles through LDS, four wavefronts per (row, 64 oscillators)
+            hipLaunchKernelGGL(osc_offset_scan_kernel, dim3(q.R * (q.VP / 64)), dim3(256), 0, stream, echunk, q.ework, q);
+        else
+            hipLaunchKernelGGL(osc_offset_scan_groups_kernel, dim3((q.R * (q.VP / 64) + 3) / 4), dim3(256), 0, stream, echunk,
+                               q.ework, q);
         return;
     }
     const OscParams& q = q0;
@@ -1311,7 +1367,13 @@ static void span_starts(const OscParams& p, int R, int V, int vpl_pre, float* as
     const int VP = p.VP, U = p.U;
     OscParams q = p;
     q.R = R; q.groups = 1; q.vgrp = V;
-    const bool memo = R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) && !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
+    // The memoised walk needs wavefronts enough to fill the chip: rows did that alone (batches), since the sections of
+    // round 3 a few LONG rows do too (a 136 s file: 16 rows x 2 groups x 136 sections)
+    const int per_wave = max(env_int("DDSPP_OSC_PREPASS_RUN", 6), 1);
+    const long long sections = V % 64 == 0 && pick_vpl(64) == 1 && q.npre >= 8
+                                   ? (long long)R * (V / 64) * ((q.npre + 4 * per_wave - 1) / (4 * per_wave)) : 0;
+    const bool memo = (R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256) || sections >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256)) &&
+                      !env_int("DDSPP_OSC_PLAIN_PREPASS", 0);
     if (memo) {
         q.ework = astart;
         // one wavefront per 64 oscillators of a row when the rows alone leave SIMDs with a single wavefront: the walk
@@ -1456,6 +1518,7 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
     const size_t wmax = (P * V + 63) / 64 + 1;        /* + 1: the last voice's slots start on a slot boundary */
     return (2 * (size_t)B * P * nchunks * VP      /* astart + chunk end phases (worst case: one span per chunk) */
             + (size_t)B * nchunks * (P + 2)       /* nk + wcount */
+            + (size_t)B * P                       /* per-row max of the audible counts */
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
@@ -1496,7 +1559,8 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     float* ework = astart + (size_t)R * sp * VP;           // chunk end phases (chunk-parallel pre-pass only)
     int* nk = (int*)(ework + (size_t)R * nchunks * VP);
     int* wcount = nk + (size_t)B * sp * P;
-    float* partial = (float*)(wcount + (size_t)B * sp * 2);
+    int* rowmax = wcount + (size_t)B * sp * 2;
+    float* partial = (float*)(rowmax + R);
     partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
 
     OscParams p{};
@@ -1513,7 +1577,14 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.astart = astart;
 
     // 1. span start offsets for every (row, oscillator) over rows = B * P
-    if (sp > 1 || p.state_in) span_starts(p, R, V, vpl_pre, astart, ework, stream);
+    if (sp > 1 || p.state_in) {
+        if (audible && T > 1536) {         // which 64-oscillator groups are never heard: asked by every wavefront below --
+            // of a long row in a kernel of its own (a 3 s row is twelve loads in flight per wavefront: cheaper than a launch)
+            hipLaunchKernelGGL(osc_row_max_kernel, dim3(R), dim3(256), 0, stream, audible, rowmax, T);
+            p.rowmax = rowmax;
+        }
+        span_starts(p, R, V, vpl_pre, astart, ework, stream);
+    }
     // 2. audible-harmonic counts per (segment, span, voice)
     if (audible)
         hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
