@@ -97,9 +97,12 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
     // else the two-call form with per-voice rows (e.g. 16 kHz: more than 16 frames reach a window of 1024 samples)
     g->fused_noise = ddspp_frequency_filter_eo_supported(N, T, K, g->Lw, c.delay_compensation) != 0;
     g->vpr = 1;
+    // (voices are summed in the kernel only when the rows alone give it workgroups enough -- a window is 30 frames, the chip
+    // holds 768 workgroups: a single 3 s segment is 50 units of eight voices or 400 of one)
+    const int forced = ddspp_option("DDSPP_VOICE_SUMS", 0);                // (tests: voice sums at small sizes)
     if (g->fused_noise)
         for (int v : {8, 4, 2})
-            if (P % v == 0) {
+            if (P % v == 0 && (forced > 0 ? v <= forced : (long long)B * (P / v) * ((T + 29) / 30) >= 768)) {
                 g->vpr = v;
                 break;
             }

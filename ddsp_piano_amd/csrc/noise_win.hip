@@ -517,6 +517,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     // is spread over all CUs by the dispatcher instead of leaving a fixed assignment's stragglers.
     int tpw = ddspp_option("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
     if (tpw < 1) tpw = 1;
+    while (tpw > 1 && tasks / tpw < 768) tpw >>= 1;          // few tasks (a single segment): one unit per workgroup
     const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design
     const dim3 grid((unsigned)((tasks + tpw - 1) / tpw)), block(256);
 #define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \

@@ -188,7 +188,10 @@ def run(plan, inputs, noise=None, need_stems=True):
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
     # (batch 64, same box: 2.12 ms per step with per-voice rows, 2.08 / 2.05 / 2.03 / 2.04 with 2 / 4 / 8 / 16)
     opt = _lib.options
-    voice_sums = opt.voice_sums or next(v for v in (8, 4, 2, 1) if P % v == 0)
+    # ... when the rows alone give the kernel workgroups enough: a window is 30 frames, the chip holds 768 workgroups -- a
+    # single 3 s segment is 50 units of eight voices, or 400 of one (0.25 -> 0.19 ms for the segment)
+    voice_sums = next(v for v in (8, 4, 2, 1) if P % v == 0 and (
+        v == 1 or (v <= opt.voice_sums if opt.voice_sums > 0 else B * (P // v) * -(-T // 30) >= 768)))
     if not (compact and voice_sums > 1 and P % voice_sums == 0 and
             not opt.no_voice_sums):
         voice_sums = 1

@@ -14,6 +14,18 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_gpu_fuzz as F  # noqa: E402
 import test_gpu_native_group as G  # noqa: E402
 
+
+
+class Env:
+    """What the tests take from pytest's monkeypatch."""
+
+    def setenv(self, k, v):
+        os.environ[k] = str(v)
+
+    def delenv(self, k, raising=False):
+        os.environ.pop(k, None)
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 FLAGS = [{}, {}, dict(scale='exp_tanh', normalize_after_nyquist_cut=False), dict(normalize_below_nyquist=False),
@@ -37,13 +49,14 @@ while time.time() - t0 < budget:
         elif kind == 1:
             K = {32: 32, 64: 64, 96: 96, 128: 96, 192: 96}[U] if rng.random() < 0.7 else int(rng.choice([32, 64, 65, 96, 128]))
             args = (seed, min(B, 5), P, min(T, 200), H, K, S, U, bool(rng.integers(0, 2)))
-            F.test_batched_group_equals_the_node_by_node_walk(*args)
+            F.test_batched_group_equals_the_node_by_node_walk(*args, Env())
         elif kind == 3:                        # the one-call C driver against the Python route
             K = int(rng.choice([32, 64, 96, 128]))
             flags = None if rng.random() < 0.6 else dict(scale='exp_tanh', normalize_after_nyquist_cut=False)
             args = (seed, min(B, 5), P, max(2, min(T, 150)), H, K, S, U, bool(rng.integers(0, 2)),
                     int(rng.choice([0, 500, 3000, 9000])), flags)
-            G.test_native_group_equals_the_python_route(*args)
+            G.test_native_group_equals_the_python_route(*args, Env())
+            os.environ.pop('DDSPP_VOICE_SUMS', None)
         else:
             K = {32: 32, 64: 64, 96: 96, 128: 96, 192: 96}[U]
             if U == 192:
