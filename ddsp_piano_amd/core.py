@@ -97,7 +97,14 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """The current HIP stream of the current device as the C-ABI takes it (the raw handle: a dozen calls per group call,
+    and torch.cuda.current_stream() builds a Stream object each time)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

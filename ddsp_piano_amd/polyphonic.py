@@ -84,12 +84,17 @@ def _side_stream(device):
 
 
 def _same_buffer_slices(tensors, step_elems):
-    """True when tensors[i] starts i * step_elems elements after tensors[0] inside one storage."""
-    t0 = tensors[0]
-    es = t0.element_size()
-    base, ptr = t0.untyped_storage().data_ptr(), t0.data_ptr()
-    return all(x.untyped_storage().data_ptr() == base and x.data_ptr() == ptr + i * step_elems * es
-               for i, x in enumerate(tensors))
+    """True when tensors[i] starts i * step_elems elements after tensors[0] inside one storage (the storage is asked of
+    the first and the last only: slices at exact multiples in between lie inside it)."""
+    t0, tl = tensors[0], tensors[-1]
+    if t0.untyped_storage().data_ptr() != tl.untyped_storage().data_ptr():
+        return False
+    step, ptr = step_elems * t0.element_size(), t0.data_ptr()
+    for x in tensors:
+        if x.data_ptr() != ptr:
+            return False
+        ptr += step
+    return True
 
 
 def _stack_voices(tensors, voice_major=None):
@@ -103,11 +108,16 @@ def _stack_voices(tensors, voice_major=None):
     Otherwise the tensors are copied into the requested order (default: voice major, P block copies)."""
     t0 = tensors[0]
     p = len(tensors)
-    if (t0.is_cuda and t0.dtype == torch.float32 and t0.dim() == 3 and
-            all(x.shape == t0.shape and x.stride() == t0.stride() and x.dtype == t0.dtype and
-                x.device == t0.device for x in tensors)):
-        b, t, c = t0.shape
-        sb, st, sc = t0.stride()
+    shape0, stride0 = t0.shape, t0.stride()
+
+    def alike():
+        for x in tensors:
+            if x.shape != shape0 or x.stride() != stride0 or x.dtype != torch.float32:
+                return False
+        return True
+    if t0.is_cuda and t0.dtype == torch.float32 and t0.dim() == 3 and alike():
+        b, t, c = shape0
+        sb, st, sc = stride0
         if sc == 1 and st == c:
             if voice_major in (None, True) and sb == t * c and _same_buffer_slices(tensors, b * t * c):
                 return torch.as_strided(t0, (p * b, t, c), (t * c, c, 1)), True
