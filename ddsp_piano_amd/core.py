@@ -81,6 +81,8 @@ def default_device():
 def tf_float32(x, device=None):
     """ddsp.core.tf_float32: cast to float32 (and make the buffer a contiguous device tensor)."""
     if isinstance(x, torch.Tensor):
+        if x.dtype == torch.float32 and x.is_cuda and x.is_contiguous():
+            return x                       # (the common case, a few hundred times per streamed push: no dispatcher round trip)
         if x.is_cuda or (device is None and not torch.cuda.is_available()):
             # already resident (or: no GPU at all -- host-logic tests; kernels refuse CPU buffers)
             return x.to(dtype=torch.float32).contiguous()
@@ -267,6 +269,18 @@ def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
     device (exact IEEE float32 multiply / floor / subtract, the same values as the cached numpy table), not cached."""
     if not sample_offset:
         return linear_tables(n_frames, n_timesteps, device)[2]
+    key = (int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'])
+    if _last_weights.get('key') == key:                    # (a streamed piece asks twice: the bank and the phase state)
+        return _last_weights['w']
+    w = _linear_weights_at(n_frames, n_timesteps, device, sample_offset)
+    _last_weights.update(key=key, w=w)
+    return w
+
+
+_last_weights = {}
+
+
+def _linear_weights_at(n_frames, n_timesteps, device, sample_offset):
     scale = float(F32(n_frames) / F32(n_timesteps))
     n = torch.arange(int(sample_offset), int(sample_offset) + int(n_timesteps), device=device,
                      dtype=torch.int64).to(torch.float32)
