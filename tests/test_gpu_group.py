@@ -441,6 +441,36 @@ def test_chunk_prepass_kernel_equals_the_block_machinery(monkeypatch):
         assert (core.polyphonic_additive(*args, spans=spans) - new).abs().max().item() < 3e-6
 
 
+def test_long_rows_take_the_sectioned_memo_prepass(monkeypatch):
+    """A file as one segment (few rows, thousands of frames): the memoised pre-pass in sections + the tiled scan with the
+    per-row audible maximum from its own kernel (rows longer than 1 536 frames) and silent 64-oscillator groups left out
+    -- the bits of the chunk-parallel pre-pass, which scans every chunk of every group."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(77)
+    B, P, T, H, sr = 1, 16, 3300, 128, 24000           # 316 chunks; 16 rows x 2 groups x 14 sections
+    N = T * 96
+    raw = synth_controls(rng, B * P, T, H, S=1, silent_frac=0.25, midi_lo=30, midi_hi=100)
+    raw['f0_hz'][:, T // 3:] *= np.float32(2 ** (-3 / 12))                                   # every voice changes note
+    raw['f0_hz'][2, 500:700] *= np.linspace(1.0, 1.06, 200, dtype=np.float32)[:, None]       # a glide: moving chunks
+    syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+    ctl = syn._controls(*[torch.as_tensor(raw[k], device='cuda') for k in
+                          ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')], want_counts=True)
+    amp = ctl['amplitudes'].reshape(B * P, T).contiguous()
+    args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
+    new = core.polyphonic_additive(*args, audible=ctl['_audible'])
+    assert torch.isfinite(new).all() and new.abs().max().item() > 0
+    set_option(monkeypatch, 'DDSPP_OSC_PLAIN_PREPASS', '1')
+    assert torch.equal(core.polyphonic_additive(*args, audible=ctl['_audible']), new)
+    set_option(monkeypatch, 'DDSPP_OSC_PLAIN_PREPASS')
+    for run in ('2', '40'):                               # other section lengths (40: one section per (row, group))
+        set_option(monkeypatch, 'DDSPP_OSC_PREPASS_RUN', run)
+        assert torch.equal(core.polyphonic_additive(*args, audible=ctl['_audible']), new), run
+    set_option(monkeypatch, 'DDSPP_OSC_PREPASS_RUN')
+    stems = core.harmonic_synthesis_fused(*args[:4], N, sr, True).reshape(B, P, N)
+    assert (new - stems.sum(1)).abs().max().item() < 6e-6 * max(1.0, float(new.abs().max()))
+
+
 @pytest.mark.parametrize('B,P,T,H,K,L', [
     (2, 2, 1, 64, 32, 100),       # a single control frame
     (1, 1, 2, 64, 32, 7),         # two frames, one voice, a 7-tap "room"
