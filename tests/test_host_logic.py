@@ -327,3 +327,23 @@ def test_linear_exact_frames_bound():
     bad_last = np.floor(np.float32(f * 96 - 1) * scale) != f - 1
     assert bad_first or bad_last
     assert core.linear_exact_frames(32) > core.linear_exact_frames(96) >= core.linear_exact_frames(192)
+
+
+def test_per_voice_tensors_are_recognised_as_slices_of_one_buffer():
+    """polyphonic._same_buffer_slices (the zero-copy test of the per-voice keys the Parallelizer hands over): slices at
+    exact multiples inside one storage; the storage is asked of the first and the last tensor only."""
+    import torch
+    from ddsp_piano_amd import polyphonic
+    whole = torch.arange(4 * 3 * 5 * 2, dtype=torch.float32).reshape(4, 3, 5, 2)          # [P, B, T, C]
+    voices = [whole[i] for i in range(4)]
+    assert polyphonic._same_buffer_slices(voices, 3 * 5 * 2)
+    assert not polyphonic._same_buffer_slices(voices, 5 * 2)                               # another step
+    assert not polyphonic._same_buffer_slices([voices[0], voices[2], voices[1], voices[3]], 3 * 5 * 2)   # another order
+    assert not polyphonic._same_buffer_slices(voices[:3] + [voices[3].clone()], 3 * 5 * 2)               # another storage
+    seg = torch.arange(3 * 4 * 5 * 2, dtype=torch.float32).reshape(3, 4, 5, 2)            # [B, P, T, C]
+    assert polyphonic._same_buffer_slices([seg[:, i] for i in range(4)], 5 * 2)
+    # host tensors (or mixed shapes) are stacked by copy, voice major by default
+    rows, vm = polyphonic._stack_voices(voices)
+    assert vm is True and rows.shape == (12, 5, 2) and torch.equal(rows, whole.reshape(12, 5, 2))
+    rows, vm = polyphonic._stack_voices([seg[:, i] for i in range(4)], False)
+    assert vm is False and torch.equal(rows, seg.reshape(12, 5, 2))
