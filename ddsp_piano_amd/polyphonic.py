@@ -72,6 +72,17 @@ def recognise(dag):
     return Plan(additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, p)
 
 
+def pick_voice_sums(n_segments, n_voices, n_frames, forced=0):
+    """Voices summed per row inside the FilteredNoise kernel (8, 4, 2 or 1 = per-voice rows): the largest divisor of the voice
+    count that still leaves the kernel 768 units of (row, 30-frame window) -- the workgroups the chip holds; `forced` > 0:
+    the largest divisor up to it, whatever the batch size (DDSPP_VOICE_SUMS).  csrc/group.cpp applies the same rule."""
+    for v in (8, 4, 2):
+        if n_voices % v == 0 and (v <= forced if forced > 0 else
+                                  n_segments * (n_voices // v) * -(-n_frames // 30) >= 768):
+            return v
+    return 1
+
+
 _side_streams = {}
 
 
@@ -200,8 +211,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     opt = _lib.options
     # ... when the rows alone give the kernel workgroups enough: a window is 30 frames, the chip holds 768 workgroups -- a
     # single 3 s segment is 50 units of eight voices, or 400 of one (0.25 -> 0.19 ms for the segment)
-    voice_sums = next(v for v in (8, 4, 2, 1) if P % v == 0 and (
-        v == 1 or (v <= opt.voice_sums if opt.voice_sums > 0 else B * (P // v) * -(-T // 30) >= 768)))
+    voice_sums = pick_voice_sums(B, P, T, opt.voice_sums)
     if not (compact and voice_sums > 1 and P % voice_sums == 0 and
             not opt.no_voice_sums):
         voice_sums = 1

@@ -347,3 +347,15 @@ def test_per_voice_tensors_are_recognised_as_slices_of_one_buffer():
     assert vm is True and rows.shape == (12, 5, 2) and torch.equal(rows, whole.reshape(12, 5, 2))
     rows, vm = polyphonic._stack_voices([seg[:, i] for i in range(4)], False)
     assert vm is False and torch.equal(rows, seg.reshape(12, 5, 2))
+
+
+def test_voice_sums_follow_the_batch_size():
+    """polyphonic.pick_voice_sums (mirrored in csrc/group.cpp): sums of eight voices at batch 64, per-voice rows for a single
+    3 s segment (50 units of eight voices would leave the chip idle), the forced form of the tests."""
+    from ddsp_piano_amd.polyphonic import pick_voice_sums
+    assert pick_voice_sums(64, 16, 750) == 8 and pick_voice_sums(1, 16, 750) == 1
+    assert pick_voice_sums(8, 16, 750) == 4            # 8 x 4 x 25 = 800 units with sums of four, 400 with eight
+    assert pick_voice_sums(1, 16, 34000) == 8          # a 136 s file: 2 x 1134 units
+    assert pick_voice_sums(64, 6, 750) == 2 and pick_voice_sums(64, 5, 750) == 1
+    assert pick_voice_sums(1, 16, 10, forced=8) == 8 and pick_voice_sums(1, 6, 10, forced=8) == 2
+    assert pick_voice_sums(1, 16, 10, forced=4) == 4
