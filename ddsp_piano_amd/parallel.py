@@ -82,9 +82,15 @@ def gather_audio(local_audio, out=None, group=None, async_op=False, dst=None):
             out.copy_(host)
         return (out, _Done()) if async_op else out
     if dst is not None:
-        work = dist.gather(local_audio, list(out.chunk(world, dim=0)) if receives else None, dst=_global_rank(dst, group),
-                           group=group, async_op=async_op)
-        return (out, work) if async_op else out
+        try:
+            work = dist.gather(local_audio, list(out.chunk(world, dim=0)) if receives else None, dst=_global_rank(dst, group),
+                               group=group, async_op=async_op)
+            return (out, work) if async_op else out
+        except NotImplementedError:        # a backend without gather (raised at dispatch, on every rank alike): all-gather,
+            full = out if receives else torch.empty((world * local_audio.shape[0],) + tuple(local_audio.shape[1:]),
+                                                    dtype=local_audio.dtype, device=local_audio.device)   # keep rank dst's copy
+            work = dist.all_gather_into_tensor(full, local_audio, group=group, async_op=async_op)
+            return (out, work) if async_op else out
     try:
         work = dist.all_gather_into_tensor(out, local_audio, group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):
