@@ -269,15 +269,19 @@ def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
     device (exact IEEE float32 multiply / floor / subtract, the same values as the cached numpy table), not cached."""
     if not sample_offset:
         return linear_tables(n_frames, n_timesteps, device)[2]
-    key = (int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'])
-    if _last_weights.get('key') == key:                    # (a streamed piece asks twice: the bank and the phase state)
-        return _last_weights['w']
+    global _last_weights
+    # the stream is part of the key: the tensor is produced on the caller's current stream and nothing orders another
+    # stream's reads behind it
+    key = (int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'], _stream())
+    last = _last_weights                                   # one (key, tensor) pair, read and replaced as a whole: host
+    if last is not None and last[0] == key:                # threads never see one call's key with another call's tensor
+        return last[1]                                     # (a streamed piece asks twice: the bank and the phase state)
     w = _linear_weights_at(n_frames, n_timesteps, device, sample_offset)
-    _last_weights.update(key=key, w=w)
+    _last_weights = (key, w)
     return w
 
 
-_last_weights = {}
+_last_weights = None
 
 
 def _linear_weights_at(n_frames, n_timesteps, device, sample_offset):
@@ -783,9 +787,10 @@ class _PlanCache:
                 self._order.append(key)
             if pin:
                 e[2] += 1
-            for rec in self._recorders:
-                if not any(x is e for x in rec):
+            for rec in self._recorders:                 # pinned the moment it is recorded: an eviction between now and
+                if not any(x is e for x in rec):       # the end of the capture would leave the graph a destroyed plan
                     rec.append(e)
+                    e[2] += 1
             self._evict()
             return e
 
@@ -805,8 +810,6 @@ class _PlanCache:
             def __exit__(self, *exc):
                 with cache._lock:
                     cache._recorders[:] = [r for r in cache._recorders if r is not self.entries]
-                    for e in self.entries:
-                        e[2] += 1
         return _Rec()
 
     def unpin_all(self, entries):

@@ -222,11 +222,20 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         }
         return code;
     };
+    // (DDSPP_HIP_CHECK returns on the spot; between the fork and the join a failing HIP call has to go through leave())
+#define DDSPP_HIP_CHECK_LEAVE(expr)                                                                          \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            ddspp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+            return leave(DDSPP_EHIP);                                                                        \
+        }                                                                                                    \
+    } while (0)
     if (g->side) {
         DDSPP_HIP_CHECK(hipEventRecord(g->ev_fork, stream));
-        DDSPP_HIP_CHECK(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+        forked = true;                      // from here on the side stream may hold work of this call
+        DDSPP_HIP_CHECK_LEAVE(hipStreamWaitEvent(g->side, g->ev_fork, 0));
         zs = g->side;
-        forked = true;
     }
     if (g->plan && g->side) {
         rc = ddspp_fftconv_transform_ir(g->plan, reverb_ir, c.reverb_keep_dry_tap ? 0 : 1, ws + g->o_fft, g->fft_bytes, zs);
@@ -256,7 +265,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         if (rc == DDSPP_OK) rc = ddspp_time_varying_fir(z, ir, zrows, R, N, T, g->Lw, c.delay_compensation, zs);
     }
     if (rc != DDSPP_OK) return leave(rc);
-    if (g->side) DDSPP_HIP_CHECK(hipEventRecord(g->ev_join, g->side));
+    if (g->side) DDSPP_HIP_CHECK_LEAVE(hipEventRecord(g->ev_join, g->side));
 
     // ---- get_controls of the additive processor over all rows (inharm_synth.py:167-219, :254-270) -------------------
     float* shifts_last = want ? (outputs->harmonic_shifts_last ? outputs->harmonic_shifts_last : (float*)(ws + g->o_shl)) : nullptr;
@@ -274,7 +283,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
 
     // ---- add chain (polyphonic_dag.py:28-37) -------------------------------------------------------------------------
     if (g->side) {
-        DDSPP_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_join, 0));
+        DDSPP_HIP_CHECK_LEAVE(hipStreamWaitEvent(stream, g->ev_join, 0));
         joined = true;
     }
     if (!want) {
@@ -283,7 +292,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         if (rc != DDSPP_OK) return leave(rc);
     } else if (P == 1) {
         // one voice: it is the last one.  dry = noise + additive (the first `add` node, two operands)
-        if (zlast != zrows) DDSPP_HIP_CHECK(hipMemcpyAsync(zlast, zrows, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
+        if (zlast != zrows) DDSPP_HIP_CHECK_LEAVE(hipMemcpyAsync(zlast, zrows, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
         rc = ddspp_mix_voices(add_last, 1, zlast, 1, dry, B, N, N, 0, stream);
         if (rc != DDSPP_OK) return leave(rc);
     } else {
@@ -291,15 +300,15 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         int pz = P / vpr, zvm = 0;
         if (!split_in_kernel) {            // per-voice noise rows (P has no even divisor): take the last voice out by copies
             if (vm) {                      // [P, B, N]: the first (P - 1) B rows are the other voices, the last B rows the last one
-                DDSPP_HIP_CHECK(hipMemcpyAsync(zlast, zrows + (size_t)(P - 1) * B * N, (size_t)B * N * 4, hipMemcpyDeviceToDevice,
+                DDSPP_HIP_CHECK_LEAVE(hipMemcpyAsync(zlast, zrows + (size_t)(P - 1) * B * N, (size_t)B * N * 4, hipMemcpyDeviceToDevice,
                                                stream));
                 pz = P - 1;
                 zvm = 1;
             } else {                       // [B, P, N]
                 float* pack = (float*)(ws + g->o_zpack);
-                DDSPP_HIP_CHECK(hipMemcpy2DAsync(pack, (size_t)(P - 1) * N * 4, zrows, (size_t)P * N * 4, (size_t)(P - 1) * N * 4, B,
+                DDSPP_HIP_CHECK_LEAVE(hipMemcpy2DAsync(pack, (size_t)(P - 1) * N * 4, zrows, (size_t)P * N * 4, (size_t)(P - 1) * N * 4, B,
                                                  hipMemcpyDeviceToDevice, stream));
-                DDSPP_HIP_CHECK(hipMemcpy2DAsync(zlast, (size_t)N * 4, zrows + (size_t)(P - 1) * N, (size_t)P * N * 4, (size_t)N * 4, B,
+                DDSPP_HIP_CHECK_LEAVE(hipMemcpy2DAsync(zlast, (size_t)N * 4, zrows + (size_t)(P - 1) * N, (size_t)P * N * 4, (size_t)N * 4, B,
                                                  hipMemcpyDeviceToDevice, stream));
                 zr = pack;
                 pz = P - 1;
@@ -314,13 +323,13 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     if (want) {
         const size_t sp = row_step;
         if (outputs->amplitudes_last)
-            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->amplitudes_last, (size_t)T * 4, amp_c + (size_t)last_row0 * T, sp * T * 4,
+            DDSPP_HIP_CHECK_LEAVE(hipMemcpy2DAsync(outputs->amplitudes_last, (size_t)T * 4, amp_c + (size_t)last_row0 * T, sp * T * 4,
                                              (size_t)T * 4, B, hipMemcpyDeviceToDevice, stream));
         if (outputs->harmonic_distribution_last)
-            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->harmonic_distribution_last, (size_t)T * H * 4, hd_c + (size_t)last_row0 * T * H,
+            DDSPP_HIP_CHECK_LEAVE(hipMemcpy2DAsync(outputs->harmonic_distribution_last, (size_t)T * H * 4, hd_c + (size_t)last_row0 * T * H,
                                              sp * T * H * 4, (size_t)T * H * 4, B, hipMemcpyDeviceToDevice, stream));
         if (outputs->magnitudes_last) {    // FilteredNoise.get_controls of the last voice: scale_fn(magnitudes + initial_bias)
-            DDSPP_HIP_CHECK(hipMemcpy2DAsync(outputs->magnitudes_last, (size_t)T * K * 4, magnitudes + (size_t)last_row0 * T * K,
+            DDSPP_HIP_CHECK_LEAVE(hipMemcpy2DAsync(outputs->magnitudes_last, (size_t)T * K * 4, magnitudes + (size_t)last_row0 * T * K,
                                              sp * T * K * 4, (size_t)T * K * 4, B, hipMemcpyDeviceToDevice, stream));
             if (c.noise_scale_kind >= 0) {
                 rc = ddspp_scale_bias(outputs->magnitudes_last, outputs->magnitudes_last, (size_t)B * T * K, c.noise_bias,
@@ -346,6 +355,7 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         DDSPP_HIP_CHECK(hipMemcpyAsync(audio, dry, (size_t)B * N * 4, hipMemcpyDeviceToDevice, stream));
     }
     return DDSPP_OK;
+#undef DDSPP_HIP_CHECK_LEAVE
 }
 
 }  // extern "C"

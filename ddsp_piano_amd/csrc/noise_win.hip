@@ -494,10 +494,11 @@ size_t win_lds_bytes(const WinGeom& g, int K_or_0) {
 bool win_fused_supported(int N, int T, int K, int Lw, int delay, WinGeom* g) {
     if (!win_geometry(N, T, Lw, delay, g) || Lw != 2 * (K - 1)) return false;
     const int U = g->U;
-    // (U = 192 at K = 96 -- two passes of eight phases, 24 noise registers -- does not fit the 168-register budget: the
-    // round-2 kernel keeps that shape, as it keeps every hop this file has no instance for)
-    const bool inst = (K == 96 && U == 96) || (K == 64 && (U == 64 || U == 96)) || (K == 32 && (U == 128 || U == 32)) ||
-                      (K == 128 && U == 128);
+    // U = 192 at K = 96 (BASELINE config 5, 48 kHz: two passes of eight phases, 24 noise registers) and K = 128 (70 KB of
+    // LDS) are two-workgroups-per-CU shapes and get the registers of two wavefronts per SIMD; every other hop keeps
+    // round 2's kernel
+    const bool inst = (K == 96 && (U == 96 || U == 192)) || (K == 64 && (U == 64 || U == 96)) ||
+                      (K == 32 && (U == 128 || U == 32)) || (K == 128 && U == 128);
     return inst && win_lds_bytes(*g, K) <= 80 * 1024;          // (two workgroups per CU at least)
 }
 
@@ -523,24 +524,27 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
 #define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \
     hipLaunchKernelGGL((noise_win_fused_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, CE, \
                        CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw, dbg)
+    // more than 64 KB of dynamic LDS has to be allowed per function AND per device (the attribute is cheap to set: no
+    // per-process flag, which would leave every device but the first without it)
+#define DDSPP_WIN_LAUNCH_W2(KH, JT, OPL, BPF)                                                                          \
+    do {                                                                                                               \
+        DDSPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&noise_win_fused_w2_kernel<KH, JT, OPL, BPF>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
+        hipLaunchKernelGGL((noise_win_fused_w2_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, \
+                           CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices,    \
+                           voice_major, tpw, dbg);                                                                     \
+    } while (0)
     const int U = g.U;
     if (K == 96 && U == 96) DDSPP_WIN_LAUNCH(48, 3, 12, 24);
     else if (K == 64 && U == 64) DDSPP_WIN_LAUNCH(32, 2, 8, 16);
     else if (K == 64 && U == 96) DDSPP_WIN_LAUNCH(32, 2, 12, 24);
     else if (K == 32 && U == 128) DDSPP_WIN_LAUNCH(16, 1, 16, 32);
     else if (K == 32 && U == 32) DDSPP_WIN_LAUNCH(16, 1, 4, 8);                 // ENSTDkCl-8kHz.gin
-    else if (K == 128 && U == 128) {                                           // ENSTDkCl-32kHz.gin: 70 KB of LDS
-        static bool raised = false;
-        if (!raised) {
-            DDSPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&noise_win_fused_w2_kernel<64, 4, 16, 32>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            raised = true;
-        }
-        hipLaunchKernelGGL((noise_win_fused_w2_kernel<64, 4, 16, 32>), grid, block, lds, stream, audio, magnitudes, CE, CO,
-                           tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw, dbg);
-    }
+    else if (K == 128 && U == 128) DDSPP_WIN_LAUNCH_W2(64, 4, 16, 32);           // ENSTDkCl-32kHz.gin: 70 KB of LDS
+    else if (K == 96 && U == 192) DDSPP_WIN_LAUNCH_W2(48, 3, 12, 48);            // 48 kHz (BASELINE config 5): 65 KB
     else DDSPP_REQUIRE(false, "frequency_filter_eo: no windowed kernel for K=%d U=%d", K, U);
 #undef DDSPP_WIN_LAUNCH
+#undef DDSPP_WIN_LAUNCH_W2
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

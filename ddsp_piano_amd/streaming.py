@@ -268,7 +268,9 @@ def render_range(make_synth, features, frame_lo, frame_hi, noise=None):
         if k in features:
             piece[k] = features[k]
     z = None if noise is None else core.tf_float32(noise)[:, :, start * U:stop * U]
-    out = syn.push(piece, noise=z, final=last)
+    # a range that is not the file's last one but whose look-ahead reaches the end of the controls has nothing more
+    # to wait for either: without `final` push() would hold the look-ahead frames back and come up short
+    out = syn.push(piece, noise=z, final=last or stop >= T)
     need = (frame_hi - start) * U
     if out.shape[1] < need:
         raise ValueError(f'frames [{frame_lo}, {frame_hi}) do not end on a block boundary of {blk} frames')
