@@ -166,6 +166,22 @@ def build_group(dp, P, sr, frame_rate=250):
     return dp.ProcessorGroup(dag)
 
 
+def build_default_model_group(dp, P, sr, frame_rate=250):
+    """The node list of ddsp_piano/default_model.py:44-80 (noise node first, explicit ddsp.processors.Add nodes)."""
+    noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr)
+    additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True)
+    ctl = ['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz']
+    dag = [(noise, ['magnitudes_0']), (additive, [c + '_0' for c in ctl]),
+           (dp.Add(name='add_0'), ['noise/signal', 'additive/signal'])]
+    for i in range(1, P):
+        dag.append((additive, [c + f'_{i}' for c in ctl]))
+        dag.append((noise, [f'magnitudes_{i}']))
+        dag.append((dp.Add(name=f'sub_add_{i}'), ['noise/signal', 'additive/signal']))
+        dag.append((dp.Add(name=f'add_{i}'), [f'add_{i - 1}/signal', f'sub_add_{i}/signal']))
+    dag.append((dp.Reverb(name='reverb', trainable=False), [f'add_{P - 1}/signal', 'reverb_ir']))
+    return dp.ProcessorGroup(dag)
+
+
 # ----------------------------------------------------------------------------------------------------
 # timing
 # ----------------------------------------------------------------------------------------------------
@@ -671,6 +687,15 @@ def main():
             extra[key] = {'workload': f'{note}; batch={b_} x {args.seconds:g} s, H={h_}, K={k_}, S={s_}',
                           'ms_per_step': ms_summary(ts), 'value': b_ * T * u_ / (float(np.median(ts)) * 1e-3),
                           'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+            if key == 'dafx22_dims':
+                # the same inputs through the node list default_model.py itself builds (explicit Add nodes, noise first)
+                pgd = build_default_model_group(dp, p_, sr_)
+                ts = event_times(lambda: call(pgd, fx), 10, warmup=3)
+                extra['default_model_dag'] = {'workload': 'ddsp_piano/default_model.py:44-80 node list at the dafx22 dims, '
+                                                          f'batch={b_} x {args.seconds:g} s (batched route since round 4)',
+                                              'ms_per_step': ms_summary(ts),
+                                              'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+                del pgd
             del fx, pgx
             torch.cuda.empty_cache()
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)

@@ -139,6 +139,8 @@ SIGNATURES = {
     'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_mix_last_voice': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
+    'ddspp_mix_last_voice_paired': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int, c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                           c_int, c_int, c_void_p]),
     'ddspp_fir_from_magnitudes_eo': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -272,7 +272,9 @@ def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
     global _last_weights
     # the stream is part of the key: the tensor is produced on the caller's current stream and nothing orders another
     # stream's reads behind it
-    key = (int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'], _stream())
+    on_gpu = torch.device(device).type == 'cuda'
+    key = (int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'],
+           _stream().value if on_gpu else None)
     last = _last_weights                                   # one (key, tensor) pair, read and replaced as a whole: host
     if last is not None and last[0] == key:                # threads never see one call's key with another call's tensor
         return last[1]                                     # (a streamed piece asks twice: the bank and the phase state)

@@ -295,12 +295,14 @@ __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __rest
 // out[b, n] = sum_v a[b, v, n] (PA rows) + sum_v z[b, v, n] (PZ rows): the add chain when one operand is
 // already a per-segment mix
 // tail_z / tail_a / out_prev (all or none): out_prev = the sum above, out = (out_prev + tail_z) + tail_a -- the last step
-// of the add chain of polyphonic_dag.py:34-37 with its three operands kept apart
+// of the add chain of polyphonic_dag.py:34-37 with its three operands kept apart; with out_sub the last step as
+// default_model.py:68-74 writes it: out_sub = tail_z + tail_a, out = out_prev + out_sub
 __global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict__ a, int PA,
                                                        const float* __restrict__ z, int PZ,
                                                        float* __restrict__ out, int B, int N, int out_stride,
                                                        int voice_major, const float* __restrict__ tail_z,
-                                                       const float* __restrict__ tail_a, float* __restrict__ out_prev) {
+                                                       const float* __restrict__ tail_a, float* __restrict__ out_prev,
+                                                       float* __restrict__ out_sub) {
     const int n4 = N / 4;
     const size_t total = (size_t)B * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
@@ -318,8 +320,14 @@ __global__ void __launch_bounds__(256) mix_voices_kernel(const float* __restrict
             reinterpret_cast<float4*>(out_prev + (size_t)b * N)[i] = acc;
             const float4 tz = reinterpret_cast<const float4*>(tail_z + (size_t)b * N)[i];
             const float4 ta = reinterpret_cast<const float4*>(tail_a + (size_t)b * N)[i];
-            acc.x = (acc.x + tz.x) + ta.x; acc.y = (acc.y + tz.y) + ta.y;
-            acc.z = (acc.z + tz.z) + ta.z; acc.w = (acc.w + tz.w) + ta.w;
+            if (out_sub) {        // default_model.py:68-74: sub_add_i = noise + additive, add_i = add_{i-1} + sub_add_i
+                const float4 sb = make_float4(tz.x + ta.x, tz.y + ta.y, tz.z + ta.z, tz.w + ta.w);
+                reinterpret_cast<float4*>(out_sub + (size_t)b * N)[i] = sb;
+                acc.x = acc.x + sb.x; acc.y = acc.y + sb.y; acc.z = acc.z + sb.z; acc.w = acc.w + sb.w;
+            } else {
+                acc.x = (acc.x + tz.x) + ta.x; acc.y = (acc.y + tz.y) + ta.y;
+                acc.z = (acc.z + tz.z) + ta.z; acc.w = (acc.w + tz.w) + ta.w;
+            }
         }
         reinterpret_cast<float4*>(out + (size_t)b * out_stride)[i] = acc;
     }
@@ -462,7 +470,8 @@ int ddspp_mix_voices(const float* a, int PA, const float* z, int PZ, float* out,
                   "mix_voices: bad arguments");
     DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0 && out_stride % 4 == 0 && out_stride >= N, "mix_voices: bad dims");
     hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
-                       out, B, N, out_stride, voice_major, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                       out, B, N, out_stride, voice_major, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
@@ -477,7 +486,21 @@ int ddspp_mix_last_voice(const float* a, int PA, const float* z, int PZ, const f
                   "mix_last_voice: bad arguments");
     DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0, "mix_last_voice: bad dims");
     hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
-                       dry, B, N, N, voice_major, noise_last, additive_last, prev);
+                       dry, B, N, N, voice_major, noise_last, additive_last, prev, (float*)nullptr);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The same for the node list of default_model.py:44-80, whose last voice is added as a pair: sub[b] = noise_last[b] +
+// additive_last[b] (`sub_add_{P-1}`), dry[b] = prev[b] + sub[b] (`add_{P-1}`); prev = `add_{P-2}`.  All [B, N].
+int ddspp_mix_last_voice_paired(const float* a, int PA, const float* z, int PZ, const float* noise_last,
+                                const float* additive_last, float* prev, float* sub, float* dry, int B, int N,
+                                int voice_major, hipStream_t stream) {
+    DDSPP_REQUIRE(prev && sub && dry && noise_last && additive_last && (a || PA == 0) && (z || PZ == 0) && PA >= 0 && PZ >= 0,
+                  "mix_last_voice_paired: bad arguments");
+    DDSPP_REQUIRE(B > 0 && N > 0 && N % 4 == 0, "mix_last_voice_paired: bad dims");
+    hipLaunchKernelGGL(mix_voices_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, a, PA, z, PZ,
+                       dry, B, N, N, voice_major, noise_last, additive_last, prev, sub);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

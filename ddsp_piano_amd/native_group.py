@@ -45,7 +45,7 @@ class NativeGroup:
 
     def __init__(self, group, features):
         plan = recognise(group.dag)
-        if plan is None:
+        if plan is None or plan.shape != 'gin':
             raise ValueError('NativeGroup takes the node list of polyphonic_dag(...) over this package\'s processors')
         add, nz, rv = plan.additive, plan.noise, plan.reverb
         if not isinstance(add, InHarmonic) or not add.inference:

@@ -1,8 +1,9 @@
 """Batched execution of the polyphonic ProcessorGroup.
 
 The reference walks 3*P + 1 DAG nodes one eager processor call at a time
-(ddsp_piano/modules/polyphonic_dag.py:24-40).  When the DAG handed to ProcessorGroup has exactly that
-shape, the voices become a batch dimension: rows = B*P go through ONE get_controls kernel, ONE
+(ddsp_piano/modules/polyphonic_dag.py:24-40; 4*P nodes in the older ddsp_piano/default_model.py:44-80, whose
+shape is taken too since round 4).  When the DAG handed to ProcessorGroup has exactly one of those
+shapes, the voices become a batch dimension: rows = B*P go through ONE get_controls kernel, ONE
 fused oscillator-bank launch, ONE FIR-design + ONE time-varying-FIR launch, one mixer pass and one
 rocFFT reverb.  Per-row arithmetic is that of the node-by-node walk (same kernels).  The voice sum: with every
 voice's stems (need_stems=True) the mixer keeps the DAG's ((add + noise_i) + additive_i) order; the compacted
@@ -21,14 +22,45 @@ from .synths import FilteredNoise, InHarmonic, MultiAdd
 
 
 class Plan:
-    def __init__(self, additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, n_synths):
+    """What `recognise` found.  shape 'gin': the node list of polyphonic_dag(...) (one MultiAdd re-used for every voice);
+    shape 'default_model': the node list of ddsp_piano/default_model.py:44-80 -- noise node first, explicit
+    ddsp.processors.Add nodes `add_0`, then per voice `sub_add_i` (noise + additive) and `add_i` (add_{i-1} + sub_add_i),
+    the reverb fed from `add_{P-1}`: `adds` / `subs` hold those processors per voice (subs[0] is None)."""
+
+    def __init__(self, additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, n_synths,
+                 shape='gin', adds=None, subs=None):
         self.additive, self.noise, self.add, self.reverb = additive, noise, add, reverb
         self.additive_keys, self.noise_keys, self.reverb_keys = additive_keys, noise_keys, reverb_keys
         self.n_synths = n_synths
+        self.shape, self.adds, self.subs = shape, adds, subs
+
+
+def _reverb_node(node, feed):
+    """(reverb, reverb_keys) of a last node fed from `feed`, or None when it is not one the batched route takes."""
+    reverb = node[0]
+    # ddsp.effects.Reverb with the impulse response as a control (maestro-v2.gin:152-153), or holding its own
+    # (trainable=True); a FeedbackDelayNetwork that holds its parameters, reverb_controls = []
+    # (ENSTDkCl-8kHz.gin:85-86) or takes them as controls; the FDN apply step
+    if not isinstance(reverb, (Reverb, FeedbackDelayNetworkApply, FeedbackDelayNetwork)):
+        return None
+    if not node[1] or node[1][0] != feed:
+        return None
+    reverb_keys = list(node[1][1:])
+    if any('/' in k for k in reverb_keys):
+        return None
+    return reverb, reverb_keys
+
+
+def _plain_keys(keys, n):
+    return len(keys) == n and not any('/' in k for k in keys)
 
 
 def recognise(dag):
-    """Return a Plan if ``dag`` is polyphonic_dag(...)'s node list over this package's processors."""
+    """Return a Plan if ``dag`` is polyphonic_dag(...)'s node list, or default_model.py's, over this package's processors."""
+    return _recognise_gin(dag) or _recognise_default_model(dag)
+
+
+def _recognise_gin(dag):
     n = len(dag)
     if n < 3:
         return None
@@ -44,32 +76,69 @@ def recognise(dag):
         a, z, m = dag[3 * i], dag[3 * i + 1], dag[3 * i + 2]
         if a[0] is not additive or z[0] is not noise or m[0] is not add:
             return None
-        if len(a[1]) != 4 or len(z[1]) != 1:
+        if not _plain_keys(a[1], 4) or not _plain_keys(z[1], 1):
             return None
         expect = [noise.name + '/signal', additive.name + '/signal']
         if i > 0:
             expect = [add.name + '/signal'] + expect
         if list(m[1]) != expect:
             return None
-        if any('/' in k for k in list(a[1]) + list(z[1])):
-            return None
         additive_keys.append(list(a[1]))
         noise_keys.append(z[1][0])
     reverb, reverb_keys = None, []
     if has_reverb:
-        node = dag[-1]
-        reverb = node[0]
-        # ddsp.effects.Reverb with the impulse response as a control (maestro-v2.gin:152-153), or holding its own
-        # (trainable=True); a FeedbackDelayNetwork that holds its parameters, reverb_controls = []
-        # (ENSTDkCl-8kHz.gin:85-86) or takes them as controls; the FDN apply step
-        if not isinstance(reverb, (Reverb, FeedbackDelayNetworkApply, FeedbackDelayNetwork)):
+        found = _reverb_node(dag[-1], add.name + '/signal')
+        if found is None:
             return None
-        if not node[1] or node[1][0] != add.name + '/signal':
-            return None
-        reverb_keys = list(node[1][1:])
-        if any('/' in k for k in reverb_keys):
-            return None
+        reverb, reverb_keys = found
     return Plan(additive, noise, add, reverb, additive_keys, noise_keys, reverb_keys, p)
+
+
+def _recognise_default_model(dag):
+    """ddsp_piano/default_model.py:44-80:  noise(magnitudes_0), additive(.._0), add_0(noise/signal, additive/signal);
+    per further voice: additive(.._i), noise(magnitudes_i), sub_add_i(noise/signal, additive/signal),
+    add_i(add_{i-1}/signal, sub_add_i/signal); then the reverb on add_{P-1}/signal (3 + 4 (P - 1) [+ 1] nodes)."""
+    from .processors import Add
+    n = len(dag)
+    if n < 3 or (n - 3) % 4 not in (0, 1):
+        return None
+    has_reverb = (n - 3) % 4 == 1
+    p = 1 + (n - 3) // 4
+    noise, additive, add0 = dag[0][0], dag[1][0], dag[2][0]
+    if not (isinstance(additive, InHarmonic) and isinstance(noise, FilteredNoise) and type(add0) is Add):
+        return None
+    if not _plain_keys(dag[0][1], 1) or not _plain_keys(dag[1][1], 4):
+        return None
+    pair = [noise.name + '/signal', additive.name + '/signal']
+    if list(dag[2][1]) != pair:
+        return None
+    additive_keys, noise_keys = [list(dag[1][1])], [dag[0][1][0]]
+    adds, subs = [add0], [None]
+    for i in range(1, p):
+        a, z, sb, m = dag[4 * i - 1], dag[4 * i], dag[4 * i + 1], dag[4 * i + 2]
+        if a[0] is not additive or z[0] is not noise or type(sb[0]) is not Add or type(m[0]) is not Add:
+            return None
+        if not _plain_keys(a[1], 4) or not _plain_keys(z[1], 1):
+            return None
+        if list(sb[1]) != pair or list(m[1]) != [adds[-1].name + '/signal', sb[0].name + '/signal']:
+            return None
+        additive_keys.append(list(a[1]))
+        noise_keys.append(z[1][0])
+        adds.append(m[0])
+        subs.append(sb[0])
+    # every Add node is an object and a name of its own (a re-used one would be overwritten in the outputs dictionary)
+    objs = adds + subs[1:]
+    names = [o.name for o in objs] + [noise.name, additive.name]
+    if len({id(o) for o in objs}) != len(objs) or len(set(names)) != len(names):
+        return None
+    reverb, reverb_keys = None, []
+    if has_reverb:
+        found = _reverb_node(dag[-1], adds[-1].name + '/signal')
+        if found is None or found[0].name in names:
+            return None
+        reverb, reverb_keys = found
+    return Plan(additive, noise, adds[-1], reverb, additive_keys, noise_keys, reverb_keys, p,
+                shape='default_model', adds=adds, subs=subs)
 
 
 def pick_voice_sums(n_segments, n_voices, n_frames, forced=0):
@@ -175,6 +244,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     outputs, i.e. the LAST voice's stems and controls.
     need_stems=True / 'all': every voice's stems ([B, P, N] under outputs['voices']), per-voice kernels."""
     P = plan.n_synths
+    default_shape = plan.shape == 'default_model'
     add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
     hd, vm = _stack_voices(add_ctl[1])               # [R, T, H]; the widest control decides the row order
     amp, _ = _stack_voices(add_ctl[0], vm)           # [R, T, 1]
@@ -316,7 +386,14 @@ def run(plan, inputs, noise=None, need_stems=True):
             else:
                 z_rows, z_n = noise_sig, pz
             prev = torch.empty((B, N), dtype=torch.float32, device=dev)
-            if P > 1:
+            sub = None
+            if P > 1 and default_shape:
+                # default_model.py:68-74: the last voice is added as a pair, add_{P-1} = add_{P-2} + (noise + additive)
+                sub = torch.empty((B, N), dtype=torch.float32, device=dev)
+                _lib.check(_lib_().ddspp_mix_last_voice_paired(_ptr(additive_mix), 1, _ptr(z_rows), z_n, _ptr(noise_last),
+                                                               _ptr(additive_last), _ptr(prev), _ptr(sub), _ptr(dry), B, N,
+                                                               zvm, _stream()))
+            elif P > 1:
                 _lib.check(_lib_().ddspp_mix_last_voice(_ptr(additive_mix), 1, _ptr(z_rows), z_n, _ptr(noise_last),
                                                         _ptr(additive_last), _ptr(prev), _ptr(dry), B, N, zvm, _stream()))
             else:
@@ -328,8 +405,21 @@ def run(plan, inputs, noise=None, need_stems=True):
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}
             outputs[noise_p.name] = {'signal': noise_last, 'controls': {'magnitudes': mags_last}}
-            add_controls = {'signal_0': prev, 'signal_1': noise_last, 'signal_2': additive_last} if P > 1 else \
-                {'signal_0': noise_last, 'signal_1': additive_last}
+            if default_shape:
+                # What this route forms of the dictionary default_model.py's node list leaves: the last voice's pair
+                # (`sub_add_{P-1}`), the mix before it (`add_{P-2}`, signal only) and the dry mix (`add_{P-1}`).  The
+                # `add_i` / `sub_add_i` of the voices before are running sums of stems the compacted bank never
+                # forms: need_stems=True renders them all.
+                if P > 1:
+                    outputs[plan.subs[last].name] = {'signal': sub,
+                                                     'controls': {'signal_one': noise_last, 'signal_two': additive_last}}
+                    outputs[plan.adds[last - 1].name] = {'signal': prev, 'controls': {}}
+                    add_controls = {'signal_one': prev, 'signal_two': sub}
+                else:
+                    add_controls = {'signal_one': noise_last, 'signal_two': additive_last}
+            else:
+                add_controls = {'signal_0': prev, 'signal_1': noise_last, 'signal_2': additive_last} if P > 1 else \
+                    {'signal_0': noise_last, 'signal_1': additive_last}
         else:
             _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), pz, _ptr(dry), B, N, N, zvm,
                                                 _stream()))
@@ -340,15 +430,30 @@ def run(plan, inputs, noise=None, need_stems=True):
             outputs[plan.reverb.name] = module_outputs
         outputs['out'] = module_outputs
         return outputs
-    prev = torch.empty((B, N), dtype=torch.float32, device=dev) if P > 1 else None
-    _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), _ptr(prev), B, P, N, N,
-                                            vmi, _stream()))
-
-    additive_sig = per_voice(additive_sig, (N,))
-    noise_sig = per_voice(noise_sig, (N,))
-
     outputs = {'inputs': inputs}
     outputs.update(inputs)
+    if default_shape:
+        # every `sub_add_i` and `add_i` of default_model.py:56-74, in the DAG's order: add_0 = noise_0 + additive_0,
+        # sub_add_i = noise_i + additive_i, add_i = add_{i-1} + sub_add_i
+        additive_sig = per_voice(additive_sig, (N,))
+        noise_sig = per_voice(noise_sig, (N,))
+        run_sum = core.add_signals([noise_sig[:, 0], additive_sig[:, 0]])
+        outputs[plan.adds[0].name] = {'signal': run_sum,
+                                      'controls': {'signal_one': noise_sig[:, 0], 'signal_two': additive_sig[:, 0]}}
+        for i in range(1, P):
+            sub_i = core.add_signals([noise_sig[:, i], additive_sig[:, i]])
+            outputs[plan.subs[i].name] = {'signal': sub_i,
+                                          'controls': {'signal_one': noise_sig[:, i], 'signal_two': additive_sig[:, i]}}
+            nxt = core.add_signals([run_sum, sub_i])
+            outputs[plan.adds[i].name] = {'signal': nxt, 'controls': {'signal_one': run_sum, 'signal_two': sub_i}}
+            run_sum = nxt
+        dry = run_sum
+    else:
+        prev = torch.empty((B, N), dtype=torch.float32, device=dev) if P > 1 else None
+        _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), _ptr(prev), B, P, N, N,
+                                                vmi, _stream()))
+        additive_sig = per_voice(additive_sig, (N,))
+        noise_sig = per_voice(noise_sig, (N,))
     outputs[additive.name] = {
         'signal': additive_sig[:, last],
         'controls': {'amplitudes': voice(ctl['amplitudes'], (T, 1)),
@@ -357,9 +462,10 @@ def run(plan, inputs, noise=None, need_stems=True):
                      'f0_hz': voice(ctl['f0_hz'], (T, S))}}
     outputs[noise_p.name] = {'signal': noise_sig[:, last],
                              'controls': {'magnitudes': voice(nctl['magnitudes'], (T, K))}}
-    add_controls = {'signal_0': prev, 'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
-        {'signal_0': noise_sig[:, last], 'signal_1': additive_sig[:, last]}
-    outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
+    if not default_shape:
+        add_controls = {'signal_0': prev, 'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
+            {'signal_0': noise_sig[:, last], 'signal_1': additive_sig[:, last]}
+        outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
     module_outputs = outputs[plan.add.name]
     # every voice's stems, which the reference can only get by re-running processors one by one
     # (synthesize_from_csv.py:99-120)

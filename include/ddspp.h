@@ -216,6 +216,13 @@ int ddspp_mix_last_voice(const float* a, int PA, const float* z, int PZ, const f
                          const float* additive_last, float* prev, float* dry, int B, int N, int voice_major,
                          hipStream_t stream);
 
+/* The same end of the chain for the node list of ddsp_piano/default_model.py:44-80 (explicit ddsp.processors.Add nodes):
+ * sub[b] = noise_last[b] + additive_last[b] (`sub_add_{P-1}`, :68-70), dry[b] = prev[b] + sub[b] (`add_{P-1}`, :72-74),
+ * prev = `add_{P-2}`.  All [B, N]. */
+int ddspp_mix_last_voice_paired(const float* a, int PA, const float* z, int PZ, const float* noise_last,
+                                const float* additive_last, float* prev, float* sub, float* dry, int B, int N,
+                                int voice_major, hipStream_t stream);
+
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
 /* ddsp.core.frequency_impulse_response(magnitudes[frames,K], window_size) as magnitudes @ M with the

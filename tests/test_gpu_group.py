@@ -163,8 +163,8 @@ def test_long_segment_whole_file_mode():
 
 
 # ddsp_piano/default_model.py:20-85 builds the group with explicit Add nodes (add_i, sub_add_i) and the
-# noise synth first; that shape is not the batched one but must be accepted and agree with the oracle.
-def _default_model_dag(mod, P, sr):
+# noise synth first; since round 4 that shape runs on the batched route too (polyphonic._recognise_default_model).
+def _default_model_dag(mod, P, sr, reverb_length=2000):
     noise = (mod.FilteredNoise if mod is O else mod.DynamicSizeFilteredNoise)(name='noise', frame_rate=250, sample_rate=sr)
     additive = mod.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True)
     dag = [(noise, ['magnitudes_0']),
@@ -175,12 +175,15 @@ def _default_model_dag(mod, P, sr):
         dag.append((noise, [f'magnitudes_{i}']))
         dag.append((mod.Add(name=f'sub_add_{i}'), ['noise/signal', 'additive/signal']))
         dag.append((mod.Add(name=f'add_{i}'), [f'add_{i - 1}/signal', f'sub_add_{i}/signal']))
-    dag.append((mod.Reverb(trainable=False, reverb_length=2000), [f'add_{P - 1}/signal', 'reverb_ir']))
+    dag.append((mod.Reverb(trainable=False, reverb_length=reverb_length), [f'add_{P - 1}/signal', 'reverb_ir']))
     return dag, noise
 
 
 def test_default_model_dag_shape():
+    """The node list of default_model.py on the batched route (round 4): every need_stems level against the oracle's walk
+    and against this package's own node-by-node walk."""
     import ddsp_piano_amd as dp
+    from ddsp_piano_amd import polyphonic
     rng = np.random.default_rng(31)
     B, P, T, H, K, S, sr, L = 2, 3, 30, 96, 64, 2, 16000, 2000
     N = T * 64
@@ -188,14 +191,72 @@ def test_default_model_dag_shape():
     noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
     odag, _ = _default_model_dag(O, P, sr)
     ref = O.ProcessorGroup(odag)(feats, return_outputs_dict=True, extra_kwargs={'noise': [{'noise': z} for z in noises]})
+    gfeats = {k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}
+    gnoises = [torch.as_tensor(z, device='cuda') for z in noises]
     gdag, gnoise = _default_model_dag(dp, P, sr)
+    plan = polyphonic.recognise(gdag)
+    assert plan is not None and plan.shape == 'default_model' and plan.n_synths == P
+    assert [a.name for a in plan.adds] == ['add_0', 'add_1', 'add_2'] and [s.name for s in plan.subs[1:]] == ['sub_add_1', 'sub_add_2']
     pg = dp.ProcessorGroup(gdag)
-    out = pg({k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}, return_outputs_dict=True,
-             noise=[torch.as_tensor(z, device='cuda') for z in noises])
+    walk = dp.ProcessorGroup(gdag, fast_path=False)(gfeats, return_outputs_dict=True, noise=gnoises)
+    # the reference's call form: the last voice's pair, the mix before it and the dry mix
+    out = pg(gfeats, return_outputs_dict=True, noise=gnoises)
+    assert pg._plan is plan or pg._plan.shape == 'default_model'
     assert rms_err(out['signal'].cpu().numpy(), ref['signal']) < TOL * max(1.0, rms(ref['signal']))
-    for k in ('add_0', f'add_{P - 1}', f'sub_add_{P - 1}'):
-        assert rms_err(out['controls'][k]['signal'].cpu().numpy(), ref['controls'][k]['signal']) < TOL
+    ctl = out['controls']
+    for k in (f'add_{P - 1}', f'sub_add_{P - 1}', f'add_{P - 2}', 'noise', 'additive'):
+        assert rms_err(ctl[k]['signal'].cpu().numpy(), ref['controls'][k]['signal']) < TOL, k
+        assert (ctl[k]['signal'] - walk['controls'][k]['signal']).abs().max().item() < 5e-6, k
+    assert ctl[f'add_{P - 1}']['controls']['signal_one'] is ctl[f'add_{P - 2}']['signal']
+    assert ctl[f'add_{P - 1}']['controls']['signal_two'] is ctl[f'sub_add_{P - 1}']['signal']
+    assert ctl['out'] is ctl['reverb'] and 'voices' not in ctl           # (the compacted route: no per-voice stems)
     assert [p.name for p in pg.processors][:3] == ['noise', 'additive', 'add_0']
+    # audio only
+    audio = pg(gfeats, noise=gnoises)
+    assert (audio - out['signal']).abs().max().item() < 5e-6
+    # every stem: the whole dictionary of the reference's walk
+    full = pg(gfeats, return_outputs_dict=True, noise=gnoises, need_stems=True)['controls']
+    for i in range(P):
+        for k in ([f'add_{i}'] + ([f'sub_add_{i}'] if i else [])):
+            assert rms_err(full[k]['signal'].cpu().numpy(), ref['controls'][k]['signal']) < TOL, k
+            assert rms_err(full[k]['controls']['signal_two'].cpu().numpy(), ref['controls'][k]['controls']['signal_two']) < TOL, k
+    # a single voice (3 nodes + reverb) and no reverb at all
+    for p1, with_reverb in ((1, True), (2, False)):
+        d1, _ = _default_model_dag(dp, p1, sr)
+        o1, _ = _default_model_dag(O, p1, sr)
+        if not with_reverb:
+            d1, o1 = d1[:-1], o1[:-1]
+        assert polyphonic.recognise(d1).shape == 'default_model'
+        r1 = O.ProcessorGroup(o1)(feats, return_outputs_dict=True, extra_kwargs={'noise': [{'noise': z} for z in noises[:p1]]})
+        g1 = dp.ProcessorGroup(d1)(gfeats, return_outputs_dict=True, noise=gnoises[:p1])
+        assert rms_err(g1['signal'].cpu().numpy(), r1['signal']) < TOL * max(1.0, rms(r1['signal']))
+        assert rms_err(g1['controls'][f'add_{p1 - 1}']['signal'].cpu().numpy(), r1['controls'][f'add_{p1 - 1}']['signal']) < TOL
+
+
+def test_default_model_dag_at_dafx22_dims():
+    """default_model.py's own dimensions (16 kHz, two sub-strings, poly 16) at batch 64: the batched route against the node
+    walk on every row and against the oracle on two."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(32)
+    B, P, T, H, K, S, sr, L = 64, 16, 125, 96, 64, 2, 16000, 24000
+    N = T * 64
+    feats = _features(rng, B, P, T, H, K, S, L)
+    noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
+    gfeats = {k: torch.as_tensor(v, device='cuda') for k, v in feats.items()}
+    gnoises = [torch.as_tensor(z, device='cuda') for z in noises]
+    gdag, _ = _default_model_dag(dp, P, sr, reverb_length=L)
+    out = dp.ProcessorGroup(gdag)(gfeats, return_outputs_dict=True, noise=gnoises)
+    walk = dp.ProcessorGroup(gdag, fast_path=False)(gfeats, return_outputs_dict=True, noise=gnoises)
+    scale = max(1.0, rms(walk['signal'].cpu().numpy()))
+    assert rms_err(out['signal'].cpu().numpy(), walk['signal'].cpu().numpy()) < 2e-6 * scale
+    for k in (f'add_{P - 1}', f'sub_add_{P - 1}', f'add_{P - 2}'):
+        assert rms_err(out['controls'][k]['signal'].cpu().numpy(), walk['controls'][k]['signal'].cpu().numpy()) < 2e-6
+    segs = [3, 40]
+    sub = {k: v[segs] for k, v in feats.items()}
+    odag, _ = _default_model_dag(O, P, sr, reverb_length=L)
+    ref = O.ProcessorGroup(odag)(sub, return_outputs_dict=True, extra_kwargs={'noise': [{'noise': z[segs]} for z in noises]})
+    assert rms_err(out['signal'][segs].cpu().numpy(), ref['signal']) < TOL * max(1.0, rms(ref['signal']))
+    assert rms_err(out['controls'][f'add_{P - 1}']['signal'][segs].cpu().numpy(), ref['controls'][f'add_{P - 1}']['signal']) < TOL
 
 
 def test_config5_shape_48k_poly32_long_ir():

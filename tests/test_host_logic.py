@@ -86,6 +86,44 @@ def test_fast_path_recognition():
     assert dp.ProcessorGroup([(a, ['x']), (b, ['a/signal'])])({'x': torch.ones(2)}).shape == (2,)
 
 
+def _default_model_dag(P, with_reverb=True):
+    """ddsp_piano/default_model.py:44-80."""
+    nz = dp.DynamicSizeFilteredNoise(name='noise', sample_rate=16000)
+    add = dp.MultiInharmonic(name='additive', sample_rate=16000, inference=True)
+    ctl = ['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz']
+    dag = [(nz, ['magnitudes_0']), (add, [c + '_0' for c in ctl]), (dp.Add(name='add_0'), ['noise/signal', 'additive/signal'])]
+    for i in range(1, P):
+        dag += [(add, [c + f'_{i}' for c in ctl]), (nz, [f'magnitudes_{i}']),
+                (dp.Add(name=f'sub_add_{i}'), ['noise/signal', 'additive/signal']),
+                (dp.Add(name=f'add_{i}'), [f'add_{i - 1}/signal', f'sub_add_{i}/signal'])]
+    if with_reverb:
+        dag.append((dp.Reverb(trainable=False, reverb_length=100), [f'add_{P - 1}/signal', 'reverb_ir']))
+    return dag
+
+
+def test_default_model_node_list_is_recognised():
+    """Round 4: the node list default_model.py builds (noise first, explicit Add nodes) takes the batched route too."""
+    for P in (1, 2, 5):
+        for rv in (True, False):
+            plan = polyphonic.recognise(_default_model_dag(P, rv))
+            assert plan is not None and plan.shape == 'default_model' and plan.n_synths == P
+            assert (plan.reverb is not None) == rv and plan.reverb_keys == (['reverb_ir'] if rv else [])
+            assert plan.noise_keys == [f'magnitudes_{i}' for i in range(P)] and plan.additive_keys[P - 1][3] == f'f0_hz_{P - 1}'
+            assert [a.name for a in plan.adds] == [f'add_{i}' for i in range(P)] and plan.add is plan.adds[-1]
+    assert polyphonic.recognise(_dag(3)).shape == 'gin'
+    bad = _default_model_dag(3)
+    bad[6] = (bad[6][0], ['add_0/signal', 'sub_add_2/signal'])         # add_1 fed from the wrong pair
+    assert polyphonic.recognise(bad) is None
+    bad = _default_model_dag(3)
+    bad[-1] = (bad[-1][0], ['add_1/signal', 'reverb_ir'])                # reverb not on the last add
+    assert polyphonic.recognise(bad) is None
+    bad = _default_model_dag(3)
+    bad[9] = (bad[5][0], bad[9][1])                                       # an Add object used twice
+    assert polyphonic.recognise(bad) is None
+    with pytest.raises(ValueError):
+        dp.NativeGroup(dp.ProcessorGroup(_default_model_dag(2)), {})     # the one-call driver keeps to polyphonic_dag's shape
+
+
 def test_stack_voices_zero_copy_on_cpu_falls_back_to_copy():
     base = torch.randn(2, 3, 5, 4)
     views = [base[:, i] for i in range(3)]
