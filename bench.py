@@ -705,7 +705,20 @@ def main():
         dw = min(time_steps(lambda: call(pgw, fw), 5, 2) for _ in range(3))
         extra['whole_file'] = {'workload': f'B=1 x {Tw / 250:g} s in one segment, poly={P}, 2 s IR',
                                'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
-        del fw, pgw, f1, pg1
+        del fw, pgw
+        torch.cuda.empty_cache()
+        # ... and a piece of typical MAESTRO length: 20 minutes = 300 000 frames, past the 131 072 frames up to which the
+        # reference's bilinear resize takes rows (t, t + 1) for every sample of frame t (core.walk_weights: the samples that
+        # take row t + 1 itself are marked and the fused kernels keep the file; before round 4 it fell to per-voice
+        # materialised envelopes)
+        Tl = 300000
+        fl, _ = make_features(1, P, Tl, H, K, S, int(2.0 * sr), device, seed=12)
+        pgl = build_group(dp, P, sr)
+        dl = min(time_steps(lambda: call(pgl, fl), 3, 1) for _ in range(2))
+        extra['whole_file_20min'] = {'workload': f'B=1 x {Tl / 250:g} s in one segment, poly={P}, 2 s IR',
+                                     'ms_per_file': dl / 3 * 1e3, 'rtf': (Tl * U * 3 / dl) / sr}
+        del fl, pgl, f1, pg1
+        torch.cuda.empty_cache()
     roof = roof_step = roof_noise = None
     if rank == 0 and not args.no_roofline:
         del feats

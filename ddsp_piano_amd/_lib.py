@@ -110,6 +110,7 @@ SIGNATURES = {
     'ddspp_group_n_samples': (c_int, [c_void_p]),
     'ddspp_group_run': (c_int, [c_void_p] * 11 + [ctypes.c_size_t, c_void_p]),
     'ddspp_linear_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    'ddspp_walk_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),
     'ddspp_fir_matrix_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ddspp_fir_eo_tables_host': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -227,7 +227,9 @@ def _linear_tables_np(n_frames, n_timesteps, rule='legacy'):
     else:
         pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
     fl = np.floor(pos)
-    lo = np.maximum(fl.astype(np.int32), 0).astype(np.int32)
+    # (TF clamps `lower` only from below: where float32(N - 1) * scale rounds up to T -- the last sample of a file of more
+    # than 131 072 frames at hop 96 -- its kernel reads a row past the tensor; that one sample takes the last row here)
+    lo = np.minimum(np.maximum(fl.astype(np.int32), 0), n_frames - 1).astype(np.int32)
     hi = np.minimum(np.maximum(np.ceil(pos).astype(np.int32), 0), n_frames - 1).astype(np.int32)
     w = (pos - fl).astype(F32)
     aligned = False
@@ -235,6 +237,50 @@ def _linear_tables_np(n_frames, n_timesteps, rule='legacy'):
         u = n_timesteps // n_frames
         aligned = bool(np.array_equal(lo, (np.arange(n_timesteps) // u).astype(np.int32)))
     return lo, hi, w, aligned
+
+
+WALK_BLOCK = 8                  # csrc/osc_common.h BLK: samples per block of the frame-walking kernels
+WALK_NEXT_ROW = F32(1.0)        # csrc/osc_common.h: the mark of a sample that takes row t + 1 itself
+
+
+def _walk_weights_np(n_frames, n_timesteps, rule='legacy', first_sample=0, n=None):
+    """(w, walkable): `wlin` as the frame-walking kernels take it -- ddspp_walk_weights_host (csrc/tables.cpp) in numpy.
+
+    The fused / compacted oscillator kernels walk frame t = n // U and interpolate between rows t and t + 1: the resize
+    kernel's (lo, hi) pair while floor(float32(n) * float32(T / N)) == n // U.  Far into a long file (frame 131 073 at
+    hop 96 -- synthesize_midi_file.py:41-73 on a piece of more than 8.7 minutes) the product rounds up to the next whole
+    frame for the last sample(s) of a frame: rows (t + 1, t + 1), weight 0, i.e. x[t + 1] itself; those samples carry
+    the mark 1.0 and the kernels substitute x1 exactly.  walkable = False when some sample needs anything else."""
+    n_frames, n_timesteps, first_sample = int(n_frames), int(n_timesteps), int(first_sample)
+    n = n_timesteps if n is None else int(n)
+    scale = F32(n_frames) / F32(n_timesteps)
+    idx = np.arange(first_sample, first_sample + n, dtype=np.int64)
+    x = idx.astype(F32)
+    if rule == 'half_pixel':
+        pos = (((x + F32(0.5)).astype(F32) * scale).astype(F32) - F32(0.5)).astype(F32)
+    else:
+        pos = (x * scale).astype(F32)
+    fl = np.floor(pos)
+    w = (pos - fl).astype(F32)
+    if n_timesteps % n_frames != 0:
+        return w, False
+    u = n_timesteps // n_frames
+    t = idx // u
+    lo = np.maximum(fl.astype(np.int64), 0)
+    off = lo != t
+    if not off.any():
+        return w, True
+    nxt = off & (lo == t + 1) & (w == 0) & (idx % u >= u - WALK_BLOCK)
+    if not np.array_equal(nxt, off):
+        return w, False
+    w = w.copy()
+    w[nxt] = WALK_NEXT_ROW
+    return w, True
+
+
+@functools.lru_cache(maxsize=64)
+def _walkable_np(n_frames, n_timesteps, rule):
+    return _walk_weights_np(n_frames, n_timesteps, rule)[1]
 
 
 _table_cache = {}
@@ -259,6 +305,32 @@ def linear_tables(n_frames, n_timesteps, device):
         return (torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device),
                 torch.from_numpy(w).to(device), aligned)
     return _cached(('lin', int(n_frames), int(n_timesteps), str(device), rule), build)
+
+
+def walk_weights(n_frames, n_timesteps, device, sample_offset=0):
+    """`wlin` of the frame-walking kernels, float32 [n_timesteps] on `device` (see _walk_weights_np): linear_weights with
+    the next-row mark.  sample_offset > 0: a streamed piece, built on the device and not cached."""
+    if not sample_offset:
+        def build():
+            return torch.from_numpy(_walk_weights_np(int(n_frames), int(n_timesteps), RECALLED['resize'])[0]).to(device)
+        return _cached(('walk', int(n_frames), int(n_timesteps), str(device), RECALLED['resize']), build)
+    global _last_weights
+    on_gpu = torch.device(device).type == 'cuda'
+    key = ('walk', int(n_frames), int(n_timesteps), str(device), int(sample_offset), RECALLED['resize'],
+           _stream().value if on_gpu else None)
+    last = _last_weights
+    if last is not None and last[0] == key:
+        return last[1]
+    w = _linear_weights_at(n_frames, n_timesteps, device, sample_offset, walk=True)
+    _last_weights = (key, w)
+    return w
+
+
+def walkable(n_frames, n_timesteps, sample_offset=0, n=None):
+    """Can the frame-walking kernels render samples sample_offset .. + n of a signal with n_frames per n_timesteps?"""
+    if not sample_offset and n is None:
+        return _walkable_np(int(n_frames), int(n_timesteps), RECALLED['resize'])
+    return _walk_weights_np(n_frames, n_timesteps, RECALLED['resize'], sample_offset, n)[1]
 
 
 def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
@@ -286,15 +358,22 @@ def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
 _last_weights = None
 
 
-def _linear_weights_at(n_frames, n_timesteps, device, sample_offset):
+def _linear_weights_at(n_frames, n_timesteps, device, sample_offset, walk=False):
     scale = float(F32(n_frames) / F32(n_timesteps))
-    n = torch.arange(int(sample_offset), int(sample_offset) + int(n_timesteps), device=device,
-                     dtype=torch.int64).to(torch.float32)
+    idx = torch.arange(int(sample_offset), int(sample_offset) + int(n_timesteps), device=device, dtype=torch.int64)
+    n = idx.to(torch.float32)
     if RECALLED['resize'] == 'half_pixel':
         pos = (n + 0.5) * scale - 0.5
     else:
         pos = n * scale
-    return (pos - torch.floor(pos)).contiguous()
+    fl = torch.floor(pos)
+    w = pos - fl
+    if walk and int(n_timesteps) % int(n_frames) == 0:
+        # the next-row mark of _walk_weights_np (whether the piece is walkable at all is the caller's question: walkable())
+        u = int(n_timesteps) // int(n_frames)
+        nxt = (fl.to(torch.int64) == idx // u + 1) & (w == 0)
+        w = torch.where(nxt, torch.ones_like(w), w)
+    return w.contiguous()
 
 
 def linear_exact_frames(upsampling):
@@ -551,7 +630,9 @@ def fused_synthesis_supported(n_frames, n_samples):
     u = n_samples // n_frames
     if u % 8 != 0 or n_frames + 1 >= n_samples:
         return False
-    return _linear_tables_np(int(n_frames), int(n_samples), RECALLED['resize'])[3]
+    # (round 4: no longer "lo[n] == n // U everywhere" -- files past 131 072 frames keep the fast path, see
+    # _walk_weights_np; only signals the frame walk cannot reproduce at all fall back to the three-operator route)
+    return _walkable_np(int(n_frames), int(n_samples), RECALLED['resize'])
 
 
 def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_samples,
@@ -561,7 +642,7 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
     h = harmonic_distribution.shape[-1]
     u = n_samples // t
     dev = f0_hz.device
-    _, _, wlin, _ = linear_tables(t, n_samples, dev)
+    wlin = walk_weights(t, n_samples, dev)
     whann = hann_window(2 * u, dev)
     if out is None:
         out = torch.empty((r, n_samples), dtype=torch.float32, device=dev)
@@ -594,7 +675,7 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     p = r // b
     u = n_samples // t
     dev = f0_hz.device
-    wlin = linear_weights(t, n_samples, dev, sample_offset)
+    wlin = walk_weights(t, n_samples, dev, sample_offset)
     whann = hann_window(2 * u, dev)
     lib = _lib_()
     nbytes = int(lib.ddspp_polyphonic_additive_workspace_bytes(b, p, t, s, h, u))
@@ -622,7 +703,7 @@ def oscillator_phase_state(f0_hz, n_chunks, upsampling, sample_rate, harmonic_sh
     r, t, s = f0_hz.shape
     h = int(harmonic_shifts.shape[-1]) if harmonic_shifts is not None else int(n_harmonics)
     dev = f0_hz.device
-    wlin = linear_weights(t, t * int(upsampling), dev, sample_offset)
+    wlin = walk_weights(t, t * int(upsampling), dev, sample_offset)
     lib = _lib_()
     nbytes = int(lib.ddspp_oscillator_phase_state_workspace_bytes(r, s, h, int(n_chunks)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

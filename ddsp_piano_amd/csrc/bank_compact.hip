@@ -278,6 +278,12 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) fe[i][j] = x0[j] + dx * wl[i];          // legacy bilinear (core.resample)
             }
+            if (r + BLK == U && wl[BLK - 1] == WALK_NEXT_ROW) {      // a long file: see osc_common.h (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) fe[i][j] = (wl[i] == WALK_NEXT_ROW) ? x1[j] : fe[i][j];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < BLK; ++i)
@@ -302,7 +308,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
-                    const float f = x0[j] + (x1[j] - x0[j]) * wli;
+                    const float f = (wli == WALK_NEXT_ROW) ? x1[j] : x0[j] + (x1[j] - x0[j]) * wli;
                     ph[j] = ph[j] + omega_of<false>(f, sr, rsr);
                     const float a = (f >= nyq) ? 0.0f : __builtin_fmaf(da[j], whi, am0[j]);
                     acc = __builtin_fmaf(a, cos_reduced(mod_2pi(ph[j] + off[j])), acc);

@@ -108,12 +108,11 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
             }
     // ---- tables -------------------------------------------------------------------------------------------------
     {
-        std::vector<int> lo(N), hi(N);
         std::vector<float> w(N), hann(2 * U);
-        int aligned = 0;
-        rc = ddspp_resample_tables_host(T, N, c.resize_rule, lo.data(), hi.data(), w.data(), &aligned);
-        if (rc == DDSPP_OK && !aligned) {
-            ddspp_set_error("group_create: the bilinear source rows of T=%d -> N=%d are not frame aligned", T, N);
+        int walkable = 0;
+        rc = ddspp_walk_weights_host(T, N, c.resize_rule, 0, N, w.data(), &walkable);
+        if (rc == DDSPP_OK && !walkable) {
+            ddspp_set_error("group_create: the bilinear source rows of T=%d -> N=%d do not follow the frame walk", T, N);
             rc = DDSPP_EINVAL;
         }
         if (rc == DDSPP_OK) rc = ddspp_hann_window_host(2 * U, hann.data());

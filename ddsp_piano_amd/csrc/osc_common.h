@@ -53,6 +53,12 @@ struct OscParams {
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };
 
 constexpr int BLK = 8;        // samples per unrolled block; divides U and the 1000-sample chunk
+// `wlin` as the frame-walking kernels take it (ddspp_walk_weights_host): the fractional part of float32(n) * float32(T / N),
+// or this mark where that product rounds up to the next whole frame -- far into a long file (frame 131 073 at hop 96) the
+// reference's resize takes row t + 1 with weight 0 for the last sample(s) of frame t, i.e. x[t + 1] itself, which
+// x0 + (x1 - x0) w cannot produce exactly for any w.  A fractional part is never 1, marked samples are a suffix of their
+// frame's last block: one scalar compare per frame pair finds them.
+constexpr float WALK_NEXT_ROW = 1.0f;
 constexpr int TILE = 32;      // samples per LDS reduction tile
 constexpr int TSTRIDE = 68;   // words per tile row: 16-byte aligned rows, 17 quads apart -> ds_read_b128 conflict free
 

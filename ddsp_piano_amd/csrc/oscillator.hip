@@ -253,6 +253,14 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                     if (MODE != MODE_PREPASS && act[j]) ae[i][j] = __builtin_fmaf(a1[j] - a0[j], w1[i], a0[j]);
                 }
             }
+            if (!CFREQ) {
+                if (r + BLK == U && wl[BLK - 1] == WALK_NEXT_ROW) {       // a long file: see osc_common.h (wave-uniform)
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                        for (int j = 0; j < VPL; ++j) fe[i][j] = (wl[i] == WALK_NEXT_ROW) ? x1[j] : fe[i][j];
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < BLK; ++i)
@@ -482,13 +490,18 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 // moving-frequency pre-pass ran at a third of the issue rate.  srv / rsrv: sample rate and its reciprocal in VECTOR
 // registers (an SGPR operand in a VOP3 fma costs 4.2 cycles).  Arithmetic and order are those of omega_of.
 template <bool FAST>
-__device__ __forceinline__ float scan_block_staged(float ph, float x0, float x1, const float* w, float srv, float rsrv) {
+__device__ __forceinline__ float scan_block_staged(float ph, float x0, float x1, const float* w, float srv, float rsrv,
+                                                   bool next_row = false) {
     float om[BLK], q[BLK];
     const float dx = x1 - x0;
 #pragma unroll
     for (int i = 0; i < BLK; ++i) om[i] = dx * w[i];
 #pragma unroll
     for (int i = 0; i < BLK; ++i) om[i] = x0 + om[i];
+    if (next_row) {                       // wave-uniform: the frame's last block holds marked samples (osc_common.h)
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = (w[i] == WALK_NEXT_ROW) ? x1 : om[i];
+    }
 #pragma unroll
     for (int i = 0; i < BLK; ++i) om[i] = om[i] * DDSPP_TWO_PI_F32;          // inharm_synth.py:69
     if (FAST) {                                                              // :70, div_const (ddspp_common.h)
@@ -783,12 +796,14 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                     weights_at(0, wl);
                 }
                 if (woff + BLK < PRE_W && n + BLK < n_hi) weights_at(woff + BLK, wn);
+                const bool nxt = r + BLK == U &&
+                                 __builtin_amdgcn_readfirstlane(__float_as_int(wl[BLK - 1])) == __float_as_int(WALK_NEXT_ROW);
                 if (fast) {
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<true>(ph[j], x0[j], x1[j], wl, srv, rsrv);
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<true>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv);
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
                 }
 #pragma unroll
                 for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
@@ -917,8 +932,9 @@ __global__ void __launch_bounds__(256) osc_prepass_chunk_kernel(const OscParams 
             const int nn = min(n + BLK, n_hi - BLK);
 #pragma unroll
             for (int i = 0; i < BLK; ++i) wn[i] = wlin_c[nn + i];
+            const bool nxt = r + BLK == U && wl[BLK - 1] == WALK_NEXT_ROW;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv);
+            for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
 #pragma unroll
             for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
             r += BLK;

@@ -95,6 +95,7 @@ int ddspp_resample_tables_host(int T, int N, int rule, int* lo, int* hi, float* 
         const float fl = floorf(pos);
         int l = (int)fl, h = (int)ceilf(pos);
         if (l < 0) l = 0;
+        if (l > T - 1) l = T - 1;       // (TF does not: the last sample of a file past 131 072 frames would read a row past the tensor)
         if (h < 0) h = 0;
         if (h > T - 1) h = T - 1;
         lo[n] = l;
@@ -119,6 +120,40 @@ int ddspp_linear_weights_host(int T, int N, int rule, long long first_sample, in
         const float pos = rule == 1 ? (x + 0.5f) * scale - 0.5f : x * scale;
         w[i] = pos - floorf(pos);
     }
+    return DDSPP_OK;
+}
+
+// `wlin` as the frame-walking kernels take it (ddspp_harmonic_synthesis, ddspp_polyphonic_additive,
+// ddspp_oscillator_phase_state): those kernels walk frame t = n / U and interpolate between rows t and t + 1, which IS the
+// resize kernel's (lo, hi) pair as long as floor(float32(n) * float32(T / N)) == n / U.  Far into a long file (frame
+// 131 073 at hop 96: what synthesize_midi_file.py renders for a piece of more than 8.7 minutes) the product rounds UP to
+// the next whole frame for the last sample(s) of a frame: lo = hi = t + 1, weight 0 -- the sample takes x[t + 1] itself.
+// Such samples get the mark 1.0 (a fractional part never is 1; WALK_NEXT_ROW in osc_common.h) and the kernels substitute
+// x1 exactly.  *walkable = 0 when a sample needs anything else (a row below t, a row above with a non-zero weight, more
+// marked samples than the 8 of a frame's last block, N not a multiple of T): the caller then takes the three-operator
+// route with the full tables of ddspp_resample_tables_host.
+int ddspp_walk_weights_host(int T, int N, int rule, long long first_sample, int n, float* w, int* walkable) {
+    DDSPP_REQUIRE(T >= 1 && N >= 1 && n >= 1 && first_sample >= 0 && w, "walk_weights_host: bad arguments");
+    DDSPP_REQUIRE(rule == 0 || rule == 1, "walk_weights_host: unknown rule %d", rule);
+    const float scale = (float)T / (float)N;
+    bool ok = (N % T == 0);
+    const long long u = ok ? N / T : 1;
+    for (int i = 0; i < n; ++i) {
+        const long long idx = first_sample + i;
+        const float x = (float)idx;
+        const float pos = rule == 1 ? (x + 0.5f) * scale - 0.5f : x * scale;
+        const float fl = floorf(pos);
+        float wi = pos - fl;
+        const long long t = idx / u, lo = (long long)fl < 0 ? 0 : (long long)fl;
+        if (ok && lo != t) {
+            // (the last frame of a whole signal clamps: rows T - 1, T - 1 either way -- callers pass pieces of one signal
+            // whose controls hold a look-ahead frame, so t + 1 exists wherever it is asked for)
+            if (lo == t + 1 && wi == 0.0f && idx % u >= u - 8) wi = 1.0f;
+            else ok = false;
+        }
+        w[i] = wi;
+    }
+    if (walkable) *walkable = ok ? 1 : 0;
     return DDSPP_OK;
 }
 

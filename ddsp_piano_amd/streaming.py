@@ -11,9 +11,10 @@ internally between two samples.  For this path that is exactly:
     every shipped sample rate); plus ONE frame of look-ahead, because frame t is interpolated towards frame t + 1;
     plus the piece's ABSOLUTE sample position: the reference's bilinear resize forms float32(n) * (T / N) and takes
     its fractional part as the interpolation weight, which rounds differently at n = 12000 and n = 1212000
-    (core.linear_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128.  That
-    only holds while the product does not round ACROSS a frame boundary: core.linear_exact_frames(U) frames (8.7 min
-    at 24 kHz), past which push() raises;
+    (core.walk_weights) -- on a pitch drop of four octaves inside one frame that is 0.03 rad at partial 128.  Past
+    core.linear_exact_frames(U) frames (8.7 min at 24 kHz) the product rounds up to the NEXT whole frame for the last
+    sample(s) of a frame: those samples carry a mark in the weight table and take row t + 1 itself (round 4; push()
+    used to raise there);
   * FilteredNoise: the time-varying FIR reaches Lw - 1 - delay samples back and `delay` samples forward: the piece is
     filtered with ceil((Lw - 1 - delay) / U) frames of context behind it and ceil(delay / U) frames ahead
     (``noise_reach``: one frame each way at 16 / 24 kHz, two at ENSTDkCl's 8 kHz with 64 bands) and cropped.  Noise
@@ -130,11 +131,15 @@ class StreamingSynthesizer:
         have = next(iter(self._buf.values())).shape[1]
         back, _ = self._reach()
         look = min(self._lookahead(), have - nb)     # fewer only at the end of the signal: nothing follows there
-        limit = core.linear_exact_frames(U)
-        if self.frame + nb + look > limit:
-            raise ValueError(f'streaming stops at frame {limit} ({limit * U} samples): past it float32(n) * (T / N) of the '
-                             'reference\'s bilinear resize rounds across a frame boundary and a piece can no longer equal '
-                             'the one-call render (core.linear_exact_frames); render such a file in one call')
+        # Past core.linear_exact_frames(U) the reference's float32(n) * (T / N) rounds up to the next whole frame for the
+        # last sample(s) of a frame; the kernels take those samples from row t + 1 (core.walk_weights marks them at the
+        # piece's absolute positions), so a piece still equals the one-call render.  Only hours into a signal does the
+        # table stop following the frame walk at all (more than a block of such samples per frame):
+        if self.frame + nb + look > core.linear_exact_frames(U) and \
+                not core.walkable(nb + look, (nb + look) * U, self.frame * U, (nb + look) * U):
+            raise ValueError(f'streaming stops at frame {self.frame}: this far into a signal the reference\'s bilinear '
+                             'resize no longer follows the frame walk of the fused kernels (core.walkable); render such '
+                             'a file in one call')
         sl = slice(0, nb + look)
         amp, vm = self._rows(self.akeys[0], sl)
         hd, _ = self._rows(self.akeys[1], sl, vm)

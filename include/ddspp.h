@@ -60,14 +60,23 @@ void ddspp_reload_options(void);
 int ddspp_hann_window_host(int n, float* window);
 /* Source rows and weights of ddsp.core.resample(method='linear') = tf.compat.v1.image.resize(BILINEAR,
  * align_corners=False): lo[N], hi[N] (int32), w[N] (float32).  rule 0: TF1 legacy kernel, pos = n * T/N;
- * rule 1: half-pixel centres.  `wlin` of ddspp_harmonic_synthesis / ddspp_polyphonic_additive is w (they require
- * *aligned == 1: N = T * U and lo[n] == n / U, true for rule 0 and every shipped sample / frame rate pair). */
+ * rule 1: half-pixel centres.  *aligned == 1: N = T * U and lo[n] == n / U everywhere (rule 0, every shipped sample /
+ * frame rate pair, up to 131 072 frames at hop 96); `wlin` of ddspp_harmonic_synthesis / ddspp_polyphonic_additive is
+ * the table of ddspp_walk_weights_host (== w while aligned). */
 int ddspp_resample_tables_host(int T, int N, int rule, int* lo, int* hi, float* w, int* aligned);
 /* w[n] for samples first_sample .. first_sample + n - 1 of a signal with T frames per N samples: `wlin` of a streamed
  * piece (ddspp_polyphonic_additive / ddspp_oscillator_phase_state with phase_state_in).  The resize kernel multiplies
  * float32(sample index) by the float32 scale at the ABSOLUTE index; the fractional part rounds differently at
  * different magnitudes, so a piece takes the weights the one-call render has at its positions. */
 int ddspp_linear_weights_host(int T, int N, int rule, long long first_sample, int n, float* w);
+/* `wlin` as ddspp_harmonic_synthesis / ddspp_polyphonic_additive / ddspp_oscillator_phase_state take it: w of
+ * ddspp_linear_weights_host, with the mark 1.0 on the samples whose source rows are (t + 1, t + 1) instead of (t, t + 1)
+ * -- far into a long file float32(n) * float32(T / N) rounds up to the next whole frame for the last sample(s) of a
+ * frame (from frame 131 073 at hop 96: synthesize_midi_file.py:41-73 on a piece of more than 8.7 minutes) and the
+ * reference's resize then takes x[t + 1] itself; the kernels substitute it exactly.  *walkable (may be NULL) = 0 when
+ * the frame walk cannot reproduce the table (N % T != 0, half-pixel rule, hours-long signals): use the three-operator
+ * route (ddspp_resample_linear + ddspp_cos_oscillator_bank) then. */
+int ddspp_walk_weights_host(int T, int N, int rule, long long first_sample, int n, float* w, int* walkable);
 /* FIR length Lw of ddsp.core.frequency_impulse_response(magnitudes[.., K], window_size) and the row count NJ of the
  * even/odd tables (0: the shape has none -- use ddspp_fir_matrix_host + ddspp_fir_from_magnitudes). */
 int ddspp_fir_tables_shape(int K, int window_size, int* Lw, int* NJ);

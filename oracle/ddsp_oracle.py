@@ -203,7 +203,10 @@ def linear_resample_positions(n_frames, n_timesteps):
     else:                                          # TF1 LegacyScaler: out * scale
         pos = (np.arange(n_timesteps, dtype=F32) * scale).astype(F32)
     fl = np.floor(pos).astype(F32)
-    lo = np.maximum(fl.astype(np.int64), 0)
+    # (TF clamps `lower` only from below.  In a file long enough for float32(N - 1) * scale to round up to T -- past
+    # 131 072 frames at hop 96 -- its kernel reads one row past the tensor for the very last sample: undefined there;
+    # here, and in the library, that sample takes the last row.)
+    lo = np.minimum(np.maximum(fl.astype(np.int64), 0), n_frames - 1)
     hi = np.minimum(np.maximum(np.ceil(pos).astype(np.int64), 0), n_frames - 1)
     w = (pos - fl).astype(F32)
     return lo, hi, w

@@ -352,7 +352,8 @@ def test_plan_cache_pins_what_a_capture_recorded():
 
 
 def test_linear_exact_frames_bound():
-    """past this many frames float32(n) * float32(1 / U) rounds across a frame boundary; streaming refuses."""
+    """past this many frames float32(n) * float32(1 / U) rounds across a frame boundary (round 4: the samples
+    concerned are marked in the weight table, test_walk_weights_...; streaming no longer refuses)."""
     import numpy as np
     from ddsp_piano_amd import core
     f = core.linear_exact_frames(96)
@@ -365,6 +366,58 @@ def test_linear_exact_frames_bound():
     bad_last = np.floor(np.float32(f * 96 - 1) * scale) != f - 1
     assert bad_first or bad_last
     assert core.linear_exact_frames(32) > core.linear_exact_frames(96) >= core.linear_exact_frames(192)
+
+
+def test_walk_weights_mark_the_samples_that_take_the_next_row():
+    """Round 4: past linear_exact_frames the reference's resize takes rows (t + 1, t + 1) for the last sample(s) of a frame;
+    the frame-walking kernels get those samples marked (core._walk_weights_np == ddspp_walk_weights_host) and substitute
+    x[t + 1] exactly.  The mark reproduces the three-operator tables sample for sample."""
+    import ctypes
+    import numpy as np
+    from ddsp_piano_amd import _lib, core
+    lib = _lib.load()
+    U = 96
+    f = core.linear_exact_frames(U)
+    # (1) a short signal: no marks, the plain fractional parts
+    w, ok = core._walk_weights_np(750, 72000)
+    assert ok and np.array_equal(w, core._linear_tables_np(750, 72000)[2]) and not (w == 1).any()
+    # (2) a 150 000-frame file: marked samples exist, all of them last samples of a frame past `f`, and the walk
+    # reproduces the table: x[lo] + (x[hi] - x[lo]) w == (mark ? x[t + 1] : x[t] + (x[t + 1] - x[t]) w)
+    T = 150000
+    N = T * U
+    lo, hi, wt, aligned = core._linear_tables_np(T, N)
+    w, ok = core._walk_weights_np(T, N)
+    assert ok and not aligned and core.fused_synthesis_supported(T, N)
+    marked = np.nonzero(w == 1)[0]
+    assert marked.size > 1000 and marked.min() // U >= f - 1 and (marked % U >= U - 8).all()
+    n = np.arange(N)
+    t = n // U
+    assert np.array_equal(lo[marked], np.minimum(t[marked] + 1, T - 1)) and (wt[marked] == 0).all()
+    rest = np.ones(N, bool)
+    rest[marked] = False
+    assert np.array_equal(lo[rest], t[rest]) and np.array_equal(w[rest], wt[rest])
+    rng = np.random.default_rng(5)
+    x = rng.uniform(20, 4000, T).astype(np.float32)
+    ref = (x[lo] + (x[hi] - x[lo]) * wt).astype(np.float32)
+    t1 = np.minimum(t + 1, T - 1)
+    walk = np.where(w == 1, x[t1], (x[t] + (x[t1] - x[t]) * w).astype(np.float32))
+    assert np.array_equal(ref, walk)
+    # (3) the C builder gives the same table, also for a piece at an absolute position
+    for first, cnt in ((0, N), (140000 * U, 2000 * U)):
+        wc = np.empty(cnt, np.float32)
+        flag = ctypes.c_int(-1)
+        tc = T if first == 0 else cnt // U
+        assert lib.ddspp_walk_weights_host(tc, tc * U, 0, first, cnt, wc.ctypes.data_as(ctypes.c_void_p), ctypes.byref(flag)) == 0
+        wp, okp = core._walk_weights_np(tc, tc * U, 'legacy', first, cnt)
+        assert flag.value == 1 and okp and np.array_equal(wc, wp)
+        assert np.array_equal(core.walk_weights(tc, tc * U, 'cpu', first).numpy(), wp)
+    assert np.array_equal(wp, w[140000 * U:142000 * U])                 # the piece's table is the file's
+    # (4) not walkable: a ratio that is no whole number, the half-pixel rule
+    assert not core._walk_weights_np(37, 1000)[1] and not core._walk_weights_np(750, 72000, 'half_pixel')[1]
+    flag = ctypes.c_int(-1)
+    wc = np.empty(1000, np.float32)
+    assert lib.ddspp_walk_weights_host(37, 1000, 0, 0, 1000, wc.ctypes.data_as(ctypes.c_void_p), ctypes.byref(flag)) == 0
+    assert flag.value == 0
 
 
 def test_per_voice_tensors_are_recognised_as_slices_of_one_buffer():
