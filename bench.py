@@ -624,7 +624,16 @@ def main():
                 ts.append(time.perf_counter() - t0)
             tg = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=device)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            extra[name] = {'ms': float(tg.item()) * 1e3, 'bytes_received': (world - 1) * B * N * 4,
+            nbytes = (world - 1) * B * N * 4
+            gbs = nbytes / max(float(tg.item()), 1e-9) * 1e-9
+            # what the number is read against on the node: xGMI is point to point, one ~153 GB/s link per peer
+            # (MI355X_MICROARCH.md: 7 links per GPU); the receiving rank takes one block from each of its world - 1 peers
+            links = min(world - 1, 7)
+            extra[name] = {'ms': float(tg.item()) * 1e3, 'bytes_received': nbytes, 'gb_per_s': gbs,
+                           'xgmi': {'links_used': links, 'gb_per_s_per_link': 153.0, 'ceiling_gb_per_s': 153.0 * links,
+                                    'frac_of_ceiling': (gbs / (153.0 * links)) if links else None,
+                                    'note': 'bytes one rank receives / the collective\'s time, against one xGMI link per '
+                                            'sending peer' + ('; ranks share one GPU here: not a link measurement' if share_gpu else '')},
                            'note': 'the collective alone, synchronous (median of 5, max over ranks)'}
     if rank == 0:
         extra['step_ms'] = ms_summary(step_ts)   # the timed steps themselves (this rank)

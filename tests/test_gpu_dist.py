@@ -56,10 +56,28 @@ parallel.gather_audio(ref, buf)
 uneven = parallel.gather_audio_uneven(ref, B)
 to_one, work = parallel.gather_audio(ref, dst=0, async_op=True)      # dist.gather over RCCL
 work.wait()
+# bench.py's `pipelined` loop: the gather of step i is issued async_op=True into one of TWO landing buffers and only
+# waited for (a stream-level wait) before the gather of step i + 1, so it runs on RCCL's stream under the next step's
+# kernels; every landed buffer must hold ITS step's audio
+pg, bufs, state, landed, wants = group(), [torch.empty_like(ref) for _ in range(2)], {'work': None}, [], []
+for i in range(10):
+    f = dict(feats)
+    f['amplitudes_0'] = feats['amplitudes_0'] + 0.05 * i          # a different render every step
+    pg.noise.seed = 100 + i
+    audio = pg(f)
+    wants.append(audio.clone())
+    if state['work'] is not None:
+        state['work'].wait()
+        landed.append(bufs[(i - 1) & 1].clone())
+    _, state['work'] = parallel.gather_audio(audio, bufs[i & 1], async_op=True, dst=0)
+state['work'].wait()
+landed.append(bufs[9 & 1].clone())
+pipelined = all(torch.equal(a, b) for a, b in zip(landed, wants)) and len(landed) == 10 and \
+    not torch.equal(wants[0], wants[1])
 dist.barrier()
 torch.cuda.synchronize()
 res = {'same': bool(torch.equal(out, ref)), 'gather': bool(torch.equal(buf, ref)) and bool(torch.equal(to_one, ref)),
-       'uneven': bool(torch.equal(uneven, ref)),
+       'uneven': bool(torch.equal(uneven, ref)), 'pipelined': bool(pipelined),
        'finite': bool(torch.isfinite(out).all()), 'shape': list(out.shape)}
 dist.destroy_process_group()
 print('RESULT ' + json.dumps(res))
@@ -79,7 +97,7 @@ def test_single_rank_rccl_shard_and_gather():
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
     res = json.loads(line[len('RESULT '):])
-    assert res == {'same': True, 'gather': True, 'uneven': True, 'finite': True, 'shape': [3, 40 * 96]}
+    assert res == {'same': True, 'gather': True, 'uneven': True, 'pipelined': True, 'finite': True, 'shape': [3, 40 * 96]}
 
 
 def test_bench_distributed_branch_runs():
@@ -187,3 +205,87 @@ def test_bench_two_rank_launcher_flow_on_one_gpu():
     assert line['config']['global_batch'] == 8 and line['value'] > 0 and line['steps'] == 3
     assert line['allgather']['bytes_received'] == 4 * 72000 * 4 and line['gather_to_rank0']['ms'] > 0
     assert line['gather'].startswith('to rank 0')
+
+
+_WORKER8 = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ['DDSPP_ROOT'], 'tests')); sys.path.insert(0, os.environ['DDSPP_ROOT'])
+from util import synth_controls, synth_ir
+import ddsp_piano_amd as dp
+from ddsp_piano_amd import parallel
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+sr, P, H, K, L, B, T = 24000, 2, 32, 96, 2000, 13, 30
+KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'], noise_controls=['magnitudes'],
+            reverb_controls=['reverb_ir'])
+rng = np.random.default_rng(13)                             # the same on every rank
+feats = {}
+for i in range(P):
+    for k, v in synth_controls(rng, B, T, H, S=1, K=K, silent_frac=0.0).items():
+        feats[f'{k}_{i}'] = torch.as_tensor(v, device='cuda')
+feats['reverb_ir'] = torch.as_tensor(synth_ir(rng, B, L), device='cuda')
+noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, T * 96]).astype(np.float32), device='cuda')
+def group():
+    return dp.ProcessorGroup(dp.polyphonic_dag(
+        dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+        dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'), n_synths=P, **KEYS))
+lo, hi = parallel.shard_range(B, world, rank)
+class Local:
+    def __call__(self, f):
+        return group()(f, noise=noise[lo:hi])
+one = parallel.synthesize_sharded(Local(), feats, dst=0)     # 13 rows over 8 ranks: 2 2 2 2 2 1 1 1, gathered to rank 0
+res = {'rows': hi - lo}
+if rank == 0:
+    ref = group()(feats, noise=noise)
+    res['ok'] = [list(one.shape) == list(ref.shape), float((one - ref).abs().max() / ref.abs().max())]
+else:
+    res['ok'] = [one is None, 0.0]
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(res))
+"""
+
+
+def test_eight_ranks_on_one_gpu_uneven_batch_to_rank0():
+    """the world-size-8 flow (config 4's rank count) on the one GPU a test box has: eight gloo ranks
+    share cuda:0, a global batch of 13 is sharded unevenly (2 2 2 2 2 1 1 1) and gathered to rank 0, which must hold the
+    unsharded render; the other ranks get None."""
+    port = _free_port()
+    procs = []
+    for rank in range(8):
+        env = _env(port)
+        env.update({'RANK': str(rank), 'WORLD_SIZE': '8', 'LOCAL_RANK': str(rank)})
+        procs.append(subprocess.Popen([sys.executable, '-c', _WORKER8], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    rows = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+        res = json.loads([l for l in so.splitlines() if l.startswith('RESULT ')][-1][len('RESULT '):])
+        assert res['ok'][0] and res['ok'][1] < 1e-6, res
+        rows.append(res['rows'])
+    assert rows == [2, 2, 2, 2, 2, 1, 1, 1]
+
+
+def test_bench_eight_rank_launcher_flow_on_one_gpu():
+    """`python bench.py --gpus 8` end to end on one GPU (ranks share it, gloo): spawn, shard, gather to rank 0, ONE JSON line
+    with n_gpus == 8 and the collectives' GB/s next to the xGMI figure they will be read against on the node."""
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'DDSPP_BENCH_SHARE_GPU': '1', 'DDSPP_BENCH_BACKEND': 'gloo'})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                        '--batch', '2', '--seconds', '1', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                       env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['shared_gpu'] is True and line['config']['global_batch'] == 16 and line['value'] > 0
+    g = line['gather_to_rank0']
+    assert g['bytes_received'] == 7 * 2 * 24000 * 4 and g['gb_per_s'] > 0
+    assert g['xgmi']['links_used'] == 7 and abs(g['xgmi']['ceiling_gb_per_s'] - 7 * 153) < 1
+    assert line['allgather']['xgmi']['frac_of_ceiling'] > 0
