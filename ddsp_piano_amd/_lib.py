@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
 SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
-           'noise.hip', 'noise_win.hip', 'noise_bands.hip', 'reverb.hip', 'reverb_part.hip', 'fdn.hip', 'group.cpp']
+           'noise.hip', 'noise_win.hip', 'noise_bands.hip', 'reverb.hip', 'reverb_part.hip', 'fdn.hip', 'probe.hip', 'group.cpp']
 ARCH = 'gfx950'
 HEADERS = ['ddspp_common.h', 'osc_common.h', 'noise_win.h', 'reverb_part.h', os.path.join('..', '..', 'include', 'ddspp.h')]
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
@@ -110,6 +110,7 @@ SIGNATURES = {
     'ddspp_group_n_samples': (c_int, [c_void_p]),
     'ddspp_group_run': (c_int, [c_void_p] * 11 + [ctypes.c_size_t, c_void_p]),
     'ddspp_linear_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    'ddspp_hbm_read_probe': (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     'ddspp_walk_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),
     'ddspp_fir_matrix_host': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1129,10 +1129,16 @@ def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, 
     return (out, last) if split_last else out
 
 
-def uniform_noise(shape, seed=0, offset=0, device=None):
-    """U(-1, 1) noise from the library's Philox4x32-10 (stand-in for the unseeded tf.random.uniform)."""
-    device = device or default_device()
+def uniform_noise(shape, seed=0, offset=0, device=None, out=None):
+    """U(-1, 1) noise from the library's Philox4x32-10 (stand-in for the unseeded tf.random.uniform).  out: a contiguous
+    float32 tensor of that many elements (a multiple of 4) to draw into."""
     n = int(np.prod(shape))
+    if out is not None:
+        if out.numel() != n or n % 4 or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError('uniform_noise(out=): a contiguous float32 tensor of prod(shape) elements, a multiple of 4')
+        _lib.check(_lib_().ddspp_uniform_noise(_ptr(out), n, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _stream()))
+        return out.view(shape)
+    device = device or default_device()
     npad = (n + 3) // 4 * 4
     out = torch.empty(npad, dtype=torch.float32, device=device)
     _lib.check(_lib_().ddspp_uniform_noise(_ptr(out), npad, int(seed) & (2 ** 64 - 1),

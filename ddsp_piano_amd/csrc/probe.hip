@@ -1,0 +1,46 @@
+// Measurement aid behind the C-ABI (bench.py's `roofline.measured_peak`): a pure read of a buffer with the access
+// pattern of the materialised oscillator bank -- every wavefront streams its own contiguous region, 1 KB per
+// instruction, sixteen instructions in flight -- and nothing else.  No arithmetic beyond one add per loaded float, no
+// stores: whatever rate this reaches on a buffer is a ceiling for ddspp_cos_oscillator_bank on the same buffer.
+// (tools/ubench/stream_patterns.hip is where the pattern was chosen: 6.2-6.4 TB/s of the 8 TB/s on the MI355X.)
+#include "ddspp_common.h"
+
+namespace ddspp {
+
+template <int UNROLL>
+__global__ void __launch_bounds__(256) hbm_read_streams_kernel(const float* __restrict__ x, size_t per_wave, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float* p = x + wave * per_wave;
+    float acc = 0.f;
+    constexpr size_t step = 64 * 4;
+    for (size_t i = 0; i < per_wave; i += step * UNROLL) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + i + u * step) + lane);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+    if (acc == 1.2345e30f) sink[0] = acc;        // never true for finite audio-rate data: keeps the loads alive
+}
+
+}  // namespace ddspp
+
+extern "C" {
+
+// Reads the first `n_floats` (rounded down to a whole number of 16 KB wavefront steps) of x with `n_waves` concurrent
+// streams (a multiple of 4; 2048 = two per SIMD is what the graded kernel runs); *bytes_read: what was read.
+int ddspp_hbm_read_probe(const float* x, size_t n_floats, int n_waves, float* sink, size_t* bytes_read, hipStream_t stream) {
+    DDSPP_REQUIRE(x && sink && n_waves >= 4 && n_waves % 4 == 0, "hbm_read_probe: bad arguments");
+    DDSPP_REQUIRE((uintptr_t)x % 16 == 0, "hbm_read_probe: the buffer must be 16-byte aligned");
+    constexpr size_t chunk = 64 * 4 * 16;                 // floats per wavefront step
+    const size_t per_wave = (n_floats / (size_t)n_waves) / chunk * chunk;
+    DDSPP_REQUIRE(per_wave > 0, "hbm_read_probe: buffer too small for %d streams", n_waves);
+    hipLaunchKernelGGL((ddspp::hbm_read_streams_kernel<16>), dim3(n_waves / 4), dim3(256), 0, stream, x, per_wave, sink);
+    DDSPP_LAUNCH_CHECK();
+    if (bytes_read) *bytes_read = per_wave * (size_t)n_waves * sizeof(float);
+    return DDSPP_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,10 @@ stream), and creating one inside a capture invalidates it.
     fast = CapturedGroup(group, example_features, return_outputs_dict=True)
     out = fast(features)            # same keys / shapes / strides as the example; returns the STATIC output tensors
 
+``group`` may be a ProcessorGroup or a NativeGroup (then the graph holds the kernels ddspp_group_run enqueues).  A replay
+costs one multi-tensor copy of the inputs into the captured buffers plus the noise draw; a caller that writes its controls
+straight into ``fast.inputs`` (the captured buffers, same keys) and calls ``fast()`` pays neither copy.
+
 The outputs are overwritten by the next call: copy what has to outlive it.  FilteredNoise nodes get fresh uniform noise
 on every call (drawn outside the graph with the processor's own counter-based generator -- a captured generator call
 would replay the same numbers for ever), or the ``noise=`` the caller passes ([B, P, N], as ProcessorGroup).
@@ -89,19 +93,30 @@ class CapturedGroup:
         kw = {'noise': self._noise} if self._noise is not None else {}
         return self.group(self._in, return_outputs_dict=self.return_outputs_dict, **kw)
 
+    @property
+    def inputs(self):
+        """The captured input buffers ({key: tensor}): written in place, `fast()` replays without copying anything."""
+        return self._in
+
     def _draw(self):
         b, p, n = self._noise.shape
-        z = self._noise_procs[0].draw_noise(b * p, n, self._noise.device)       # one counter step per call, as eager
-        self._noise.copy_(z.view(b, p, n))
+        if (b * p * n) % 4 == 0:                                                  # one counter step per call, as eager
+            self._noise_procs[0].draw_noise(b * p, n, self._noise.device, out=self._noise.view(b * p, n))
+        else:
+            self._noise.copy_(self._noise_procs[0].draw_noise(b * p, n, self._noise.device).view(b, p, n))
 
-    def __call__(self, features, noise=None):
-        src = []
-        for k in self._keys:
+    def __call__(self, features=None, noise=None):
+        dst, src = [], []
+        for k in (self._keys if features is not None else ()):
             v = features[k]
+            if v is self._in[k]:                      # the caller wrote into the captured buffer
+                continue
             if tuple(v.shape) != tuple(self._in[k].shape):
                 raise ValueError(f'{k}: captured for shape {tuple(self._in[k].shape)}, got {tuple(v.shape)}')
+            dst.append(self._in[k])
             src.append(v if v.dtype == torch.float32 else core.tf_float32(v))
-        torch._foreach_copy_([self._in[k] for k in self._keys], src)
+        if dst:
+            torch._foreach_copy_(dst, src)
         if self._noise is not None:
             if noise is None:
                 self._draw()

@@ -231,9 +231,9 @@ class FilteredNoise(Processor):
     def _n_samples(self, magnitudes):
         return int(self.n_samples)
 
-    def draw_noise(self, batch_size, n_samples, device):
+    def draw_noise(self, batch_size, n_samples, device, out=None):
         call = next(self._calls)
-        return core.uniform_noise((batch_size, n_samples), seed=self.seed, offset=call << 40, device=device)
+        return core.uniform_noise((batch_size, n_samples), seed=self.seed, offset=call << 40, device=device, out=out)
 
     def get_signal(self, magnitudes, noise=None):
         magnitudes = core.tf_float32(magnitudes)

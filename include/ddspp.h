@@ -232,6 +232,14 @@ int ddspp_mix_last_voice_paired(const float* a, int PA, const float* z, int PZ, 
                                 const float* additive_last, float* prev, float* sub, float* dry, int B, int N,
                                 int voice_major, hipStream_t stream);
 
+/* ---- measurement aid --------------------------------------------------------------------------- */
+
+/* A pure read of x[0 .. n_floats) by n_waves concurrent wavefront streams (1 KB per instruction, sixteen in flight: the
+ * access pattern of ddspp_cos_oscillator_bank on materialised envelopes, nothing else) -- the HBM rate the graded kernel
+ * could reach at most on that buffer in this run (bench.py: roofline.measured_peak).  sink: one float of device memory
+ * (never written for finite data); *bytes_read (host, may be NULL): the bytes the launch reads. */
+int ddspp_hbm_read_probe(const float* x, size_t n_floats, int n_waves, float* sink, size_t* bytes_read, hipStream_t stream);
+
 /* ---- FilteredNoise --------------------------------------------------------------------------- */
 
 /* ddsp.core.frequency_impulse_response(magnitudes[frames,K], window_size) as magnitudes @ M with the

@@ -55,3 +55,34 @@ def test_replay_equals_the_eager_call(dict_form):
     assert (a - b).abs().max().item() > 1e-4
     with pytest.raises(ValueError):
         fast({k: v[:, :100] if k != 'reverb_ir' else v for k, v in feats.items()})
+
+
+def test_native_group_captured_with_inputs_written_in_place():
+    """The one-call driver's kernels as a graph, controls written straight into the captured buffers (`fast.inputs`,
+    `fast()`): no per-replay copies; equal to the eager NativeGroup call on the same inputs and noise."""
+    import ddsp_piano_amd as dp
+    sr, B, P, T, H, K, S, L = 24000, 1, 4, 125, 128, 96, 1, 6000
+    N = T * (sr // 250)
+    group = dp.ProcessorGroup(dp.polyphonic_dag(
+        dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+        dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'),
+        n_synths=P, **KEYS))
+    f0 = _features(1, B, P, T, H, K, S, L)
+    native = dp.NativeGroup(group, f0)
+    fast = dp.CapturedGroup(native, f0, return_outputs_dict=True)
+    assert set(fast.inputs) == set(f0)
+    rng = np.random.default_rng(4)
+    for seed in (5, 6):
+        feats = _features(seed, B, P, T, H, K, S, L)
+        noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, N]).astype(np.float32), device='cuda')
+        want = native(feats, return_outputs_dict=True, noise=noise)
+        for k, v in feats.items():
+            fast.inputs[k].copy_(v)                   # the caller's producer writes here
+        got = fast(noise=noise)
+        assert torch.equal(got['signal'], want['signal'])
+        assert torch.equal(got['controls']['add']['signal'], want['controls']['add']['signal'])
+        same = fast(fast.inputs, noise=noise)          # passing the captured buffers themselves: nothing is copied either
+        assert torch.equal(same['signal'], want['signal'])
+    a = fast()['signal'].clone()                      # the library's own noise stream: a fresh draw per replay
+    b = fast()['signal'].clone()
+    assert not torch.equal(a, b) and torch.isfinite(a).all()

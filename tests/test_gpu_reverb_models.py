@@ -37,7 +37,7 @@ def test_multi_instrument_feedback_delay_reverb_matches_oracle():
     ref = O.MultiInstrumentFeedbackDelayReverb(tables, n, sr, exact_solve=True)(pm)
     for b in range(4):
         err = rms_err(got[b], ref[b])
-        assert err < 5e-4 * rms(ref[b]), (b, err, rms(ref[b]))
+        assert err < 2e-4 * rms(ref[b]), (b, err, rms(ref[b]))      # (64-network distribution: max 4.7e-5)
     assert np.array_equal(got[0], got[2])                            # same instrument, same impulse response
     # reshape_embedding is split-then-stack: a plain reshape(D, 4) of the table row is a different network
     wrong = dict(tables)
@@ -142,4 +142,6 @@ def test_fdn_complex64_inverse_switch_against_the_complex64_oracle():
         errs[mode] = np.asarray([rms_err(audio[b], ref_audio[b]) / rms(ref_audio[b]) for b in range(n)])
     print('FDN audio error vs the complex64 oracle, per room (2 damped, 4 lively):', errs)
     assert (errs['float64'][:2] < 1e-4).all() and (errs['complex64'][:2] < 1e-4).all()
-    assert (errs['complex64'] < 5e-3).all() and (errs['float64'] < 5e-3).all()
+    # (round 4: over 64 networks of the same draw the worst audio error is 4.4e-5 with either solve,
+    # profiles/r04_fdn_error_distribution.txt -- the bound follows the measured distribution, not a guess)
+    assert (errs['complex64'] < 2e-4).all() and (errs['float64'] < 2e-4).all()
