@@ -46,6 +46,17 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     const cfloat_p whann_c = (cfloat_p)(uintptr_t)p.whann;
     const float nyq = p.nyq, sr = p.sr, rsr = p.rsr;
     const int* offs = reinterpret_cast<const int*>(tile);    // exclusive offsets of the sub-rows (written by the kernel)
+    // The Hann cross-fade weights of a block come from an LDS copy of the window (two broadcast ds_read_b128 per block,
+    // issued before the phase scan, used in stage 4): as VECTOR operands.  A VALU instruction with an SGPR operand issues
+    // at ~1.7x the cost of one without (tools/ubench/fma_ceiling: 1.75 against 1.03 ns per wave64 multiply-add), and the
+    // scalar form needed an s_load_dwordx8 and eight s_mov per block on top.
+    // The copy lives in the tile's own padding -- rows are TSTRIDE = 68 words for 64 lanes: four spare words per row, the
+    // float4 w[4 q .. 4 q + 3] in row q -- so the kernel's LDS footprint (16 workgroups per CU) does not grow; hops above
+    // 4 TILE = 128 (48 kHz) keep the rest behind the tile.
+    auto hann4 = [&](int q) {
+        const float* src = q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE);
+        return *reinterpret_cast<const float4*>(src);
+    };
     int vk[VPL], vs[VPL], lrow[VPL], vidx[VPL];
     bool valid[VPL];
     float kmul[VPL];
@@ -236,12 +247,9 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 
     // Hann cross-fade weights w[r + i] and bilinear weights wlin[n0 + i] of the block: scalar loads issued one block
     // ahead (wave-uniform addresses -> s_load_dwordx8)
-    float w1[BLK], wl[BLK];
+    float wl[BLK];
 #pragma unroll
-    for (int i = 0; i < BLK; ++i) {
-        w1[i] = whann_c[r + i];
-        wl[i] = wlin_c[n_begin + i];
-    }
+    for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n_begin + i];
 
     // Two loops: the outer one walks frames, the inner one the blocks of a frame.  The controls of frame t + 2 are
     // requested when frame t starts and only touched when it ends: inside the inner loop nothing depends on them, so
@@ -249,15 +257,14 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     for (int n0 = n_begin; n0 < n_end;) {
     const int nf_end = min(n0 + (U - r), n_end);
     for (; n0 < nf_end; n0 += BLK) {
-        float wnext[BLK], wlnext[BLK];
+        float wlnext[BLK], w1[BLK];
         {
-            const int rn = (r + BLK == U) ? 0 : r + BLK;
             const int nn = min(n0 + BLK, N - BLK);
 #pragma unroll
-            for (int i = 0; i < BLK; ++i) {
-                wnext[i] = whann_c[rn + i];
-                wlnext[i] = wlin_c[nn + i];
-            }
+            for (int i = 0; i < BLK; ++i) wlnext[i] = wlin_c[nn + i];
+            const float4 wa = hann4(r >> 2), wb = hann4((r >> 2) + 1);
+            w1[0] = wa.x; w1[1] = wa.y; w1[2] = wa.z; w1[3] = wa.w;
+            w1[4] = wb.x; w1[5] = wb.y; w1[6] = wb.z; w1[7] = wb.w;
         }
         if (fast && const_freq) {
             // ---- stage 1: the float32 phase scan (VPL sequential chains, interleaved) ---------------------------
@@ -270,6 +277,9 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                     pv[i][j] = ph[j];
                 }
             finish_block(pv, pv, w1, std::false_type{});
+            // (a marker the paths do not share: without one the compiler sinks the common stages of the three inlined
+            // finish_block bodies into one copy behind selector flags -- a dozen scalar branches per block)
+            asm volatile("; bank block: constant frequency");
         } else if (fast) {
             float pv[BLK][VPL], fe[BLK][VPL], om[BLK][VPL];
 #pragma unroll
@@ -297,8 +307,13 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                     ph[j] = ph[j] + om[i][j];
                     pv[i][j] = ph[j];
                 }
-            if (need_mask) finish_block(pv, fe, w1, std::true_type{});
-            else finish_block(pv, fe, w1, std::false_type{});
+            if (need_mask) {
+                finish_block(pv, fe, w1, std::true_type{});
+                asm volatile("; bank block: moving frequency, Nyquist mask");
+            } else {
+                finish_block(pv, fe, w1, std::false_type{});
+                asm volatile("; bank block: moving frequency");
+            }
         } else {
             // generic path (negative / denormal / huge frequencies, unchecked sample rates): IEEE division, fmod
             // based floormod, one sample at a time -- correctness only
@@ -317,10 +332,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
             }
         }
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) {
-            w1[i] = wnext[i];
-            wl[i] = wlnext[i];
-        }
+        for (int i = 0; i < BLK; ++i) wl[i] = wlnext[i];
         // ---- tile bookkeeping ---------------------------------------------------------------------------------
         tpos += BLK;
         if (tpos == TILE || n0 + BLK >= n_end) {
@@ -428,6 +440,10 @@ bank_compact_kernel(const OscParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < p.U; i += 64) {                   // w[0 .. U) of the Hann window into the tile's padding (bank_slot)
+        const int q = i >> 2;
+        (q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE))[i & 3] = p.whann[i];
+    }
     if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
         bank_slot<2>(p, tile, c);
     else
@@ -466,7 +482,7 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
 }  // namespace
 
 void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
-    const size_t lds = (size_t)(TILE * TSTRIDE) * sizeof(float);
+    const size_t lds = (size_t)(TILE * TSTRIDE + (p.U > 4 * TILE ? p.U - 4 * TILE : 0)) * sizeof(float);   // tile (+ what of the Hann window its padding cannot hold)
     const dim3 grid((unsigned)((size_t)p.R * p.spans * p.wmax)), blk(64);
     if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1>), grid, blk, lds, stream, p);
     else hipLaunchKernelGGL((bank_compact_kernel<2>), grid, blk, lds, stream, p);
