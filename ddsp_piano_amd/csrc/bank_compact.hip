@@ -168,6 +168,9 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     int cpos = 0, tpos = 0, tile_n0 = n_begin;
 
     auto flush_tile = [&](int nt0, int count) {
+#if defined(DDSPP_BANK_ABLATE) && (DDSPP_BANK_ABLATE & 1)
+        return;
+#endif
         // column sums: lane (col, half) adds 32 of the 64 lane partials of sample `col`
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -222,7 +225,11 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
         for (int i = 0; i < BLK; ++i)
 #pragma unroll
+#if defined(DDSPP_BANK_ABLATE) && (DDSPP_BANK_ABLATE & 4)
+            for (int j = 0; j < VPL; ++j) pv[i][j] = pv[i][j] * 0.5f;
+#else
             for (int j = 0; j < VPL; ++j) pv[i][j] = __builtin_amdgcn_cosf(pv[i][j]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- stage 4: Hann cross-fade of the amplitudes (core.upsample_with_windows: a0 w[U + r] + a1 w[r] with
         // w[U + r] + w[r] = 1 to an ulp = a0 + (a1 - a0) w[r]), Nyquist mask, harmonic sum over the lane's own -------
@@ -241,8 +248,15 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
                 acc[i] = __builtin_fmaf(a, pv[i][j], acc[i]);
             }
+#if defined(DDSPP_BANK_ABLATE) && (DDSPP_BANK_ABLATE & 2)
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) keep += acc[i];
+        if (keep == 1.2345e30f) tile[lane] = keep;
+#else
 #pragma unroll
         for (int i = 0; i < BLK; ++i) tile[(tpos + i) * TSTRIDE + lane] = acc[i];
+#endif
     };
 
     // Hann cross-fade weights w[r + i] and bilinear weights wlin[n0 + i] of the block: scalar loads issued one block
