@@ -221,6 +221,81 @@ __device__ __forceinline__ void inharmonic_controls_body(const InharmParams& p) 
     }
 }
 
+// More than 256 harmonics (no shipped configuration; up to 512): the register-resident body above would keep three arrays
+// of 32 values per lane and spilled 7 400 registers' worth.  This one keeps nothing: the harmonics
+// of a frame are walked twice, 16 at a time -- once for the sum the normalisation divides by, once more to form, cut,
+// normalise and store them -- at the price of evaluating the scale function twice.  Same arithmetic per element; the sum
+// is added up in the same lane order (j ascending, then the DPP row sum).
+__device__ __forceinline__ void inharmonic_controls_wide_body(const InharmParams& p) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, rowi = lane >> 4;
+    const size_t nframes = (size_t)p.R * p.T;
+    const size_t frame = ((size_t)blockIdx.x * 4 + (size_t)(threadIdx.x >> 6)) * 4 + rowi;
+    const bool live = frame < nframes;
+    const size_t fr = min(frame, nframes - 1);
+    const int H = p.H, nj = (H + 15) / 16;
+    const float f0 = p.f0_hz[fr * p.S];
+    const float inharm = fmaxf(p.inharm_coef[fr], 0.0f);
+    float amp = apply_scale(p.scale, p.amplitudes[fr]);
+    bool is_last = false;
+    unsigned b_last = 0, tt = 0;
+    if (p.shifts_last) {
+        const unsigned row = (unsigned)(fr / (size_t)p.T), last_lo = (unsigned)(p.R / p.P) * (unsigned)(p.P - 1);
+        tt = (unsigned)(fr - (size_t)row * p.T);
+        is_last = live && (p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1);
+        b_last = p.vmajor ? row - last_lo : row / (unsigned)p.P;
+    }
+    const float* src = p.harmonic_distribution + fr * H;
+    auto element = [&](int k, float& hd, float& shift, bool& above) {      // :37-44, :186
+        const float m = (float)(k + 1);
+        float g = m * m;
+        g = g * inharm + 1.0f;
+        g = sqrtf(g);
+        shift = g - 1.0f;
+        hd = apply_scale(p.scale, src[k]);
+        above = (f0 * m) * g >= p.nyquist;
+    };
+    // pass 1: the sum the normalisation divides by (:194-198 before the cut, or :210-214 after it)
+    float sum = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+        const int k = sub + 16 * j;
+        float hd = 0.0f, shift;
+        bool above = false;
+        if (k < H) element(k, hd, shift, above);
+        if (p.normalize_after_nyquist_cut && p.normalize_below_nyquist && above) hd = 0.0f;
+        if (k < H) sum += hd;
+    }
+    const float tot = row_sum(sum);
+    const float den = tot == 0.0f ? 1e-7f : tot;                            // core.safe_divide
+    if (p.normalize_below_nyquist) amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
+    amp = amp / p.n_substrings;
+    // pass 2: form, (normalise,) cut, (normalise,) store
+    int last = 0;
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+        const int k = sub + 16 * j;
+        if (k >= H) continue;
+        float hd, shift;
+        bool above;
+        element(k, hd, shift, above);
+        if (!p.normalize_after_nyquist_cut) hd = hd / den;
+        if (p.normalize_below_nyquist && above) hd = 0.0f;
+        if (p.normalize_after_nyquist_cut) hd = hd / den;
+        if (live) {
+            p.hd_out[frame * H + k] = hd;
+            if (p.shifts_out) p.shifts_out[frame * H + k] = shift;
+            if (is_last) p.shifts_last[((size_t)b_last * p.T + tt) * H + k] = shift;
+        }
+        if (amp * hd != 0.0f) last = k + 1;
+    }
+    if (live && sub == 0) p.amp_out[frame] = amp;
+    if (p.count_out) {
+        last = row_max(last);
+        if (live && sub == 0) p.count_out[frame] = last;
+    }
+}
+__global__ void __launch_bounds__(256) inharmonic_controls_wide_kernel(const InharmParams p) { inharmonic_controls_wide_body(p); }
+
 // (93 registers, five wavefronts per SIMD: held to 64 registers / eight wavefronts the compiler spreads the loads out
 // between the uses and the kernel takes 370 us instead of 195; three or four passes per wavefront 215 / 250 us)
 template <int NJ, int CTL_PASS>
@@ -386,7 +461,7 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     else if (nj <= 8) hipLaunchKernelGGL((inharmonic_controls_kernel<8, 2>), grid, block, 0, stream, p);
     else if (nj <= 12) hipLaunchKernelGGL((inharmonic_controls_kernel<12, 1>), grid, block, 0, stream, p);
     else if (nj <= 16) hipLaunchKernelGGL((inharmonic_controls_kernel<16, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((inharmonic_controls_kernel<32, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(inharmonic_controls_wide_kernel, grid, block, 0, stream, p);      // 257 .. 512 harmonics
     if (audible_out)
         hipLaunchKernelGGL(frames_moved_kernel, dim3(stream_grid(frames)), dim3(256), 0, stream, f0_hz, inharm_coef,
                            audible_out, R, T, S);

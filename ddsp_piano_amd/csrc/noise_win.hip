@@ -333,7 +333,8 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                 const float *gl, *xl;
                 win_lane<OPL, BPF>(g, G, Xs, fr, min(ph, NP - 1), gl, xl);
                 const int qA = g.q_hi0 + (OPL / 4) * (8 * p + 2 * wibs);     // phase A's first block
-                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4, qA - g.nsteps + 1, g.gs, acc);
+                const int trim = (dbg & 8) ? OPL / 4 : 0;        // timing only (wrong audio): what would 11 % fewer steps buy?
+                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4 - trim, qA - g.nsteps + 1 + trim, g.gs, acc);
             }
             // out_last: the segment's last voice leaves on its own and stays out of the sum -- the outputs dictionary
             // of the reference's DAG holds that voice's noise next to the mix
