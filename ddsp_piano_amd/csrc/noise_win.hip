@@ -520,7 +520,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     int tpw = ddspp_option("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
     if (tpw < 1) tpw = 1;
     while (tpw > 1 && tasks / tpw < 768) tpw >>= 1;          // few tasks (a single segment): one unit per workgroup
-    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design
+    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk
     const dim3 grid((unsigned)((tasks + tpw - 1) / tpw)), block(256);
 #define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \
     hipLaunchKernelGGL((noise_win_fused_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, CE, \
