@@ -86,3 +86,22 @@ def test_native_group_captured_with_inputs_written_in_place():
     a = fast()['signal'].clone()                      # the library's own noise stream: a fresh draw per replay
     b = fast()['signal'].clone()
     assert not torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_replay_with_the_large_lds_noise_instances():
+    """The 32 kHz / 48 kHz FilteredNoise instances raise their dynamic-LDS limit at every launch (per device):
+    that has to be legal inside a stream capture too.  48 kHz dims (hop 192, K = 96) and 32 kHz (hop 128, K = 128)."""
+    import ddsp_piano_amd as dp
+    for sr, H, K in ((48000, 64, 96), (32000, 64, 128)):
+        B, P, T, S, L = 2, 2, 125, 1, 4000
+        N = T * (sr // 250)
+        group = dp.ProcessorGroup(dp.polyphonic_dag(
+            dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+            dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'),
+            n_synths=P, **KEYS))
+        fast = dp.CapturedGroup(group, _features(1, B, P, T, H, K, S, L))
+        feats = _features(2, B, P, T, H, K, S, L)
+        noise = torch.as_tensor(np.random.default_rng(sr).uniform(-1, 1, [B, P, N]).astype(np.float32), device='cuda')
+        want = group(feats, noise=noise)
+        got = fast(feats, noise=noise)
+        assert torch.equal(got, want), sr
