@@ -303,6 +303,155 @@ __global__ void __launch_bounds__(256)
 inharmonic_controls_kernel(const InharmParams p) {
     inharmonic_controls_body<NJ, CTL_PASS>(p);
 }
+// The same conditioning for the flags every model of the reference ships with (cut above Nyquist FIRST, then
+// normalise: normalize_below_nyquist and normalize_after_nyquist_cut both set) and a whole number of 16-harmonic groups,
+// with the scale function a template argument (round 4).  Same arithmetic per element and the same order of additions as
+// inharmonic_controls_body -- the two agree bit for bit (tests/test_gpu_controls.py) -- but a third of the instructions:
+//   * the body above re-decided the scale function with scalar branches at every element, kept hd[] / shift[] in
+//     register tuples the compiler shuffled with ~25 v_mov_b64 per element, and wrapped every element in an EXEC branch;
+//     here an element is straight-line code under one wave-uniform "is any of the four frames' groups alive" test;
+//   * the inharmonicity factor sqrt(1 + B k^2) only DECIDES here (is the partial at or above Nyquist?) unless the frame
+//     belongs to a segment's last voice, whose shifts the outputs dictionary keeps: the decision is taken from the
+//     hardware's 1-ulp v_sqrt_f32 and redone with the correctly rounded square root (fifteen instructions) only for a
+//     wavefront that holds a partial within 1e-6 of Nyquist -- the two can differ by 2^-22 at most; the shifts that are
+//     stored come from the correctly rounded one, in a loop of their own that most wavefronts skip.
+template <int KIND>
+__device__ __forceinline__ float scale_of(const ScaleFn& s, float x) {
+    if (KIND == SCALE_EXP_SIGMOID) return s.max_value * sigmoid_pow(x, s.log_exponent) + s.threshold;
+    if (KIND == SCALE_EXP_TANH) return s.max_value * sigmoid_pow(2.0f * (s.gain * x), s.log_exponent) + s.threshold;
+    return x;
+}
+
+template <int NJ, int KIND>
+__global__ void __launch_bounds__(256) inharmonic_controls_lean_kernel(const InharmParams p) {
+    constexpr int CTL_PASS = 2;
+    const int lane = threadIdx.x & 63, sub = lane & 15, rowi = lane >> 4;
+    const size_t nframes = (size_t)p.R * p.T;
+    const size_t wave0 = ((size_t)blockIdx.x * 4 + (size_t)wave_uniform(threadIdx.x >> 6)) * (4 * CTL_PASS);
+    if (wave0 >= nframes) return;
+    constexpr int H = 16 * NJ;
+    const float nyq = p.nyquist, near = p.nyquist * 1e-6f;
+    float raw_f0[CTL_PASS], raw_in[CTL_PASS], raw_amp[CTL_PASS];
+#pragma unroll
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t fr = min(wave0 + 4 * u + rowi, nframes - 1);
+        raw_f0[u] = p.f0_hz[fr * p.S];                                  // f0_hz[..., 0:1]  (:264)
+        raw_in[u] = p.inharm_coef[fr];
+        raw_amp[u] = p.amplitudes[fr];
+    }
+    unsigned row0 = 0, tt0 = 0, last_lo = 0;
+    if (p.shifts_last) {
+        row0 = (unsigned)wave0 / (unsigned)p.T;
+        tt0 = (unsigned)wave0 - row0 * (unsigned)p.T;
+        last_lo = (unsigned)(p.R / p.P) * (unsigned)(p.P - 1);          // voice major: first row of the last voice
+    }
+    unsigned dead[CTL_PASS];           // bit j: harmonics 16 j .. 16 j + 15 of the lane's frame are cut whole
+    float raw_hd[CTL_PASS][NJ];
+    const size_t wframes = min((size_t)(4 * CTL_PASS), nframes - wave0);
+    const __amdgpu_buffer_rsrc_t window = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.harmonic_distribution + wave0 * H), 0, (int)(wframes * H * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t frame = wave0 + 4 * u + rowi;
+        unsigned d = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (raw_f0[u] * (float)(16 * j + 1) >= nyq) d |= 1u << j;
+        if (frame >= nframes) d = ~0u;
+        dead[u] = d;
+        // (buffer loads: a cut group's lanes point past the end of the wavefront's 8-frame window and get their 0.0
+        // from the bounds check, without a memory access and without a branch -- all sixteen loads are in flight at once;
+        // as `dead ? 0 : src[k]` each became an EXEC branch holding the load AND the wait for it)
+        const unsigned at = (unsigned)((4 * u + rowi) * H + sub) * 4u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            raw_hd[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(window, ((d >> j) & 1) ? 0x40000000u : at + 64u * j, 0, 0));
+    }
+    const float subf = (float)(sub + 1);
+#pragma unroll
+    for (int u = 0; u < CTL_PASS; ++u) {
+        const size_t frame = wave0 + 4 * u + rowi;
+        const bool live = frame < nframes;
+        const float f0 = raw_f0[u];
+        const float inharm = fmaxf(raw_in[u], 0.0f);                    // :183
+        float amp = scale_of<KIND>(p.scale, raw_amp[u]);                // :185
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f, h5 = 0.f, h6 = 0.f, h7 = 0.f;
+        float* const hd[8] = {&h0, &h1, &h2, &h3, &h4, &h5, &h6, &h7};
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool dj = (dead[u] >> j) & 1;
+            if (!__all(dj)) {                                           // (wave-uniform)
+                const float m = subf + (float)(16 * j);                 // linspace(1, H, H)
+                float x = m * m;                       // tf.math.pow(int_multiplier, 2)        :37
+                x = x * inharm + 1.0f;                 //                                        :38
+                const float fm = f0 * m;
+                float freq = fm * __builtin_amdgcn_sqrtf(x);            // f0_hz * int_multiplier * inharm_factor :42
+                if (__any(fabsf(freq - nyq) <= near)) {
+                    asm volatile("; a partial at Nyquist: the correctly rounded square root decides");    // (and keeps this a branch)
+                    freq = fm * sqrtf(x);
+                }
+                const float v = scale_of<KIND>(p.scale, raw_hd[u][j]);                      // :186
+                const float c = (dj || freq >= nyq) ? 0.0f : v;         // core.remove_above_nyquist :200-208
+                *hd[j] = c;
+                sum += c;
+            }
+        }
+        amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
+        {                                                               // :210-214
+            const float tot = row_sum(sum);
+            const float den = tot == 0.0f ? 1e-7f : tot;                // core.safe_divide
+            const float rden = 1.0f / den;
+            if (__all(den > 1e-30f && den < 1e30f)) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) *hd[j] = div_const(*hd[j], den, rden);
+            } else {                                                    // (the IEEE division, whatever it gives)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (!((dead[u] >> j) & 1)) *hd[j] = *hd[j] / den;
+            }
+        }
+        amp = amp / p.n_substrings;                                     // :269 (1.0 for InHarmonic)
+        int last = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (amp * *hd[j] != 0.0f) last = sub + 16 * j + 1;
+        if (live) {
+            float* dst = p.hd_out + frame * H + sub;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dst[16 * j] = *hd[j];
+            if (sub == 0) p.amp_out[frame] = amp;
+        }
+        if (p.count_out) {
+            last = row_max(last);
+            if (live && sub == 0) p.count_out[frame] = last;            // bit 16 is added by frames_moved_kernel
+        }
+        // harmonic_shifts: every frame's when the caller keeps them all, else those of the segments' last voices
+        bool is_last = false;
+        unsigned row = row0, tt = tt0 + 4 * (unsigned)u + (unsigned)rowi;
+        if (p.shifts_last) {
+            while (tt >= (unsigned)p.T) {
+                tt -= (unsigned)p.T;
+                ++row;
+            }
+            is_last = live && (p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1);
+        }
+        if (__any(live && (p.shifts_out != nullptr || is_last))) {
+            const unsigned b = p.vmajor ? row - last_lo : row / (unsigned)p.P;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float m = subf + (float)(16 * j);
+                float g = m * m;
+                g = g * inharm + 1.0f;
+                g = sqrtf(g);                          //                                        :39
+                const float shift = g - 1.0f;          //                                        :44
+                if (live && p.shifts_out) p.shifts_out[frame * H + sub + 16 * j] = shift;
+                if (is_last) p.shifts_last[((size_t)b * p.T + tt) * H + sub + 16 * j] = shift;
+            }
+        }
+    }
+}
+
 // Bit 16 of the per-frame info word: the frame's frequencies may differ from the previous frame's (some f0 sub-string
 // or the clamped inharmonicity coefficient moved; never set on a row's first frame).  Equal inputs give equal harmonic
 // frequencies, so a clear bit is a guarantee; the oscillator pre-pass finds its constant chunks with it.  A kernel of
@@ -456,7 +605,20 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     const int nj = (H + 15) / 16;
     const size_t per_wg = (size_t)4 * 4 * (nj <= 8 ? 2 : 1);            // four wavefronts of 4 * CTL_PASS frames
     const dim3 grid((unsigned)((frames + per_wg - 1) / per_wg)), block(256);
-    if (nj <= 4) hipLaunchKernelGGL((inharmonic_controls_kernel<4, 2>), grid, block, 0, stream, p);
+    const bool lean = normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 && nj <= 8 && (nj == 4 || nj == 6 || nj == 8);
+#define DDSPP_LEAN(NJ)                                                                                              \
+    do {                                                                                                            \
+        if (scale_kind == SCALE_EXP_SIGMOID)                                                                        \
+            hipLaunchKernelGGL((inharmonic_controls_lean_kernel<NJ, SCALE_EXP_SIGMOID>), grid, block, 0, stream, p); \
+        else if (scale_kind == SCALE_EXP_TANH)                                                                      \
+            hipLaunchKernelGGL((inharmonic_controls_lean_kernel<NJ, SCALE_EXP_TANH>), grid, block, 0, stream, p);    \
+        else                                                                                                        \
+            hipLaunchKernelGGL((inharmonic_controls_lean_kernel<NJ, SCALE_NONE>), grid, block, 0, stream, p);        \
+    } while (0)
+    if (lean && nj == 8 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(8);
+    else if (lean && nj == 6 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(6);
+    else if (lean && nj == 4 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(4);
+    else if (nj <= 4) hipLaunchKernelGGL((inharmonic_controls_kernel<4, 2>), grid, block, 0, stream, p);
     else if (nj <= 6) hipLaunchKernelGGL((inharmonic_controls_kernel<6, 2>), grid, block, 0, stream, p);
     else if (nj <= 8) hipLaunchKernelGGL((inharmonic_controls_kernel<8, 2>), grid, block, 0, stream, p);
     else if (nj <= 12) hipLaunchKernelGGL((inharmonic_controls_kernel<12, 1>), grid, block, 0, stream, p);

@@ -18,6 +18,7 @@ struct WinGeom {
     int wpr;      // windows per row
     int opl;      // outputs per lane
     int bpf;      // U / 4
+    int trim;     // the walk's first and last steps are the exact triangles fir_win_step can leave out
 };
 
 bool win_fused_supported(int N, int T, int K, int Lw, int delay, WinGeom* g);

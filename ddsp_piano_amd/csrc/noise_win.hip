@@ -44,7 +44,16 @@ __device__ __forceinline__ int win_mswz(int s) { return ((s >> 1) & 3) << 3; }
 //   gl: the lane's tap pointer for (g = 0, q = 0): image of its own frame + padl + OPL ph + delay - 3
 //   xl: the lane's noise pointer for (g = 0, r = 0)
 //   q_hi, q_lo: first (highest) block index of phase B, last (lowest) of phase A, relative to the lane's frame.
-template <int OPL, int AQ, int RS>
+// HEAD / TAIL (round 4): position of the step in the walk when it is one of the first OPL / 4 + 1 or last OPL / 4 steps
+// of a trimmed walk (WinGeom::trim), else -1.  Both half-waves walk the union of their block ranges, so at the top of
+// the walk only phase B meets taps at all, at the bottom only phase A, and in those steps most (tap, sample) pairs lie
+// outside [0, Lw) for BOTH halves: with m = e - d,
+//   step i from the top      : tap_B = OPL - 1 - ... >= 0   <=>  m >= OPL - 1 - 4 i        (tap_A = tap_B - OPL < 0 there)
+//   step j from the bottom   : tap_A <= Lw - 1              <=>  m <= 4 j                  (tap_B = tap_A + OPL > Lw - 1)
+// (for the shapes win_geometry marks: (delay + OPL - 1) % 4 == 0 and Lw + 2 + OPL == 4 nsteps -- every shipped one).  The
+// pairs outside only ever multiply zeros of the gaps between the frame images: leaving them out changes no result
+// and saves 168 of the 2 592 multiply-adds of a walk at the headline shape.
+template <int OPL, int AQ, int RS, int HEAD = -1, int TAIL = -1>
 __device__ __forceinline__ void fir_win_step(const float4 (&ring)[RS], const float4& xq, int u, float (&acc)[OPL]) {
     float tp[4 * AQ];
 #pragma unroll
@@ -53,15 +62,47 @@ __device__ __forceinline__ void fir_win_step(const float4 (&ring)[RS], const flo
         tp[4 * k] = t.x; tp[4 * k + 1] = t.y; tp[4 * k + 2] = t.z; tp[4 * k + 3] = t.w;
     }
     const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
+    constexpr int M_LO = HEAD >= 0 ? OPL - 1 - 4 * HEAD : -4, M_HI = TAIL >= 0 ? 4 * TAIL : OPL;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int e = 0; e < OPL; ++e) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+        for (int e = 0; e < OPL; ++e)
+            if (e - d >= M_LO && e - d <= M_HI) acc[e] = __builtin_fmaf(xs[d], tp[e - d + 3], acc[e]);
+}
+
+template <int OPL, int AQ, int RS, bool IS_HEAD, int POS = 0>
+__device__ __forceinline__ void fir_win_step_at(const float4 (&ring)[RS], const float4& xq, int u, int pos, float (&acc)[OPL]) {
+    if constexpr (POS <= OPL / 4) {
+        if (pos == POS) {
+            if (IS_HEAD) fir_win_step<OPL, AQ, RS, POS, -1>(ring, xq, u, acc);
+            else fir_win_step<OPL, AQ, RS, -1, POS>(ring, xq, u, acc);
+        } else {
+            fir_win_step_at<OPL, AQ, RS, IS_HEAD, POS + 1>(ring, xq, u, pos, acc);
+        }
+    }
+}
+
+// One whole turn of the ring: RS steps, the tap block and the noise block of step u + 2 issued BEFORE step u's FMAs.
+// KIND 0: plain; 1: the walk's first turn (steps 0 .. OPL / 4 trimmed from the top); 2: its last (the last OPL / 4 steps).
+template <int OPL, int AQ, int RS, int KIND>
+__device__ __forceinline__ void fir_win_turn(float4 (&ring)[RS], float4 (&xr)[RS], const float* gp, const float* xb,
+                                             float (&acc)[OPL]) {
+    constexpr int HN = OPL / 4 + 1, TN = OPL / 4;
+#pragma unroll
+    for (int u = 0; u < RS; ++u) {
+        ring[(u + AQ + 1) % RS] = lds4(gp + 4 * (u + AQ + 1));
+        xr[(u + 2) % RS] = lds4(xb + 4 * (RS - u - 2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND == 1 && u < HN) fir_win_step_at<OPL, AQ, RS, true>(ring, xr[u % RS], u, u, acc);
+        else if (KIND == 2 && u >= RS - TN) fir_win_step_at<OPL, AQ, RS, false>(ring, xr[u % RS], u, RS - 1 - u, acc);
+        else fir_win_step<OPL, AQ, RS>(ring, xr[u % RS], u, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int OPL, int BPF>
 __device__ __forceinline__ void fir_win_core(const float* __restrict__ gl, const float* __restrict__ xl, int q_hi,
-                                             int q_lo, int gs, float (&acc)[OPL]) {
+                                             int q_lo, int gs, float (&acc)[OPL], bool trim = false) {
     constexpr int AQ = (OPL + 6) / 4;        // 16-byte blocks holding the OPL + 3 taps of a step
     constexpr int RS = AQ + 2;               // register ring: the step's window + the blocks of the next two steps
     const int g_hi = q_hi >= 0 ? q_hi / BPF : -((-q_hi + BPF - 1) / BPF);
@@ -76,19 +117,27 @@ __device__ __forceinline__ void fir_win_core(const float* __restrict__ gl, const
         for (int k = 0; k <= AQ; ++k) ring[k] = lds4(gp + 4 * k);
         xr[0] = lds4(xb + 4 * RS);
         xr[1] = lds4(xb + 4 * (RS - 1));
+        // the walk's first steps open its first segment, its last steps close its last one; they are trimmed where they
+        // fall into whole turns (first segment of at least a turn; last segment a whole number of turns) -- true for every
+        // wavefront at the 24 kHz and 48 kHz shapes, for some at the others: an untrimmed step is merely not shortened
+        const bool head = trim && g == g_hi && g != g_lo && len >= RS;
+        const bool tail = trim && g == g_lo && g != g_hi && len % RS == 0;
         int i0 = 0;
-        for (; i0 + RS <= len; i0 += RS) {                               // whole turns of the ring: no exits inside
-#pragma unroll
-            for (int u = 0; u < RS; ++u) {
-                // the tap block and the noise block of step u + 2 are issued BEFORE this step's FMAs
-                ring[(u + AQ + 1) % RS] = lds4(gp + 4 * (u + AQ + 1));
-                xr[(u + 2) % RS] = lds4(xb + 4 * (RS - u - 2));
-                __builtin_amdgcn_sched_barrier(0);
-                fir_win_step<OPL, AQ, RS>(ring, xr[u % RS], u, acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        const int len_t = tail ? len - RS : len;
+        if (head) {
+            fir_win_turn<OPL, AQ, RS, 1>(ring, xr, gp, xb, acc);
+            asm volatile("; walk: first turn");
+            gp += 4 * RS; xb -= 4 * RS; i0 = RS;
+        }
+        for (; i0 + RS <= len_t; i0 += RS) {                             // whole turns of the ring: no exits inside
+            fir_win_turn<OPL, AQ, RS, 0>(ring, xr, gp, xb, acc);
             gp += 4 * RS;
             xb -= 4 * RS;
+        }
+        if (tail) {                                                      // (then the segment has no rest)
+            fir_win_turn<OPL, AQ, RS, 2>(ring, xr, gp, xb, acc);
+            asm volatile("; walk: last turn");
+            i0 += RS;
         }
 #pragma unroll
         for (int u = 0; u < RS - 1; ++u) {                               // the rest of the segment
@@ -333,8 +382,9 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                 const float *gl, *xl;
                 win_lane<OPL, BPF>(g, G, Xs, fr, min(ph, NP - 1), gl, xl);
                 const int qA = g.q_hi0 + (OPL / 4) * (8 * p + 2 * wibs);     // phase A's first block
-                const int trim = (dbg & 8) ? OPL / 4 : 0;        // timing only (wrong audio): what would 11 % fewer steps buy?
-                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4 - trim, qA - g.nsteps + 1 + trim, g.gs, acc);
+                const int cut = (dbg & 8) ? OPL / 4 : 0;         // timing only (wrong audio): what would 11 % fewer steps buy?
+                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4 - cut, qA - g.nsteps + 1 + cut, g.gs, acc,
+                                       g.trim != 0 && !(dbg & 16));
             }
             // out_last: the segment's last voice leaves on its own and stays out of the sum -- the outputs dictionary
             // of the reference's DAG holds that voice's noise next to the mix
@@ -433,7 +483,7 @@ __global__ void __launch_bounds__(256) tv_fir_win_kernel(const float* __restrict
                 const float *gl, *xl;
                 win_lane<OPL, BPF>(g, G, Xs, fr, min(ph, NP - 1), gl, xl);
                 const int qA = g.q_hi0 + (OPL / 4) * (8 * p + 2 * wibs);     // phase A's first block
-                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4, qA - g.nsteps + 1, g.gs, acc);
+                fir_win_core<OPL, BPF>(gl, xl, qA + OPL / 4, qA - g.nsteps + 1, g.gs, acc, g.trim != 0);
                 if (fr_ok && ph < NP && F0 + fr < T) {
                     float4* o = reinterpret_cast<float4*>(out + (size_t)row * N + (size_t)U * (F0 + fr) + OPL * ph);
 #pragma unroll
@@ -483,6 +533,9 @@ bool win_geometry(int N, int T, int Lw, int delay, WinGeom* g) {
     g->U = U; g->delay = delay; g->padl = padl; g->gs = gs; g->nsteps = q_hi0 - q_lo0 + 1; g->q_hi0 = q_hi0;
     g->gshift = padl & ~3;
     g->RL = RL; g->RH = RH; g->W = W; g->wpr = (T + W - 1) / W; g->opl = OPL; g->bpf = bpf;
+    // phase B's first tap is the first step's only one and phase A's last tap the last step's only one: the walk's ends
+    // are the two triangles fir_win_step's HEAD / TAIL leave out
+    g->trim = (delay + OPL - 1) % 4 == 0 && Lw + 2 + OPL == 4 * g->nsteps;
     return true;
 }
 
@@ -520,7 +573,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     int tpw = ddspp_option("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
     if (tpw < 1) tpw = 1;
     while (tpw > 1 && tasks / tpw < 768) tpw >>= 1;          // few tasks (a single segment): one unit per workgroup
-    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk
+    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk, 16 = untrimmed walk
     const dim3 grid((unsigned)((tasks + tpw - 1) / tpw)), block(256);
 #define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \
     hipLaunchKernelGGL((noise_win_fused_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, CE, \

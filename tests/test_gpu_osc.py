@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import O, rms, rms_err, synth_controls
+from util import O, rms, rms_err, set_option, synth_controls
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -226,6 +226,51 @@ def test_inharmonic_get_controls_shapes_counts_and_last_voice(H, T, B, S):
                     assert torch.equal(grp['_audible'], got['_audible'])
                     rows = np.arange(B).reshape(P, B // P)[-1] if vm else np.arange(B).reshape(B // P, P)[:, -1]
                     assert np.array_equal(grp['_shifts_last'].cpu().numpy(), ref['harmonic_shifts'][rows]), (P, vm)
+
+
+@pytest.mark.parametrize('H,scale', [(128, 'exp_sigmoid'), (96, 'exp_tanh'), (64, None), (128, 'exp_tanh')])
+def test_lean_get_controls_kernel_equals_the_generic_one_bitwise(H, scale, monkeypatch):
+    """The default flags at 64 / 96 / 128 harmonics run inharmonic_controls_lean_kernel (controls.hip): the cut above
+    Nyquist decided from the hardware square root, the correctly rounded one only for a wavefront with a partial within
+    1e-6 of Nyquist.  Every output equals the all-purpose kernel's (DDSPP_CONTROLS_GENERIC=1) bit for bit -- also when
+    partials are parked ON Nyquist (f0 = Nyquist / k exactly, with and without inharmonicity), in silent frames
+    (f0 = 0) and in the half-empty last wavefront -- and the cut is the oracle's cut."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(H)
+    B, T, S, sr = 6, 37, 1, 24000
+    raw = synth_controls(rng, B, T, H, S=S, midi_lo=21, midi_hi=108)
+    nyq = np.float32(sr / 2)
+    f0 = raw['f0_hz']
+    for i, k in enumerate((1, 2, 3, 7, 16, 17, 33, 64, H - 1, H)):
+        f0[1, i, 0] = nyq / np.float32(k)                 # partial k lands on (or an ulp off) Nyquist
+        f0[2, i, 0] = nyq / np.float32(k)
+        raw['inharm_coef'][2, i] = 0.0                     # ... exactly on it
+        f0[3, i, 0] = np.nextafter(nyq / np.float32(k), np.float32(0))
+        raw['inharm_coef'][3, i] = 0.0
+    f0[4, :5, 0] = 0.0
+    if scale is None:
+        raw['amplitudes'] = np.abs(raw['amplitudes'])
+        raw['harmonic_distribution'] = np.abs(raw['harmonic_distribution'])
+    ofn = {'exp_sigmoid': O.exp_sigmoid, 'exp_tanh': O.exp_tanh, None: None}[scale]
+    gfn = {'exp_sigmoid': dp.exp_sigmoid, 'exp_tanh': dp.exp_tanh, None: None}[scale]
+    dev = {k: _dev(v) for k, v in raw.items()}
+    order = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    syn = dp.MultiInharmonic(scale_fn=gfn, sample_rate=sr)
+    runs = {}
+    for generic in (1, 0):
+        set_option(monkeypatch, 'DDSPP_CONTROLS_GENERIC', generic)
+        full = syn._controls(*[dev[k] for k in order], want_counts=True)
+        grp = syn._controls(*[dev[k] for k in order], want_counts=True, want_shifts=False, last_voice_of=(3, False))
+        runs[generic] = {**{k: v.clone() for k, v in full.items() if torch.is_tensor(v)},
+                         '_shifts_last': grp['_shifts_last'].clone(), 'hd_grp': grp['harmonic_distribution'].clone()}
+    assert set(runs[0]) == set(runs[1])
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    ref = O.MultiInharmonic(scale_fn=ofn, sample_rate=sr).get_controls(**raw)
+    hd = runs[0]['harmonic_distribution'].cpu().numpy()
+    assert ((ref['harmonic_distribution'] == 0) == (hd == 0)).all()
+    assert np.array_equal(runs[0]['harmonic_shifts'].cpu().numpy(), ref['harmonic_shifts'])
+    np.testing.assert_allclose(hd, ref['harmonic_distribution'], rtol=2e-5, atol=1e-9)
 
 
 def test_custom_python_scale_fn():
