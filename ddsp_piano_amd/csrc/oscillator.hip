@@ -337,7 +337,9 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         } else {
             float* cb = comb + comb_buf * (p.groups * 32);
             if (lane < 32) cb[grp * 32 + lane] = s;
+#if !(defined(DDSPP_OSC_ABLATE) && (DDSPP_OSC_ABLATE & 2))   // timing only: the wavefronts of a row never meet
             __syncthreads();
+#endif
             if (grp == 0 && lane < count) {
                 float tot = cb[lane];
                 for (int g = 1; g < p.groups; ++g) tot += cb[g * 32 + lane];
@@ -380,6 +382,17 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     auto do_block = [&](int n0, const float (*fb)[VPL], const float (*ab)[VPL]) {
         using T_ = std::true_type;
         using F_ = std::false_type;
+#if defined(DDSPP_OSC_ABLATE) && (DDSPP_OSC_ABLATE & 1)      // timing only: the loads and nothing else
+        if (!FUSED) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) s += fb[i][j] + ab[i][j];
+            if (s == 1.2345e30f) p.out[0] = s;
+            return;
+        }
+#endif
         if (!FUSED) classify_block(fb, ab);
         bool fast = vals_ok;
         if (MODE != MODE_PLAIN) {
