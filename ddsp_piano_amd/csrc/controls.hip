@@ -375,8 +375,10 @@ __global__ void __launch_bounds__(256) inharmonic_controls_lean_kernel(const Inh
         const float f0 = raw_f0[u];
         const float inharm = fmaxf(raw_in[u], 0.0f);                    // :183
         float amp = scale_of<KIND>(p.scale, raw_amp[u]);                // :185
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f, h5 = 0.f, h6 = 0.f, h7 = 0.f;
-        float* const hd[8] = {&h0, &h1, &h2, &h3, &h4, &h5, &h6, &h7};
+        // (twelve scalars behind constant pointers, not `float hd[NJ]`: as an array the values live in a register tuple
+        // that the compiler shuffles with v_mov_b64 around every wave-uniform branch -- 69 moves at NJ = 8, 307 at 12)
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f, h5 = 0.f, h6 = 0.f, h7 = 0.f, h8 = 0.f, h9 = 0.f, h10 = 0.f, h11 = 0.f;
+        float* const hd[12] = {&h0, &h1, &h2, &h3, &h4, &h5, &h6, &h7, &h8, &h9, &h10, &h11};
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -603,9 +605,13 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     p.scale = ScaleFn{scale_kind, logf(exponent), max_value, threshold, gain};
     const size_t frames = (size_t)R * T;
     const int nj = (H + 15) / 16;
-    const size_t per_wg = (size_t)4 * 4 * (nj <= 8 ? 2 : 1);            // four wavefronts of 4 * CTL_PASS frames
+    const bool two_pass = nj <= 8 || (nj == 12 && normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 &&
+                                      !ddspp_option("DDSPP_CONTROLS_GENERIC", 0));          // (the lean kernel: always two)
+    const size_t per_wg = (size_t)4 * 4 * (two_pass ? 2 : 1);           // four wavefronts of 4 * CTL_PASS frames
     const dim3 grid((unsigned)((frames + per_wg - 1) / per_wg)), block(256);
-    const bool lean = normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 && nj <= 8 && (nj == 4 || nj == 6 || nj == 8);
+    // every shipped model: 48 / 64 / 96 / 128 / 192 harmonics (8, 16, 16 / 24, 24 / 48, 32 kHz) with the default flags
+    const bool lean = normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 &&
+                      (nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12) && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0);
 #define DDSPP_LEAN(NJ)                                                                                              \
     do {                                                                                                            \
         if (scale_kind == SCALE_EXP_SIGMOID)                                                                        \
@@ -615,9 +621,11 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
         else                                                                                                        \
             hipLaunchKernelGGL((inharmonic_controls_lean_kernel<NJ, SCALE_NONE>), grid, block, 0, stream, p);        \
     } while (0)
-    if (lean && nj == 8 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(8);
-    else if (lean && nj == 6 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(6);
-    else if (lean && nj == 4 && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0)) DDSPP_LEAN(4);
+    if (lean && nj == 8) DDSPP_LEAN(8);
+    else if (lean && nj == 6) DDSPP_LEAN(6);
+    else if (lean && nj == 4) DDSPP_LEAN(4);
+    else if (lean && nj == 3) DDSPP_LEAN(3);
+    else if (lean && nj == 12) DDSPP_LEAN(12);
     else if (nj <= 4) hipLaunchKernelGGL((inharmonic_controls_kernel<4, 2>), grid, block, 0, stream, p);
     else if (nj <= 6) hipLaunchKernelGGL((inharmonic_controls_kernel<6, 2>), grid, block, 0, stream, p);
     else if (nj <= 8) hipLaunchKernelGGL((inharmonic_controls_kernel<8, 2>), grid, block, 0, stream, p);

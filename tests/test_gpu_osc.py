@@ -228,9 +228,9 @@ def test_inharmonic_get_controls_shapes_counts_and_last_voice(H, T, B, S):
                     assert np.array_equal(grp['_shifts_last'].cpu().numpy(), ref['harmonic_shifts'][rows]), (P, vm)
 
 
-@pytest.mark.parametrize('H,scale', [(128, 'exp_sigmoid'), (96, 'exp_tanh'), (64, None), (128, 'exp_tanh')])
+@pytest.mark.parametrize('H,scale', [(128, 'exp_sigmoid'), (96, 'exp_tanh'), (64, None), (128, 'exp_tanh'), (48, 'exp_sigmoid'), (192, 'exp_sigmoid')])
 def test_lean_get_controls_kernel_equals_the_generic_one_bitwise(H, scale, monkeypatch):
-    """The default flags at 64 / 96 / 128 harmonics run inharmonic_controls_lean_kernel (controls.hip): the cut above
+    """The default flags at 48 / 64 / 96 / 128 / 192 harmonics run inharmonic_controls_lean_kernel (controls.hip): the cut above
     Nyquist decided from the hardware square root, the correctly rounded one only for a wavefront with a partial within
     1e-6 of Nyquist.  Every output equals the all-purpose kernel's (DDSPP_CONTROLS_GENERIC=1) bit for bit -- also when
     partials are parked ON Nyquist (f0 = Nyquist / k exactly, with and without inharmonicity), in silent frames
