@@ -178,6 +178,28 @@ __global__ void __launch_bounds__(PTH) part_fwd_kernel(const float* __restrict__
 // a step of the p loop loads ONE new X value and ONE H value for MAC_CH products -- every spectrum is read (8 + Pn) / 8
 // times per chunk instead of once per output block (the first version of this file read 0.65 GB here).
 constexpr int MAC_CH = 8;
+constexpr int MAC_AHEAD = 4;      // steps of the p loop whose X and H values are already requested
+// (round 4: the loop used to load H[p] and use it in the next instruction, and to take its new X value behind the products
+// -- one exposed memory latency per step of a loop whose arithmetic is eight complex multiply-adds; and every product
+// carried both the complex and the "bin 0 holds two real bins" form under EXEC masks: 248 EXEC branches in the kernel.
+// Now the values of MAC_AHEAD steps ahead are in flight, a product is four FMAs, and the packed bin is patched up by the
+// one wavefront that owns it.)
+template <bool PACKED>
+__device__ __forceinline__ void mac_step(float2 (&acc)[MAC_CH], const float2 (&win)[MAC_CH], int u, float2 h, bool packed) {
+#pragma unroll
+    for (int c = 0; c < MAC_CH; ++c) {
+        const float2 x = win[(c - u + MAC_CH) % MAC_CH];       // window slot (c - u) mod MAC_CH holds X_{ic + c - p}
+        float re = __builtin_fmaf(x.x, h.x, acc[c].x), im = __builtin_fmaf(x.x, h.y, acc[c].y);
+        const float re2 = __builtin_fmaf(-x.y, h.y, re), im2 = __builtin_fmaf(x.y, h.x, im);
+        if (PACKED && packed) {                                  // bin 0 holds (DC, Nyquist): two real products
+            im = __builtin_fmaf(x.y, h.y, acc[c].y);
+            acc[c] = make_float2(re, im);
+        } else {
+            acc[c] = make_float2(re2, im2);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) part_mac_kernel(const float2* __restrict__ X, const float2* __restrict__ H,
                                                      float2* __restrict__ Y, int nbx, int Pn, int hrow_stride_blocks, int i0,
                                                      int nbo, int jmax, int nchunks) {
@@ -190,8 +212,9 @@ __global__ void __launch_bounds__(256) part_mac_kernel(const float2* __restrict_
     const int ic = i0 + chunk * MAC_CH;                       // first output block of the chunk
     const float2* xrow = X + (size_t)row * nbx * PM + bin;
     const float2* hrow = H + (size_t)row * hrow_stride_blocks * PM + bin;
-    auto xload = [&](int jb) {                                // X_j is zero outside [0, jmax]
-        return (jb >= 0 && jb <= jmax) ? xrow[(size_t)jb * PM] : make_float2(0.0f, 0.0f);
+    auto xload = [&](int jb) {                                // X_j is zero outside [0, jmax] (jb is wave-uniform)
+        const float2 v = xrow[(size_t)min(max(jb, 0), jmax) * PM];
+        return (jb >= 0 && jb <= jmax) ? v : make_float2(0.0f, 0.0f);
     };
     float2 acc[MAC_CH], win[MAC_CH];
 #pragma unroll
@@ -199,27 +222,28 @@ __global__ void __launch_bounds__(256) part_mac_kernel(const float2* __restrict_
         acc[c] = make_float2(0.0f, 0.0f);
         win[c] = xload(ic + c);                               // p = 0: X_{ic + c}
     }
-    const bool packed = bin == 0;                             // bin 0 holds (DC, Nyquist): two real products
+    const bool packed = bin == 0;
+    const bool packed_wave = wave_uniform(tile == 0 && threadIdx.x < 64);
     const int p_end = min(Pn - 1, ic + MAC_CH - 1);           // beyond, i - p < 0 for every i of the chunk
+    // hq[k] / xq[k]: H_p and the X value that enters the window after step p, for the steps p = p_cur + k
+    float2 hq[MAC_AHEAD], xq[MAC_AHEAD];
+#pragma unroll
+    for (int k = 0; k < MAC_AHEAD; ++k) {
+        hq[k] = hrow[(size_t)min(k, p_end) * PM];
+        xq[k] = xload(ic - k - 1);
+    }
     for (int p0 = 0; p0 <= p_end; p0 += MAC_CH) {
 #pragma unroll
         for (int u = 0; u < MAC_CH; ++u) {
             const int p = p0 + u;
             if (p > p_end) break;
-            const float2 h = hrow[(size_t)p * PM];
-            // window slot (c - u) mod MAC_CH holds X_{ic + c - p}
-#pragma unroll
-            for (int c = 0; c < MAC_CH; ++c) {
-                const float2 x = win[(c - u + MAC_CH) % MAC_CH];
-                if (packed) {
-                    acc[c].x = __builtin_fmaf(x.x, h.x, acc[c].x);
-                    acc[c].y = __builtin_fmaf(x.y, h.y, acc[c].y);
-                } else {
-                    acc[c] = cadd(acc[c], cmul(x, h));
-                }
-            }
+            const float2 h = hq[u % MAC_AHEAD], xin = xq[u % MAC_AHEAD];
+            hq[u % MAC_AHEAD] = hrow[(size_t)min(p + MAC_AHEAD, p_end) * PM];
+            xq[u % MAC_AHEAD] = xload(ic - (p + MAC_AHEAD) - 1);
+            if (packed_wave) mac_step<true>(acc, win, u, h, packed);
+            else mac_step<false>(acc, win, u, h, false);
             // next p: every slot's block index drops by one; the slot that held X_{ic + MAC_CH - 1 - p} takes X_{ic - p - 1}
-            win[(MAC_CH - 1 - u + MAC_CH) % MAC_CH] = xload(ic - p - 1);
+            win[(MAC_CH - 1 - u + MAC_CH) % MAC_CH] = xin;
         }
     }
 #pragma unroll
@@ -239,9 +263,26 @@ __global__ void __launch_bounds__(PTH) part_inv_kernel(const float2* __restrict_
     Twiddles tw;
     load_twiddles(tw, W, j);
     const float2* yrow = Y + ((size_t)row * nbo + ib) * PM;
-    float2 acc[16];
+    float2 acc[16], uu[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = yrow[j + 256 * r];
+    // (round 4: the unpack factors and the dry samples are requested HERE, with the spectrum -- they used to be loaded
+    // where they are used, sixteen + sixteen loads each followed by its own wait.  A workgroup that walks several blocks
+    // with the next block's spectrum in flight was tried as well: 62 us against 39, the registers do not fit.)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uu[r] = U[j + 256 * r];
+    const float* drow = dry ? dry + (size_t)row * dry_stride : nullptr;
+    float dv[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const long long m0 = (long long)i * PM + 2 * (j + 256 * q) - start;
+        dv[2 * q] = dv[2 * q + 1] = 0.0f;
+        if (drow) {                                                                    // (uniform)
+            const float a = drow[min(max(m0, 0ll), (long long)out_len - 1)], c = drow[min(max(m0 + 1, 0ll), (long long)out_len - 1)];
+            dv[2 * q] = (m0 >= 0 && m0 < out_len) ? a : 0.0f;
+            dv[2 * q + 1] = (m0 + 1 >= 0 && m0 + 1 < out_len) ? c : 0.0f;
+        }
+    }
     // Y -> Z' = E + i O,  E = (Y[k] + conj Y[M - k]) / 2,  O = (Y[k] - conj Y[M - k]) / 2 * conj U[k]
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[pidx(j + 256 * r)] = acc[r];
@@ -259,22 +300,21 @@ __global__ void __launch_bounds__(PTH) part_inv_kernel(const float2* __restrict_
         }
         const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y + ym.y));
         const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y - ym.y));
-        const float2 o = cmul(d, cconj(U[k]));
+        const float2 o = cmul(d, cconj(uu[r]));
         v[r] = make_float2(e.x - o.y, e.y + o.x);            // e + i o
     }
     __syncthreads();
     fft4096<true>(v, buf, tw, j);
     // the last Bs of the 2 Bs outputs: complex n in [M / 2, M) -> real samples 2 (n - M / 2), + 1 of block i
     const float scale = 1.0f / (float)PM;
-    const float* drow = dry ? dry + (size_t)row * dry_stride : nullptr;
     float* orow = out + (size_t)row * out_len;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int n = PM / 2 + j + 256 * q;
         const float2 z = buf[pidx(n)];
         const long long m0 = (long long)i * PM + 2 * (n - PM / 2) - start;      // output index of the real part
-        if (m0 >= 0 && m0 < out_len) orow[m0] = z.x * scale + (drow ? drow[m0] : 0.0f);
-        if (m0 + 1 >= 0 && m0 + 1 < out_len) orow[m0 + 1] = z.y * scale + (drow ? drow[m0 + 1] : 0.0f);
+        if (m0 >= 0 && m0 < out_len) orow[m0] = z.x * scale + dv[2 * q];
+        if (m0 + 1 >= 0 && m0 + 1 < out_len) orow[m0 + 1] = z.y * scale + dv[2 * q + 1];
     }
 }
 
