@@ -19,6 +19,7 @@ struct WinGeom {
     int opl;      // outputs per lane
     int bpf;      // U / 4
     int trim;     // the walk's first and last steps are the exact triangles fir_win_step can leave out
+    int Lw;       // taps of an impulse response
 };
 
 bool win_fused_supported(int N, int T, int K, int Lw, int delay, WinGeom* g);

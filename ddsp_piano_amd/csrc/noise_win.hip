@@ -152,6 +152,133 @@ __device__ __forceinline__ void fir_win_core(const float* __restrict__ gl, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The walk on the matrix pipe (round 4).  A convolution is a sum of outer products: with A = four consecutive taps and
+// B = four consecutive input samples, v_mfma_f32_4x4x1_16b_f32 adds SIXTEEN independent 4 x 4 outer products -- one per
+// block of four lanes -- in one instruction: 256 multiply-adds, every one of them a (tap, sample) pair the filter needs.
+// The matrix pipe sustains the same multiply-add rate as the vector pipe on paper (tools/ubench/mfma_ceiling: 72-74
+// TMAC/s), but at 1050 W instead of the 1350-1400 W at which the vector walk is throttled, with a quarter of the
+// instructions, and without the vector walk's waste (two halves of a wavefront walking the union of their ranges, the
+// ragged ends of 12-output lanes).
+//   lane block b = frame fr = 16 fh + b of the window (fh = which half of its 32 frames), sub = lane & 3;
+//   accumulator c (4 registers): D_c[i][jj] = sum over input blocks q of  tap[4 t + rho + i] * x[4 q + jj],
+//   t = c + dq - q, which is a term of output n_rel = 4 c + (i + jj) of the frame (rho = delay % 4, dq = delay / 4);
+//   a wavefront owns QB consecutive c: the QB - 1 output quads c0 + 1 .. c0 + QB - 1, whose values are the (i + jj < 4)
+//   part of D_c plus the (i + jj >= 4) part of D_{c-1} (quad_perm adds, win_mfma_quad below).
+// Per input block (one step): ONE new tap block joins a ring of QB + 1 registers, one x block is loaded, and up to QB
+// instructions are issued -- those whose tap block lies in [t_min, t_max] (a bit mask: the first and the last QB - 1
+// steps of a walk are triangles, and a pair outside the range would read the neighbouring image).  As in fir_win_core
+// the walk is cut where the input block changes frame (the taps are those of the INPUT sample's frame): a fresh ring per
+// segment, every loop bound wave-uniform.
+typedef float win_f4 __attribute__((ext_vector_type(4)));
+constexpr int win_floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// The walk is SKEWED: at step sg every accumulator k meets the SAME tap block t = t_min + sg and its own input block
+// q = Q0 + k - sg (Q0 = c0 + dq - t_min), so that all QB instructions of all NT = t_max - t_min + 1 steps are pairs the
+// filter needs -- no triangles at the ends, no masks, no loop, no branch: NT steps of straight-line code.  The QB input
+// blocks of a step are consecutive; one new block per step joins a ring of QB + 1 registers.  The taps are those of the
+// INPUT block's frame: the QB blocks of a step lie in at most two frames (QB <= BPF), so a step fetches the tap block
+// from the image of one or two frames.  Everything about the schedule -- which accumulator takes which image at which
+// step, which input blocks lie outside the staged frames (they only feed pairs no output of the task uses, but an
+// instruction computes all sixteen products: they enter as zeros) -- follows from (hop, delay, taps, task) and is
+// resolved at COMPILE time (DELAY, LW, RL, RH, OH are template arguments, checked against the geometry at launch): a
+// first version that decided them at run time spent its time in scalar branches (0.79 ms), a second one in 637 selects
+// with 1 700 spilled scalar registers.
+constexpr int WIN_MW_AHEAD = 2;       // steps whose operands are already requested (one step is ~110 cycles of the matrix pipe)
+template <int QB, int BPF, int T_MIN, int NT, int Q0, int Q_MIN, int Q_MAX, int SG>
+struct WinMfmaSteps {
+    static constexpr int RSZ = QB + WIN_MW_AHEAD;
+    // the operands of step S: its new input block into the ring slot no accumulator holds then, its one or two tap blocks
+    template <int S>
+    static __device__ __forceinline__ void fetch(const float* __restrict__ gi, const float* __restrict__ xl, int gs,
+                                                 float (&xr)[RSZ], float& tlo, float& thi) {
+        if constexpr (S < NT) {
+            constexpr int qn = Q0 - S;
+            constexpr int slot = ((-S) % RSZ + RSZ) % RSZ;
+            if constexpr (S > 0) {                                        // (step 0's blocks are loaded with the ring)
+                if constexpr (qn >= Q_MIN && qn <= Q_MAX) xr[slot] = xl[4 * (qn + win_floordiv(qn, BPF))];
+                else xr[slot] = 0.0f;
+            }
+            constexpr int n_lo = win_floordiv(qn, BPF), n_hi = win_floordiv(qn + QB - 1, BPF);
+            tlo = gi[n_lo * gs + 4 * (T_MIN + S)];
+            if constexpr (n_hi != n_lo) thi = gi[n_hi * gs + 4 * (T_MIN + S)];
+            else thi = tlo;
+        }
+    }
+    // tl[j] / th[j]: the tap blocks of step SG + j
+    static __device__ __forceinline__ void run(const float* __restrict__ gi, const float* __restrict__ xl, int gs,
+                                               win_f4 (&acc)[QB], float (&xr)[RSZ], float (&tl)[WIN_MW_AHEAD], float (&th)[WIN_MW_AHEAD]) {
+        if constexpr (SG < NT) {
+            constexpr int g_lo = win_floordiv(Q0 - SG, BPF);
+            const float ta = tl[0], tb = th[0];
+#pragma unroll
+            for (int j = 0; j + 1 < WIN_MW_AHEAD; ++j) {
+                tl[j] = tl[j + 1];
+                th[j] = th[j + 1];
+            }
+            fetch<SG + WIN_MW_AHEAD>(gi, xl, gs, xr, tl[WIN_MW_AHEAD - 1], th[WIN_MW_AHEAD - 1]);
+            __builtin_amdgcn_sched_barrier(0);                // (one basic block of NT steps: keep the loads where they are)
+#pragma unroll
+            for (int k = 0; k < QB; ++k) {
+                const float a = win_floordiv(Q0 + k - SG, BPF) == g_lo ? ta : tb;
+                acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr[((k - SG) % RSZ + RSZ) % RSZ], acc[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WinMfmaSteps<QB, BPF, T_MIN, NT, Q0, Q_MIN, Q_MAX, SG + 1>::run(gi, xl, gs, acc, xr, tl, th);
+        }
+    }
+};
+
+template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH>
+__device__ __forceinline__ void fir_win_mfma(const float* __restrict__ gi,    // lane: image of its own frame + padl + rho + sub
+                                             const float* __restrict__ xl,    // lane: noise of its own frame + sub
+                                             int gs, win_f4 (&acc)[QB]) {
+    constexpr int RHO = DELAY & 3, DQ = DELAY >> 2, T_MIN = RHO == 0 ? 0 : -1, T_MAX = (LW - 1 - RHO) >> 2;
+    constexpr int NT = T_MAX - T_MIN + 1;
+    constexpr int Q_MIN = -RL * BPF, Q_MAX = (RH + 1) * BPF - 1;
+    constexpr int C0 = (QB - 1) * OH - 1, Q0 = C0 + DQ - T_MIN;
+    static_assert(QB <= BPF, "the input blocks of a step must not span three frames");
+    typedef WinMfmaSteps<QB, BPF, T_MIN, NT, Q0, Q_MIN, Q_MAX, 0> Steps;
+    // block q of frame g lies at xl + 4 ((BPF + 1) g + q - g BPF) = xl + 4 (q + g)
+    float xr[Steps::RSZ];
+#pragma unroll
+    for (int k = 0; k < QB; ++k) {
+        const int q = Q0 + k;
+        xr[k] = (q >= Q_MIN && q <= Q_MAX) ? xl[4 * (q + win_floordiv(q, BPF))] : 0.0f;
+    }
+    // (template recursion, not `#pragma unroll`: the second instance of the NT x QB body was left a loop -- and a ring
+    // indexed by a loop variable lives in scratch memory: 2.4 ms)
+    float tl[WIN_MW_AHEAD], th[WIN_MW_AHEAD];
+    Steps::template fetch<0>(gi, xl, gs, xr, tl[0], th[0]);
+    Steps::template fetch<1>(gi, xl, gs, xr, tl[1], th[1]);
+    static_assert(WIN_MW_AHEAD == 2, "the prologue fetches steps 0 and 1");
+    Steps::run(gi, xl, gs, acc, xr, tl, th);
+}
+// output quad c of a lane block from the accumulators of c and c - 1: lane sub gets n_rel = 4 c + sub
+template <int CTRL>
+__device__ __forceinline__ float win_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float win_mfma_quad(const win_f4& lower, const win_f4& own, int sub) {
+    const float w0 = own[0];
+    const float w1 = (sub + 1 >= 4) ? lower[1] : own[1];
+    const float w2 = (sub + 2 >= 4) ? lower[2] : own[2];
+    const float w3 = (sub + 3 >= 4) ? lower[3] : own[3];
+    return ((w0 + win_dpp<0x93>(w1)) + win_dpp<0x4E>(w2)) + win_dpp<0x39>(w3);     // quad rotations by 1, 2, 3 lanes
+}
+
+// the walk of one task and its QB - 1 output quads: o[c] = output 4 (c0 + c) + sub of the lane block's frame, c = 1 .. QB - 1
+template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH>
+__device__ __forceinline__ void fir_win_mfma_quads(const float* __restrict__ gi, const float* __restrict__ xl, int gs, int sub,
+                                                   float (&o)[QB]) {
+    win_f4 acc[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) acc[c] = win_f4{0.f, 0.f, 0.f, 0.f};
+    fir_win_mfma<QB, BPF, DELAY, LW, RL, RH, OH>(gi, xl, gs, acc);
+#pragma unroll
+    for (int c = 1; c < QB; ++c) o[c] = win_mfma_quad(acc[c - 1], acc[c], sub);
+}
+
 // per-lane pointers of the walk for output phase ph of window-relative frame fr
 template <int OPL, int BPF>
 __device__ __forceinline__ void win_lane(const WinGeom& g, const float* G, const float* Xs, int fr, int ph,
@@ -186,7 +313,7 @@ __device__ __forceinline__ void win_store_x(float* __restrict__ Xs, int nblk, in
 // TRACE (tools/ubench/noise_win_trace.hip only): every wavefront of the first workgroups writes the clock at its phase
 // boundaries to `trace`.
 constexpr int WIN_TRACE_WGS = 64, WIN_TRACE_UNITS = 8, WIN_TRACE_MARKS = 8;
-template <int KH, int JT, int OPL, int BPF, bool TRACE>
+template <int KH, int JT, int OPL, int BPF, bool TRACE, int QB = 0, int MW_DELAY = 0, int MW_LW = 0, int MW_RL = 0, int MW_RH = 0>
 __device__ __forceinline__ void
 noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                        const float* __restrict__ mags,       // [R, T, 2 KH]
@@ -325,6 +452,11 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     }
     __syncthreads();
     float vsum[NPASS][OPL];
+    // matrix-pipe walk (QB > 0): a wavefront's task = (half of the window's 32 frames, group of QB - 1 output quads);
+    // the accumulators run on through the voices of a sum
+    constexpr int MW_NPH = QB > 0 ? U / (4 * (QB > 0 ? QB - 1 : 1)) : 1, MW_PASS = QB > 0 ? (2 * MW_NPH + 3) / 4 : 1;
+    constexpr int QBA = QB > 0 ? QB : 1;
+    float mvs[MW_PASS][QBA];      // sums over the voices of a row's outputs (the vector walk's vsum)
     const int tstride = TRACE ? max(dbg >> 8, 1) : 1;            // TRACE: every tstride-th workgroup is recorded
     auto mark = [&](int unit, int k) {
         if (TRACE && (int)blockIdx.x % tstride == 0 && (int)blockIdx.x / tstride < WIN_TRACE_WGS &&
@@ -372,6 +504,48 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
         // ---- 2. the walk: NPASS passes of 8 phases
         const int orow = task / g.wpr;
         const bool lastv = out_last != nullptr && iv == vq - 1 && (orow % pq) == pq - 1;
+        if constexpr (QB > 0) {
+            const int sub = lane & 3, blk = lane >> 2;
+#pragma unroll
+            for (int p = 0; p < MW_PASS; ++p) {
+                const int tk = 4 * p + wibs;                             // (wave-uniform)
+                if (tk < 2 * MW_NPH) {
+                    const int fh = tk & 1, oh = tk >> 1;
+                    const int frw = 16 * fh + blk;
+                    float o[QBA];                                        // this voice's outputs 4 c + sub of the task's quads
+#pragma unroll
+                    for (int c = 1; c < QB; ++c) o[c] = 0.0f;
+                    if (!(dbg & 1)) {
+                        // (the 4 QB accumulator registers live only inside the call: held across the voices of a sum
+                        // they did not fit beside the design's fragments -- 79 spilled registers)
+                        const int frc = min(frw, g.W - 1);
+                        const float* gi = G + (frc + g.RL) * g.gs + g.padl + (MW_DELAY & 3) + sub;
+                        const float* xl = Xs + 4 * (BPF + 1) * (frc + g.RL) + sub;
+                        static_assert(QB == 0 || MW_NPH <= 2, "one instance of the walk per group of output quads");
+                        if (oh == 0) fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 0>(gi, xl, g.gs, sub, o);
+                        else fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 1>(gi, xl, g.gs, sub, o);
+                    }
+                    if (iv == 0) {
+#pragma unroll
+                        for (int c = 1; c < QB; ++c) mvs[p][c] = o[c];
+                    } else if (!lastv) {
+#pragma unroll
+                        for (int c = 1; c < QB; ++c) mvs[p][c] += o[c];
+                    }
+                    if (iv == vq - 1 && frw < g.W && F0 + frw < T) {
+                        const size_t n = (size_t)U * (F0 + frw) + 4 * (QB - 1) * oh + sub;
+                        float* dst = out + (size_t)orow * N + n;
+#pragma unroll
+                        for (int c = 1; c < QB; ++c) dst[4 * (c - 1)] = mvs[p][c];
+                        if (lastv) {
+                            float* dl = out_last + (size_t)(orow / pq) * N + n;
+#pragma unroll
+                            for (int c = 1; c < QB; ++c) dl[4 * (c - 1)] = o[c];
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int ph = 8 * p + 2 * wib + half;
@@ -409,6 +583,7 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                 }
             }
         }
+        }
         mark(unit, 3);
         if (dbg & 4) __builtin_amdgcn_s_setprio(3);
         store_m();                       // M has been free since the design
@@ -434,6 +609,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 noise_win_fused_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
     noise_win_fused_body<KH, JT, OPL, BPF, TRACE>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias,
                                                   scale, vq, n_voices, vmajor, tpw, dbg, trace);
+}
+#ifndef DDSPP_WIN_MW_WAVES
+#define DDSPP_WIN_MW_WAVES 3
+#endif
+template <int KH, int JT, int OPL, int BPF, int QB, int DELAY, int LW, int RL, int RH, bool TRACE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDSPP_WIN_MW_WAVES, DDSPP_WIN_MW_WAVES)))
+noise_win_fused_mw_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
+    noise_win_fused_body<KH, JT, OPL, BPF, TRACE, QB, DELAY, LW, RL, RH>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g,
+                                                      bias, scale, vq, n_voices, vmajor, tpw, dbg, trace);
 }
 template <int KH, int JT, int OPL, int BPF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -536,6 +720,7 @@ bool win_geometry(int N, int T, int Lw, int delay, WinGeom* g) {
     // phase B's first tap is the first step's only one and phase A's last tap the last step's only one: the walk's ends
     // are the two triangles fir_win_step's HEAD / TAIL leave out
     g->trim = (delay + OPL - 1) % 4 == 0 && Lw + 2 + OPL == 4 * g->nsteps;
+    g->Lw = Lw;
     return true;
 }
 
@@ -589,7 +774,18 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
                            voice_major, tpw, dbg);                                                                     \
     } while (0)
     const int U = g.U;
-    if (K == 96 && U == 96) DDSPP_WIN_LAUNCH(48, 3, 12, 24);
+    // the matrix-pipe walk needs the taps below index 0 that a misaligned delay makes it read to be zeros of a gap: any
+    // image but the window's first, i.e. at least one frame of look-back
+    // the matrix-pipe walk: its schedule is compiled for one (delay, taps, look-back, look-ahead); a misaligned delay makes
+    // it read taps below index 0, which are zeros of a gap in any image but the window's first (RL >= 1)
+    const bool mw = ddspp_option("DDSPP_WIN_MFMA", 0) && g.padl >= 8;      // opt-in: same time as the vector walk
+#define DDSPP_WIN_LAUNCH_MW(KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH)                                                        \
+    hipLaunchKernelGGL((noise_win_fused_mw_kernel<KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH>), grid, block, lds, stream, audio, \
+                       magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices,   \
+                       voice_major, tpw, dbg)
+    if (K == 96 && U == 96 && mw && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
+        DDSPP_WIN_LAUNCH_MW(48, 3, 12, 24, 13, 93, 190, 1, 1);
+    else if (K == 96 && U == 96) DDSPP_WIN_LAUNCH(48, 3, 12, 24);
     else if (K == 64 && U == 64) DDSPP_WIN_LAUNCH(32, 2, 8, 16);
     else if (K == 64 && U == 96) DDSPP_WIN_LAUNCH(32, 2, 12, 24);
     else if (K == 32 && U == 128) DDSPP_WIN_LAUNCH(16, 1, 16, 32);
@@ -599,6 +795,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     else DDSPP_REQUIRE(false, "frequency_filter_eo: no windowed kernel for K=%d U=%d", K, U);
 #undef DDSPP_WIN_LAUNCH
 #undef DDSPP_WIN_LAUNCH_W2
+#undef DDSPP_WIN_LAUNCH_MW
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

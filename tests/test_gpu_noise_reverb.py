@@ -173,6 +173,42 @@ def test_scale_fn_fused_into_the_fir_design_is_bit_identical(K, scale):
     assert dp.DynamicSizeFilteredNoise(scale_fn=lambda x: torch.sigmoid(x)).raw_scale() is None
 
 
+@pytest.mark.parametrize('R,T,P,vq,split', [(3, 40, 1, 1, False), (16, 61, 8, 8, False), (16, 61, 8, 4, True), (32, 30, 16, 8, True),
+                                            (4, 750, 2, 2, False)])
+def test_matrix_pipe_walk_equals_the_vector_walk(R, T, P, vq, split, monkeypatch):
+    """DDSPP_WIN_MFMA=1 (noise_win.hip: the walk as sixteen 4 x 4 outer products per v_mfma_f32_4x4x1, a skewed schedule
+    resolved at compile time for the 24 kHz shape) against the default vector walk: the same (tap, sample) products added
+    up in another order -- equal to a few ulp of the running sums, rows summed over voices and the last voice apart
+    included; and against the oracle's frequency_filter."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(R * 7 + T)
+    U, K = 96, 96
+    N = T * U
+    raw = torch.as_tensor(rng.normal(0, 2, [R, T, K]).astype(np.float32), device='cuda')
+    noise = torch.as_tensor(rng.uniform(-1, 1, [R, N]).astype(np.float32), device='cuda')
+    synth = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=250 * U, initial_bias=-3.0)
+    rs = synth.raw_scale()
+    outs = {}
+    for mw in (0, 1):
+        set_option(monkeypatch, 'DDSPP_WIN_MFMA', mw)
+        if P == 1:
+            outs[mw] = (core.frequency_filter(noise, raw, window_size=synth.window_size, raw_scale=rs),)
+        else:
+            res = core.frequency_filter_voice_sums(noise, raw, synth.window_size, rs, P, vq, False, split_last=split)
+            outs[mw] = tuple(t for t in (res if isinstance(res, (tuple, list)) else (res,)) if torch.is_tensor(t))
+    set_option(monkeypatch, 'DDSPP_WIN_MFMA')
+    assert len(outs[0]) == len(outs[1])
+    for a, b in zip(outs[0], outs[1]):
+        assert a.shape == b.shape
+        assert not torch.equal(a, b) or a.abs().max().item() == 0.0          # (the switch did switch)
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    if P == 1:
+        mags = synth.get_controls(raw)['magnitudes'].cpu().numpy()
+        ref = O.frequency_filter(noise.cpu().numpy(), mags, window_size=synth.window_size)
+        assert rms_err(outs[1][0].cpu().numpy(), ref) < 1e-5
+
+
 @pytest.mark.parametrize('B,T,U,K', [(3, 40, 96, 96), (2, 25, 96, 64), (1, 300, 96, 96), (2, 30, 128, 32), (5, 11, 192, 96)])
 def test_fused_frequency_filter_equals_the_two_kernel_form(B, T, U, K, monkeypatch):
     """ddspp_frequency_filter_eo (design on the matrix cores + time-varying FIR, impulse responses kept in LDS)

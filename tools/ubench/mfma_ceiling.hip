@@ -56,6 +56,12 @@ __global__ void __launch_bounds__(256) k(float* __restrict__ out, int iters, flo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[(4 * i + e) % 12] = __builtin_fmaf(b[e], a[(e + i) & 3], v[(4 * i + e) % 12]);
                 }
+            } else if (OP == 4) {   // the walk's pattern: one A operand for a run of instructions, accumulators in VGPRs
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[(4 * r + i) % NACC]) : "v"(a[r & 3]), "v"(b[i]));
+            } else if (OP == 5) {   // the same with the accumulators in AGPRs
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc[(4 * r + i) % NACC]) : "v"(a[r & 3]), "v"(b[i]));
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -107,6 +113,8 @@ int main(int argc, char** argv) {
         run<1, 8>("mfma+lds", w, target);
         run<2, 8>("mix", w, target);
         run<3, 8>("vfma", w, target);
+        run<4, 13>("mfma vgpr", w, target);
+        run<5, 13>("mfma agpr", w, target);
     }
     return 0;
 }

@@ -58,6 +58,11 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
+        if (argc > 4 && atoi(argv[4]) == 1)         // argv[4] = 1: the matrix-pipe walk
+            hipLaunchKernelGGL((noise_win_fused_mw_kernel<48, 3, 12, 24, 13, 93, 190, 1, 1, true>), grid, block, lds, 0, x, mags, CE, CO, ti,
+                               we, wo, out, vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw,
+                               (int)((grid.x / WIN_TRACE_WGS) << 8), trace);
+        else
         hipLaunchKernelGGL((noise_win_fused_kernel<48, 3, 12, 24, true>), grid, block, lds, 0, x, mags, CE, CO, ti, we, wo, out,
                            vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw, (int)((grid.x / WIN_TRACE_WGS) << 8), trace);
         hipEventRecord(e1);
