@@ -315,13 +315,6 @@ inharmonic_controls_kernel(const InharmParams p) {
 //     hardware's 1-ulp v_sqrt_f32 and redone with the correctly rounded square root (fifteen instructions) only for a
 //     wavefront that holds a partial within 1e-6 of Nyquist -- the two can differ by 2^-22 at most; the shifts that are
 //     stored come from the correctly rounded one, in a loop of their own that most wavefronts skip.
-template <int KIND>
-__device__ __forceinline__ float scale_of(const ScaleFn& s, float x) {
-    if (KIND == SCALE_EXP_SIGMOID) return s.max_value * sigmoid_pow(x, s.log_exponent) + s.threshold;
-    if (KIND == SCALE_EXP_TANH) return s.max_value * sigmoid_pow(2.0f * (s.gain * x), s.log_exponent) + s.threshold;
-    return x;
-}
-
 template <int NJ, int KIND>
 __global__ void __launch_bounds__(256) inharmonic_controls_lean_kernel(const InharmParams p) {
     constexpr int CTL_PASS = 2;
@@ -472,8 +465,11 @@ __global__ void __launch_bounds__(256) frames_moved_kernel(const float* __restri
 
 __global__ void __launch_bounds__(256) scale_bias_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        size_t n, float bias, ScaleFn s) {
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256)
-        y[g] = apply_scale(s, x[g] + bias);
+    with_scale_kind(s.kind, [&](auto kind) {
+        constexpr int KIND = decltype(kind)::value < 0 ? SCALE_NONE : decltype(kind)::value;
+        for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256)
+            y[g] = scale_of<KIND>(s, x[g] + bias);
+    });
 }
 
 // out = (((s0 + s1) + s2) + ...) elementwise: python `sum(signals.values())` of MultiAdd.

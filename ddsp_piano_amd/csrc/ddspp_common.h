@@ -97,6 +97,36 @@ __device__ __forceinline__ float sigmoid_pow(float y, float p) {
     return __builtin_amdgcn_exp2f(-p * __builtin_amdgcn_logf(1.0f + fast_exp(-y)));
 }
 
+// The same with the kind a compile-time constant, and a dispatcher that decides it ONCE around a loop: apply_scale's
+// run-time `kind` costs a maze of scalar branches per ELEMENT when the compiler cannot hoist it (round 4: eight branches
+// per magnitude in the FilteredNoise kernels' staging, 2 us per unit of 32 frames; 76 instead of 28 instructions per
+// harmonic in get_controls).
+template <int KIND>
+__device__ __forceinline__ float scale_of(const ScaleFn& s, float x) {
+    if (KIND == SCALE_EXP_SIGMOID) return s.max_value * sigmoid_pow(x, s.log_exponent) + s.threshold;
+    if (KIND == SCALE_EXP_TANH) return s.max_value * sigmoid_pow(2.0f * (s.gain * x), s.log_exponent) + s.threshold;
+    return x;
+}
+template <int KIND>
+struct ScaleKind {
+    static constexpr int value = KIND;
+};
+// f(ScaleKind<k>{}) with k = the kind, or -1 for "leave the values alone" (kind < 0)
+template <class F>
+__device__ __forceinline__ void with_scale_kind(int kind, F&& f) {
+    if (kind == SCALE_EXP_SIGMOID) f(ScaleKind<SCALE_EXP_SIGMOID>{});
+    else if (kind == SCALE_EXP_TANH) f(ScaleKind<SCALE_EXP_TANH>{});
+    else if (kind == SCALE_NONE) f(ScaleKind<SCALE_NONE>{});
+    else f(ScaleKind<-1>{});
+}
+// raw magnitudes -> scale_fn(m + bias), four at a time (kind -1: untouched)
+template <int KIND>
+__device__ __forceinline__ float4 scale4_of(const ScaleFn& s, float4 m, float bias) {
+    if (KIND < 0) return m;
+    return make_float4(scale_of<KIND>(s, m.x + bias), scale_of<KIND>(s, m.y + bias), scale_of<KIND>(s, m.z + bias),
+                       scale_of<KIND>(s, m.w + bias));
+}
+
 __device__ __forceinline__ float apply_scale(const ScaleFn& s, float x) {
     if (s.kind == SCALE_EXP_SIGMOID) {
         // max_value * sigmoid(x) ** log(exponent) + threshold          (ddsp.core.exp_sigmoid)

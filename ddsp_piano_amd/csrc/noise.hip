@@ -113,15 +113,10 @@ __global__ void __launch_bounds__(256) fir_eo_kernel(const float* __restrict__ m
             const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
             float4* dst = reinterpret_cast<float4*>(mtile);
             const int n4 = nf * (K / 4);
-            if (scale.kind < 0) {
-                for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-            } else {  // raw network outputs: FilteredNoise.get_controls' scale_fn(magnitudes + initial_bias) on the way in
-                for (int i = threadIdx.x; i < n4; i += 256) {
-                    const float4 m = src[i];
-                    dst[i] = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
-                                         apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
-                }
-            }
+            // raw network outputs: FilteredNoise.get_controls' scale_fn(magnitudes + initial_bias) on the way in
+            with_scale_kind(scale.kind, [&](auto kind) {
+                for (int i = threadIdx.x; i < n4; i += 256) dst[i] = scale4_of<decltype(kind)::value>(scale, src[i], bias);
+            });
         }
         __syncthreads();
         for (int f = wib; f < nf; f += 4) {
@@ -210,18 +205,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             constexpr int N4 = FT * PER_ROW;
             const float4* src = reinterpret_cast<const float4*>(mags + (size_t)f0 * K);
             const int lim = nf * PER_ROW - 1;
+            with_scale_kind(scale.kind, [&](auto kind) {
 #pragma unroll
-            for (int u = 0; u < (N4 + 63) / 64; ++u) {
-                const int i = lane + 64 * u;
-                if (i < N4) {
-                    float4 m = src[min(i, lim)];
-                    if (scale.kind >= 0)
-                        m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
-                                        apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
-                    const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
-                    *reinterpret_cast<float4*>(reg + fr * ASTR + 4 * c4) = m;
+                for (int u = 0; u < (N4 + 63) / 64; ++u) {
+                    const int i = lane + 64 * u;
+                    if (i < N4) {
+                        const float4 m = scale4_of<decltype(kind)::value>(scale, src[min(i, lim)], bias);
+                        const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
+                        *reinterpret_cast<float4*>(reg + fr * ASTR + 4 * c4) = m;
+                    }
                 }
-            }
+            });
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -572,18 +566,17 @@ noise_fir_fused_kernel(const float* __restrict__ x,          // [R, N] noise
         }
         {
             constexpr int PER_ROW = K / 4;
+            with_scale_kind(scale.kind, [&](auto kind) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = threadIdx.x + 256 * u;
-                if (i < FUS_FRAMES * PER_ROW) {
-                    float4 m = mv[u];
-                    if (scale.kind >= 0)
-                        m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
-                                        apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
-                    const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
-                    *reinterpret_cast<float4*>(M + fr * ASTR + 4 * c4) = m;
+                for (int u = 0; u < 2; ++u) {
+                    const int i = threadIdx.x + 256 * u;
+                    if (i < FUS_FRAMES * PER_ROW) {
+                        const float4 m = scale4_of<decltype(kind)::value>(scale, mv[u], bias);
+                        const int fr = i / PER_ROW, c4 = i - fr * PER_ROW;
+                        *reinterpret_cast<float4*>(M + fr * ASTR + 4 * c4) = m;
+                    }
                 }
-            }
+            });
         }
         __syncthreads();
         if (iv + 1 < vq) prefetch(task, iv + 1);                              // in flight during steps 2-4

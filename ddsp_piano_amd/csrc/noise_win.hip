@@ -185,6 +185,12 @@ constexpr int win_floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1
 // first version that decided them at run time spent its time in scalar branches (0.79 ms), a second one in 637 selects
 // with 1 700 spilled scalar registers.
 constexpr int WIN_MW_AHEAD = 2;       // steps whose operands are already requested (one step is ~110 cycles of the matrix pipe)
+// What rides in the walk's instruction stream (fir_win_mfma's last argument): nothing, or the FIR design of the NEXT unit
+// (WinDesignRide below: two 16 x 16 x 4 matrix instructions and one LDS read of magnitudes per walk step, 24 steps).
+struct WinNoRide {
+    template <int SG>
+    __device__ __forceinline__ void step() {}
+};
 template <int QB, int BPF, int T_MIN, int NT, int Q0, int Q_MIN, int Q_MAX, int SG>
 struct WinMfmaSteps {
     static constexpr int RSZ = QB + WIN_MW_AHEAD;
@@ -206,8 +212,10 @@ struct WinMfmaSteps {
         }
     }
     // tl[j] / th[j]: the tap blocks of step SG + j
+    template <class Ride>
     static __device__ __forceinline__ void run(const float* __restrict__ gi, const float* __restrict__ xl, int gs,
-                                               win_f4 (&acc)[QB], float (&xr)[RSZ], float (&tl)[WIN_MW_AHEAD], float (&th)[WIN_MW_AHEAD]) {
+                                               win_f4 (&acc)[QB], float (&xr)[RSZ], float (&tl)[WIN_MW_AHEAD], float (&th)[WIN_MW_AHEAD],
+                                               Ride& ride) {
         if constexpr (SG < NT) {
             constexpr int g_lo = win_floordiv(Q0 - SG, BPF);
             const float ta = tl[0], tb = th[0];
@@ -223,16 +231,17 @@ struct WinMfmaSteps {
                 const float a = win_floordiv(Q0 + k - SG, BPF) == g_lo ? ta : tb;
                 acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xr[((k - SG) % RSZ + RSZ) % RSZ], acc[k], 0, 0, 0);
             }
+            ride.template step<SG>();
             __builtin_amdgcn_sched_barrier(0);
-            WinMfmaSteps<QB, BPF, T_MIN, NT, Q0, Q_MIN, Q_MAX, SG + 1>::run(gi, xl, gs, acc, xr, tl, th);
+            WinMfmaSteps<QB, BPF, T_MIN, NT, Q0, Q_MIN, Q_MAX, SG + 1>::run(gi, xl, gs, acc, xr, tl, th, ride);
         }
     }
 };
 
-template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH>
+template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH, class Ride>
 __device__ __forceinline__ void fir_win_mfma(const float* __restrict__ gi,    // lane: image of its own frame + padl + rho + sub
                                              const float* __restrict__ xl,    // lane: noise of its own frame + sub
-                                             int gs, win_f4 (&acc)[QB]) {
+                                             int gs, win_f4 (&acc)[QB], Ride& ride) {
     constexpr int RHO = DELAY & 3, DQ = DELAY >> 2, T_MIN = RHO == 0 ? 0 : -1, T_MAX = (LW - 1 - RHO) >> 2;
     constexpr int NT = T_MAX - T_MIN + 1;
     constexpr int Q_MIN = -RL * BPF, Q_MAX = (RH + 1) * BPF - 1;
@@ -252,7 +261,7 @@ __device__ __forceinline__ void fir_win_mfma(const float* __restrict__ gi,    //
     Steps::template fetch<0>(gi, xl, gs, xr, tl[0], th[0]);
     Steps::template fetch<1>(gi, xl, gs, xr, tl[1], th[1]);
     static_assert(WIN_MW_AHEAD == 2, "the prologue fetches steps 0 and 1");
-    Steps::run(gi, xl, gs, acc, xr, tl, th);
+    Steps::run(gi, xl, gs, acc, xr, tl, th, ride);
 }
 // output quad c of a lane block from the accumulators of c and c - 1: lane sub gets n_rel = 4 c + sub
 template <int CTRL>
@@ -268,13 +277,13 @@ __device__ __forceinline__ float win_mfma_quad(const win_f4& lower, const win_f4
 }
 
 // the walk of one task and its QB - 1 output quads: o[c] = output 4 (c0 + c) + sub of the lane block's frame, c = 1 .. QB - 1
-template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH>
+template <int QB, int BPF, int DELAY, int LW, int RL, int RH, int OH, class Ride>
 __device__ __forceinline__ void fir_win_mfma_quads(const float* __restrict__ gi, const float* __restrict__ xl, int gs, int sub,
-                                                   float (&o)[QB]) {
+                                                   float (&o)[QB], Ride& ride) {
     win_f4 acc[QB];
 #pragma unroll
     for (int c = 0; c < QB; ++c) acc[c] = win_f4{0.f, 0.f, 0.f, 0.f};
-    fir_win_mfma<QB, BPF, DELAY, LW, RL, RH, OH>(gi, xl, gs, acc);
+    fir_win_mfma<QB, BPF, DELAY, LW, RL, RH, OH>(gi, xl, gs, acc, ride);
 #pragma unroll
     for (int c = 1; c < QB; ++c) o[c] = win_mfma_quad(acc[c - 1], acc[c], sub);
 }
@@ -423,18 +432,17 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
         }
     };
     auto store_m = [&]() {                                        // scale_fn on raw magnitudes on the way
+        with_scale_kind(scale.kind, [&](auto kind) {              // (the kind decided once, not per magnitude)
 #pragma unroll
-        for (int u = 0; u < MQ; ++u) {
-            const int i = threadIdx.x + 256 * u;
-            if (i < D * PER_ROW) {
-                float4 m = mv[u];
-                if (scale.kind >= 0)
-                    m = make_float4(apply_scale(scale, m.x + bias), apply_scale(scale, m.y + bias),
-                                    apply_scale(scale, m.z + bias), apply_scale(scale, m.w + bias));
-                const int s = i / PER_ROW, c4 = i - s * PER_ROW;
-                *reinterpret_cast<float4*>(M + s * K + ((4 * c4) ^ win_mswz(s))) = m;
+            for (int u = 0; u < MQ; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < D * PER_ROW) {
+                    const float4 m = scale4_of<decltype(kind)::value>(scale, mv[u], bias);
+                    const int s = i / PER_ROW, c4 = i - s * PER_ROW;
+                    *reinterpret_cast<float4*>(M + s * K + ((4 * c4) ^ win_mswz(s))) = m;
+                }
             }
-        }
+        });
     };
     // A workgroup walks a contiguous run of tpw tasks (tpw vq units); two barriers per unit:
     //   [M(u) in LDS]  design u (M -> G) -> BARRIER -> fetch M(u+1), walk u (G, Xs), M(u+1) to LDS -> BARRIER ->
@@ -522,8 +530,9 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                         const float* gi = G + (frc + g.RL) * g.gs + g.padl + (MW_DELAY & 3) + sub;
                         const float* xl = Xs + 4 * (BPF + 1) * (frc + g.RL) + sub;
                         static_assert(QB == 0 || MW_NPH <= 2, "one instance of the walk per group of output quads");
-                        if (oh == 0) fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 0>(gi, xl, g.gs, sub, o);
-                        else fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 1>(gi, xl, g.gs, sub, o);
+                        WinNoRide none;
+                        if (oh == 0) fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 0>(gi, xl, g.gs, sub, o, none);
+                        else fir_win_mfma_quads<QBA, BPF, MW_DELAY, MW_LW, MW_RL, MW_RH, 1>(gi, xl, g.gs, sub, o, none);
                     }
                     if (iv == 0) {
 #pragma unroll
@@ -596,6 +605,251 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The design RIDING in the matrix-pipe walk (round 4, DDSPP_WIN_MFMA=2).  With the walk on the matrix pipe the kernel
+// is no longer bound by the walk but by how little of a workgroup's design / staging overlaps another workgroup's walk
+// (DESIGN.md 5a).  Here the 48 matrix instructions that design unit u + 1 are dealt out behind the first 24 steps of
+// the walk of unit u (WinDesignRide), their accumulators stay in registers until unit u's images are dead, and the
+// magnitudes run one unit further ahead.  Per trip:
+//   images u (design registers -> G), noise u (registers -> Xs), magnitudes u + 1 (registers -> M), fetch noise u + 1 and
+//   magnitudes u + 2   -> BARRIER ->   walk u with the design of u + 1 riding, outputs   -> BARRIER
+// Two wavefronts per SIMD (the walk's 52 accumulators, the design's 16, the table fragments, two prefetches).
+// (Also built: the noise / magnitude staging riding in the walk as well, double-buffered in 78 KB of LDS.  Same results;
+// 0.575 ms against this kernel's 0.54: a wavefront's instruction stream is serial, what rides in it delays its own
+// matrix instructions, and two wavefronts per SIMD do not cover for each other.)
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+struct WinDesignRide {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    float bE[KS], bO[KS];          // table fragments of this wavefront's column block
+    f32x4 hE[2], hO[2];            // E / O of the two row tiles of the next unit
+    const float* mlane;            // M + col K + 2 kq (row tile 0)
+    int sw, K;                     // swizzle of the lane's row, floats per row
+    float2 am;                     // magnitudes of the next ride step
+    __device__ __forceinline__ void reset() {
+        hE[0] = hE[1] = hO[0] = hO[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        am = *reinterpret_cast<const float2*>(mlane + (0 ^ sw));
+    }
+    template <int SG>
+    __device__ __forceinline__ void step() {
+        if constexpr (SG < 2 * KS) {
+            constexpr int t = SG / KS, st = SG % KS;
+            const float2 a = am;
+            if constexpr (SG + 1 < 2 * KS) {
+                constexpr int tn = (SG + 1) / KS, sn = (SG + 1) % KS;
+                am = *reinterpret_cast<const float2*>(mlane + 16 * tn * K + ((8 * sn) ^ sw));
+            }
+            hE[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bE[st], hE[t], 0, 0, 0);
+            hO[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bO[st], hO[t], 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void all() {          // the design standing alone (a workgroup's first unit)
+        reset();
+        run_all<0>();
+    }
+    template <int SG>
+    __device__ __forceinline__ void run_all() {
+        if constexpr (SG < 2 * KS) {
+            step<SG>();
+            run_all<SG + 1>();
+        }
+    }
+};
+
+template <int KH, int JT, int BPF, int QB, int DELAY, int LW, int RL, int RH, bool TRACE>
+__device__ __forceinline__ void
+noise_win_ride_body(const float* __restrict__ x, const float* __restrict__ mags, const float* __restrict__ CE,
+                    const float* __restrict__ CO, const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
+                    const float* __restrict__ tap_wo, float* __restrict__ out, float* __restrict__ out_last, int R, int N, int T,
+                    int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices, int vmajor, int tpw, int dbg,
+                    long long* __restrict__ trace) {
+    constexpr int K = 2 * KH, KS = KH / 4, D = WIN_D, U = 4 * BPF;
+    constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
+    static_assert(JT == 3 && D == 32, "wavefronts 0 .. 2 design both row tiles of their column block, wavefront 3 none");
+    static_assert(U == 8 * (QB - 1), "two groups of QB - 1 output quads per frame");
+    static_assert(2 * KS <= (LW + 2) / 4, "the design's steps must fit the walk's");
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* M = lds_dyn;                                       // [D][K], 8-float groups XOR-swizzled by the row
+    float* Xs = M + D * K;                                    // padded noise of D frames
+    float* Gtop = Xs + (BPF + 1) * 4 * D;
+    float* G = Gtop - g.gshift;                               // image s, tap k: G[s gs + padl + k]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wibs = wave_uniform(wib);
+    const int col = lane & 15, kq = lane >> 4;
+    const bool designer = wibs < JT;                          // wavefront jt designs column block jt of both row tiles
+    const int jcol = 16 * min(wib, JT - 1) + col;
+    const int jc = min(jcol, NJ - 1);
+    WinDesignRide<KS> ride;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        ride.bE[st] = CE[(4 * st + kq) * NJ + jc];
+        ride.bO[st] = CO[(4 * st + kq) * NJ + jc];
+    }
+    ride.mlane = M + col * K + 2 * kq;
+    ride.sw = win_mswz(col);
+    ride.K = K;
+    for (int i = threadIdx.x; i < D * g.gs - g.gshift; i += 256) Gtop[i] = 0.0f;      // the gaps stay zero for ever
+#pragma unroll
+    for (int st = 0; st < KS; ++st) asm volatile("" ::"v"(ride.bE[st]), "v"(ride.bO[st]));
+    const int nblk = N / 4;
+    const int ntasks = (R / vq) * g.wpr;
+    const int n_seg = R / n_voices, pq = n_voices / vq;
+    const int nunits = ntasks * vq;
+    auto unit_geometry = [&](int unit, int& row, int& F0) {
+        const int task = unit / vq, iv = unit - task * vq;
+        const int orow = task / g.wpr;
+        if (vq == 1) {
+            row = orow;
+        } else {
+            const int b = orow / pq, v = (orow - b * pq) * vq + iv;
+            row = vmajor ? v * n_seg + b : b * n_voices + v;
+        }
+        F0 = (task - orow * g.wpr) * g.W;
+    };
+    float4 xv[XQ], mv[MQ];
+    int tq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int v = 3 * kq + i;                                  // 0..3 index, 4..7 even weight, 8..11 odd weight
+        const int* src = v < 4 ? tap_idx : (v < 8 ? reinterpret_cast<const int*>(tap_we) : reinterpret_cast<const int*>(tap_wo));
+        tq[i] = src[4 * jc + (v & 3)];
+    }
+    asm volatile("" ::"v"(tq[0]), "v"(tq[1]), "v"(tq[2]));
+    auto fetch_x = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+        win_fetch_x<BPF, XQ>(x + (size_t)row * N, nblk, BPF * (F0 - g.RL), xv);
+    };
+    auto store_x = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+        win_store_x<BPF, XQ>(Xs, nblk, BPF * (F0 - g.RL), xv);
+    };
+    auto fetch_m = [&](int unit) {
+        int row, F0;
+        unit_geometry(min(unit, nunits - 1), row, F0);
+#pragma unroll
+        for (int u = 0; u < MQ; ++u) {
+            const int i = min((int)threadIdx.x + 256 * u, D * PER_ROW - 1);
+            const int sr = i / PER_ROW, c4 = i - sr * PER_ROW;
+            const int f = min(max(F0 - g.RL + sr, 0), T - 1);
+            mv[u] = reinterpret_cast<const float4*>(mags + ((size_t)row * T + f) * K)[c4];
+        }
+    };
+    auto store_m = [&]() {                                        // scale_fn on raw magnitudes on the way
+        with_scale_kind(scale.kind, [&](auto kind) {
+#pragma unroll
+            for (int u = 0; u < MQ; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < D * PER_ROW) {
+                    const float4 m = scale4_of<decltype(kind)::value>(scale, mv[u], bias);
+                    const int sr = i / PER_ROW, c4 = i - sr * PER_ROW;
+                    *reinterpret_cast<float4*>(M + sr * K + ((4 * c4) ^ win_mswz(sr))) = m;
+                }
+            }
+        });
+    };
+    // tap weights -> frame images (a lane holds E, O of the frames 4 kq .. 4 kq + 3 of a tile at column 16 jt + col).
+    // An unused slot has index -1 and weights 0: it writes a zero to the gap float below tap 0 -- no branches.
+    auto write_images = [&]() {
+        if (!designer) return;
+        int v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = __shfl(tq[i % 3], col + 16 * (i / 3));
+        const int4 ti = make_int4(v[0], v[1], v[2], v[3]);
+        const float4 we = make_float4(__int_as_float(v[4]), __int_as_float(v[5]), __int_as_float(v[6]), __int_as_float(v[7]));
+        const float4 wo = make_float4(__int_as_float(v[8]), __int_as_float(v[9]), __int_as_float(v[10]), __int_as_float(v[11]));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float E = ride.hE[t][rr], O = ride.hO[t][rr];
+                float* dst = G + (16 * t + 4 * kq + rr) * g.gs + g.padl;
+                dst[ti.x] = __builtin_fmaf(wo.x, O, we.x * E);
+                dst[ti.y] = __builtin_fmaf(wo.y, O, we.y * E);
+                dst[ti.z] = __builtin_fmaf(wo.z, O, we.z * E);
+                dst[ti.w] = __builtin_fmaf(wo.w, O, we.w * E);
+            }
+        }
+    };
+    const int upw = tpw * vq;
+    const int u_begin = min((int)blockIdx.x * upw, nunits), u_end = min(u_begin + upw, nunits);
+    if (u_begin >= u_end) return;
+    fetch_x(u_begin);
+    fetch_m(u_begin);
+    store_m();                           // magnitudes of the first unit
+    fetch_m(u_begin + 1);
+    __syncthreads();
+    if (designer) ride.all();            // the first unit's design stands alone
+    __syncthreads();                     // M is free
+    float mvs[QB];                       // sums over the voices of a row
+    const int tstride = TRACE ? max(dbg >> 8, 1) : 1;
+    auto mark = [&](int unit, int k) {   // 0 trip start | 1 images | 2 noise in LDS | 3 magnitudes in LDS | 4 fetches issued | 5 past the barrier | 6 walk done
+        if (TRACE && (int)blockIdx.x % tstride == 0 && (int)blockIdx.x / tstride < WIN_TRACE_WGS &&
+            unit - u_begin < WIN_TRACE_UNITS && lane == 0)
+            trace[(((size_t)(blockIdx.x / tstride) * WIN_TRACE_UNITS + (unit - u_begin)) * 4 + wib) * WIN_TRACE_MARKS + k] =
+                wall_clock64();
+    };
+    const int sub = lane & 3, blk = lane >> 2;
+    const int fh = wibs & 1, oh = wibs >> 1;                     // the wavefront's task: half of the frames, half of the quads
+    for (int unit = u_begin; unit < u_end; ++unit) {
+        const int task = unit / vq, iv = unit - task * vq;
+        int row, F0;
+        unit_geometry(unit, row, F0);
+        mark(unit, 0);
+        write_images();
+        mark(unit, 1);
+        store_x(unit);
+        mark(unit, 2);
+        store_m();                       // magnitudes of unit + 1 (the ride reads them)
+        mark(unit, 3);
+        fetch_x(unit + 1);               // in flight during the walk
+        fetch_m(unit + 2);
+        mark(unit, 4);
+        __syncthreads();
+        mark(unit, 5);
+        const int orow = task / g.wpr;
+        const bool lastv = out_last != nullptr && iv == vq - 1 && (orow % pq) == pq - 1;
+        const int frw = 16 * fh + blk;
+        float o[QB];
+#pragma unroll
+        for (int c = 1; c < QB; ++c) o[c] = 0.0f;
+        {
+            const int frc = min(frw, g.W - 1);
+            const float* gi = G + (frc + g.RL) * g.gs + g.padl + (DELAY & 3) + sub;
+            const float* xl = Xs + 4 * (BPF + 1) * (frc + g.RL) + sub;
+            if (designer) {
+                ride.reset();
+                if (oh == 0) fir_win_mfma_quads<QB, BPF, DELAY, LW, RL, RH, 0>(gi, xl, g.gs, sub, o, ride);
+                else fir_win_mfma_quads<QB, BPF, DELAY, LW, RL, RH, 1>(gi, xl, g.gs, sub, o, ride);
+            } else {
+                WinNoRide none;
+                fir_win_mfma_quads<QB, BPF, DELAY, LW, RL, RH, 1>(gi, xl, g.gs, sub, o, none);     // (wavefront 3: oh = 1)
+            }
+        }
+        if (iv == 0) {
+#pragma unroll
+            for (int c = 1; c < QB; ++c) mvs[c] = o[c];
+        } else if (!lastv) {
+#pragma unroll
+            for (int c = 1; c < QB; ++c) mvs[c] += o[c];
+        }
+        if (iv == vq - 1 && frw < g.W && F0 + frw < T) {
+            const size_t n = (size_t)U * (F0 + frw) + 4 * (QB - 1) * oh + sub;
+            float* dst = out + (size_t)orow * N + n;
+#pragma unroll
+            for (int c = 1; c < QB; ++c) dst[4 * (c - 1)] = mvs[c];
+            if (lastv) {
+                float* dl = out_last + (size_t)(orow / pq) * N + n;
+#pragma unroll
+                for (int c = 1; c < QB; ++c) dl[4 * (c - 1)] = o[c];
+            }
+        }
+        mark(unit, 6);
+        __syncthreads();                 // G, Xs and M are free
+    }
+}
+
 // Three workgroups per CU (168 registers) for the shapes whose LDS allows it; K = 128 (70 KB of LDS: two workgroups per CU)
 // gets the registers of two wavefronts per SIMD instead.
 #define DDSPP_WIN_KERNEL_ARGS                                                                                          \
@@ -618,6 +872,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDSPP_
 noise_win_fused_mw_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
     noise_win_fused_body<KH, JT, OPL, BPF, TRACE, QB, DELAY, LW, RL, RH>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g,
                                                       bias, scale, vq, n_voices, vmajor, tpw, dbg, trace);
+}
+template <int KH, int JT, int BPF, int QB, int DELAY, int LW, int RL, int RH, bool TRACE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+noise_win_fused_ride_kernel(DDSPP_WIN_KERNEL_ARGS = nullptr) {
+    noise_win_ride_body<KH, JT, BPF, QB, DELAY, LW, RL, RH, TRACE>(x, mags, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T,
+                                                                    NJ, g, bias, scale, vq, n_voices, vmajor, tpw, dbg, trace);
 }
 template <int KH, int JT, int OPL, int BPF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -783,7 +1043,11 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     hipLaunchKernelGGL((noise_win_fused_mw_kernel<KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH>), grid, block, lds, stream, audio, \
                        magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices,   \
                        voice_major, tpw, dbg)
-    if (K == 96 && U == 96 && mw && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
+    if (K == 96 && U == 96 && mw && ddspp_option("DDSPP_WIN_MFMA", 0) == 2 && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
+        hipLaunchKernelGGL((noise_win_fused_ride_kernel<48, 3, 24, 13, 93, 190, 1, 1>), grid, block, lds, stream, audio, magnitudes,
+                           CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw,
+                           dbg);
+    else if (K == 96 && U == 96 && mw && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
         DDSPP_WIN_LAUNCH_MW(48, 3, 12, 24, 13, 93, 190, 1, 1);
     else if (K == 96 && U == 96) DDSPP_WIN_LAUNCH(48, 3, 12, 24);
     else if (K == 64 && U == 64) DDSPP_WIN_LAUNCH(32, 2, 8, 16);

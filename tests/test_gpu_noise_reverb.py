@@ -190,7 +190,7 @@ def test_matrix_pipe_walk_equals_the_vector_walk(R, T, P, vq, split, monkeypatch
     synth = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=250 * U, initial_bias=-3.0)
     rs = synth.raw_scale()
     outs = {}
-    for mw in (0, 1):
+    for mw in (0, 1, 2):
         set_option(monkeypatch, 'DDSPP_WIN_MFMA', mw)
         if P == 1:
             outs[mw] = (core.frequency_filter(noise, raw, window_size=synth.window_size, raw_scale=rs),)
@@ -198,11 +198,12 @@ def test_matrix_pipe_walk_equals_the_vector_walk(R, T, P, vq, split, monkeypatch
             res = core.frequency_filter_voice_sums(noise, raw, synth.window_size, rs, P, vq, False, split_last=split)
             outs[mw] = tuple(t for t in (res if isinstance(res, (tuple, list)) else (res,)) if torch.is_tensor(t))
     set_option(monkeypatch, 'DDSPP_WIN_MFMA')
-    assert len(outs[0]) == len(outs[1])
-    for a, b in zip(outs[0], outs[1]):
-        assert a.shape == b.shape
+    assert len(outs[0]) == len(outs[1]) == len(outs[2])
+    for a, b, c in zip(outs[0], outs[1], outs[2]):
+        assert a.shape == b.shape == c.shape
         assert not torch.equal(a, b) or a.abs().max().item() == 0.0          # (the switch did switch)
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+        assert torch.equal(b, c)                    # 2: the same walk with the next unit's design riding in it
     if P == 1:
         mags = synth.get_controls(raw)['magnitudes'].cpu().numpy()
         ref = O.frequency_filter(noise.cpu().numpy(), mags, window_size=synth.window_size)

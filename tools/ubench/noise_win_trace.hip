@@ -58,7 +58,11 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        if (argc > 4 && atoi(argv[4]) == 1)         // argv[4] = 1: the matrix-pipe walk
+        if (argc > 4 && atoi(argv[4]) == 2) {       // argv[4] = 2: the matrix-pipe walk with the next unit's design riding
+            hipLaunchKernelGGL((noise_win_fused_ride_kernel<48, 3, 24, 13, 93, 190, 1, 1, true>), grid, block, lds, 0, x, mags, CE, CO, ti,
+                               we, wo, out, vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw,
+                               (int)((grid.x / WIN_TRACE_WGS) << 8), trace);
+        } else if (argc > 4 && atoi(argv[4]) == 1)  // argv[4] = 1: the matrix-pipe walk
             hipLaunchKernelGGL((noise_win_fused_mw_kernel<48, 3, 12, 24, 13, 93, 190, 1, 1, true>), grid, block, lds, 0, x, mags, CE, CO, ti,
                                we, wo, out, vq > 1 ? out_last : nullptr, R, N, T, NJ, g, -5.0f, sf, vq, n_voices, 0, tpw,
                                (int)((grid.x / WIN_TRACE_WGS) << 8), trace);
@@ -73,7 +77,10 @@ int main(int argc, char** argv) {
     }
     std::vector<long long> h(trace_n);
     hipMemcpy(h.data(), trace, trace_n * 8, hipMemcpyDeviceToHost);
-    const char* names[7] = {"design", "barrierB", "walk", "store_m", "barrierC", "store_x", "(next)"};
+    const char* names_v[7] = {"design", "barrierB", "walk", "store_m", "barrierC", "store_x", "(next)"};
+    const char* names_r[7] = {"images", "store_x", "store_m", "fetches", "barrier", "walk+ride", "barrier2"};
+    const char** names = (argc > 4 && atoi(argv[4]) == 2) ? names_r : names_v;
+    // (ride kernel: images | store_x + store_m + fetches | barrier | walk + ride + outputs | - | barrier | -)
     // per-phase average over the traced workgroups / units, per wavefront index
     for (int w = 0; w < 4; ++w) {
         double acc[7] = {0};
