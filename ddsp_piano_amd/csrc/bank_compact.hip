@@ -259,42 +259,51 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #endif
     };
 
-    // Hann cross-fade weights w[r + i] and bilinear weights wlin[n0 + i] of the block: scalar loads issued one block
-    // ahead (wave-uniform addresses -> s_load_dwordx8)
-    float wl[BLK];
-#pragma unroll
-    for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n_begin + i];
-
-    // Two loops: the outer one walks frames, the inner one the blocks of a frame.  The controls of frame t + 2 are
-    // requested when frame t starts and only touched when it ends: inside the inner loop nothing depends on them, so
-    // no wait for them (and no register shuffling of loop-carried copies) sits between two blocks.
-    for (int n0 = n_begin; n0 < n_end;) {
-    const int nf_end = min(n0 + (U - r), n_end);
-    for (; n0 < nf_end; n0 += BLK) {
-        float wlnext[BLK], w1[BLK];
-        {
-            const int nn = min(n0 + BLK, N - BLK);
-#pragma unroll
-            for (int i = 0; i < BLK; ++i) wlnext[i] = wlin_c[nn + i];
-            const float4 wa = hann4(r >> 2), wb = hann4((r >> 2) + 1);
-            w1[0] = wa.x; w1[1] = wa.y; w1[2] = wa.z; w1[3] = wa.w;
-            w1[4] = wb.x; w1[5] = wb.y; w1[6] = wb.z; w1[7] = wb.w;
+    // The path a block takes -- constant frequency, moving, moving with a Nyquist mask, generic -- is a property of the
+    // FRAME pair (classify_frame), so the block loop exists once per path (round 4: as one loop with the choice inside,
+    // every block paid two or three taken scalar branches to reach its body, and the constant-frequency path paid for the
+    // moving paths' scalar weight prefetch).  `block_tail`: what follows every block whatever its path.
+    auto hann_weights = [&](float* w1) {
+        const float4 wa = hann4(r >> 2), wb = hann4((r >> 2) + 1);
+        w1[0] = wa.x; w1[1] = wa.y; w1[2] = wa.z; w1[3] = wa.w;
+        w1[4] = wb.x; w1[5] = wb.y; w1[6] = wb.z; w1[7] = wb.w;
+    };
+    auto block_tail = [&](int n0) {
+        // ---- tile bookkeeping ---------------------------------------------------------------------------------
+        tpos += BLK;
+        if (tpos == TILE || n0 + BLK >= n_end) {
+            flush_tile(tile_n0, tpos);
+            tile_n0 += tpos;
+            tpos = 0;
         }
-        if (fast && const_freq) {
-            // ---- stage 1: the float32 phase scan (VPL sequential chains, interleaved) ---------------------------
-            float pv[BLK][VPL];
+        // ---- chunk boundary (ddsp.core.angular_cumsum) ---------------------------------------------------------
+        cpos += BLK;
+        if (cpos == DDSPP_CHUNK) {
+            cpos = 0;
 #pragma unroll
-            for (int i = 0; i < BLK; ++i)
+            for (int j = 0; j < VPL; ++j) {
+                const float e = mod_2pi(ph[j]);      // phase[:, :, -1] % 2pi
+                asum[j] = asum[j] + e;               // cumsum over chunks (float32, sequential)
+                off[j] = mod_2pi(asum[j]);           // % 2pi
+                ph[j] = 0.0f;
+            }
+        }
+        r += BLK;
+    };
+    // bilinear weights wlin[n0 + i] of a block (moving paths only): scalar loads issued one block ahead (wave-uniform
+    // addresses -> s_load_dwordx8); the first block of a moving frame loads its own
+    auto moving_blocks = [&](int& n0, int nf_end, auto mask_tag) {
+        float wl[BLK];
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    ph[j] = ph[j] + om_c[j];
-                    pv[i][j] = ph[j];
-                }
-            finish_block(pv, pv, w1, std::false_type{});
-            // (a marker the paths do not share: without one the compiler sinks the common stages of the three inlined
-            // finish_block bodies into one copy behind selector flags -- a dozen scalar branches per block)
-            asm volatile("; bank block: constant frequency");
-        } else if (fast) {
+        for (int i = 0; i < BLK; ++i) wl[i] = wlin_c[n0 + i];
+        for (; n0 < nf_end; n0 += BLK) {
+            float wlnext[BLK], w1[BLK];
+            {
+                const int nn = min(n0 + BLK, N - BLK);
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) wlnext[i] = wlin_c[nn + i];
+                hann_weights(w1);
+            }
             float pv[BLK][VPL], fe[BLK][VPL], om[BLK][VPL];
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
@@ -321,14 +330,46 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                     ph[j] = ph[j] + om[i][j];
                     pv[i][j] = ph[j];
                 }
-            if (need_mask) {
-                finish_block(pv, fe, w1, std::true_type{});
-                asm volatile("; bank block: moving frequency, Nyquist mask");
-            } else {
-                finish_block(pv, fe, w1, std::false_type{});
-                asm volatile("; bank block: moving frequency");
-            }
-        } else {
+            finish_block(pv, fe, w1, mask_tag);
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) wl[i] = wlnext[i];
+            block_tail(n0);
+        }
+    };
+
+    // Two loops: the outer one walks frames, the inner one the blocks of a frame.  The controls of frame t + 2 are
+    // requested when frame t starts and only touched when it ends: inside the inner loop nothing depends on them, so
+    // no wait for them (and no register shuffling of loop-carried copies) sits between two blocks.
+    for (int n0 = n_begin; n0 < n_end;) {
+    const int nf_end = min(n0 + (U - r), n_end);
+    if (fast && const_freq) {
+        // (also tried: the four blocks of a whole tile back to back with no test between them -- 2 % slower, the code grows)
+        for (; n0 < nf_end; n0 += BLK) {
+            float w1[BLK];
+            hann_weights(w1);
+            // ---- stage 1: the float32 phase scan (VPL sequential chains, interleaved) ---------------------------
+            float pv[BLK][VPL];
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    ph[j] = ph[j] + om_c[j];
+                    pv[i][j] = ph[j];
+                }
+            finish_block(pv, pv, w1, std::false_type{});
+            // (a marker the paths do not share: without one the compiler sinks the common stages of the inlined
+            // finish_block bodies into one copy behind selector flags -- a dozen scalar branches per block)
+            asm volatile("; bank block: constant frequency");
+            block_tail(n0);
+        }
+    } else if (fast && need_mask) {
+        moving_blocks(n0, nf_end, std::true_type{});
+        asm volatile("; bank blocks: moving frequency, Nyquist mask");
+    } else if (fast) {
+        moving_blocks(n0, nf_end, std::false_type{});
+        asm volatile("; bank blocks: moving frequency");
+    } else {
+        for (; n0 < nf_end; n0 += BLK) {
             // generic path (negative / denormal / huge frequencies, unchecked sample rates): IEEE division, fmod
             // based floormod, one sample at a time -- correctness only
 #pragma unroll 1
@@ -344,29 +385,8 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 }
                 tile[(tpos + i) * TSTRIDE + lane] = acc;
             }
+            block_tail(n0);
         }
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) wl[i] = wlnext[i];
-        // ---- tile bookkeeping ---------------------------------------------------------------------------------
-        tpos += BLK;
-        if (tpos == TILE || n0 + BLK >= n_end) {
-            flush_tile(tile_n0, tpos);
-            tile_n0 += tpos;
-            tpos = 0;
-        }
-        // ---- chunk boundary (ddsp.core.angular_cumsum) ---------------------------------------------------------
-        cpos += BLK;
-        if (cpos == DDSPP_CHUNK) {
-            cpos = 0;
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const float e = mod_2pi(ph[j]);      // phase[:, :, -1] % 2pi
-                asum[j] = asum[j] + e;               // cumsum over chunks (float32, sequential)
-                off[j] = mod_2pi(asum[j]);           // % 2pi
-                ph[j] = 0.0f;
-            }
-        }
-        r += BLK;
     }
     // ---- frame boundary ----------------------------------------------------------------------------------------
     if (r == U) {
