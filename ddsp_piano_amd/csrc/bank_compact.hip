@@ -54,8 +54,10 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     // float4 w[4 q .. 4 q + 3] in row q -- so the kernel's LDS footprint (16 workgroups per CU) does not grow; hops above
     // 4 TILE = 128 (48 kHz) keep the rest behind the tile.
     auto hann4 = [&](int q) {
-        const float* src = q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE);
-        return *reinterpret_cast<const float4*>(src);
+        // (an arithmetic select: written `q < TILE ? a : b` this was two scalar BRANCHES per call, four per block)
+        const int a = q * TSTRIDE + 64, b = TILE * TSTRIDE + 4 * (q - TILE);
+        const int off = a + ((b - a) & -(int)(q >= TILE));
+        return *reinterpret_cast<const float4*>(tile + off);
     };
     int vk[VPL], vs[VPL], lrow[VPL], vidx[VPL];
     bool valid[VPL];
