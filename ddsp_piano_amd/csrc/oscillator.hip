@@ -802,25 +802,34 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
                 w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w;
                 w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
             };
-            for (int n = n_lo; n < n_hi; n += BLK) {
-                const int woff = (n - n_lo) & (PRE_W - 1);
-                if (woff == 0) {                   // (the look-ahead never crosses a refill: the step reads its own weights)
-                    stage_weights(n);
-                    weights_at(0, wl);
-                }
-                if (woff + BLK < PRE_W && n + BLK < n_hi) weights_at(woff + BLK, wn);
-                const bool nxt = r + BLK == U &&
-                                 __builtin_amdgcn_readfirstlane(__float_as_int(wl[BLK - 1])) == __float_as_int(WALK_NEXT_ROW);
-                if (fast) {
+            // Frame by frame (round 4): the weights of the frame's samples are staged once (U <= PRE_W), the exact /
+            // IEEE division is chosen once per frame pair, and only a frame's LAST block can hold "next row" samples
+            // -- the block loop itself has no test but its own (it had five scalar branches per 60-instruction block).
+            for (int n = n_lo; n < n_hi;) {
+                const int nf = min(n + min(U - r, PRE_W), n_hi);   // end of the frame's part inside the chunk (of PRE_W samples of a longer frame)
+                stage_weights(n);                                   // weights of samples n .. n + 255 (the frame's are among them)
+                weights_at(0, wl);
+                auto blocks = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    int woff = 0;
+                    for (; n + BLK < nf; n += BLK) {                // all but the frame's last block
+                        weights_at(woff + BLK, wn);
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<true>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
-                } else {
+                        for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<FAST>(ph[j], x0[j], x1[j], wl, srv, rsrv, false);
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<false>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
-                }
+                        for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
+                        woff += BLK;
+                        r += BLK;
+                    }
+                    const bool nxt = r + BLK == U &&
+                                     __builtin_amdgcn_readfirstlane(__float_as_int(wl[BLK - 1])) == __float_as_int(WALK_NEXT_ROW);
 #pragma unroll
-                for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
-                r += BLK;
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<FAST>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
+                    n += BLK;
+                    r += BLK;
+                };
+                if (fast) blocks(std::true_type{});
+                else blocks(std::false_type{});
                 if (r == U) {
                     r = 0;
                     ++tt;
