@@ -139,16 +139,19 @@ __device__ __forceinline__ void fir_win_core(const float* __restrict__ gl, const
             asm volatile("; walk: last turn");
             i0 += RS;
         }
+        // the rest of the segment: nested tests -- a segment of whole turns (every one at the 24 kHz shape) leaves at the
+        // first (they were RS - 1 separate tests, each a scalar branch: fifteen per walk for nothing)
+        [&] {
 #pragma unroll
-        for (int u = 0; u < RS - 1; ++u) {                               // the rest of the segment
-            if (i0 + u < len) {
+            for (int u = 0; u < RS - 1; ++u) {
+                if (i0 + u >= len) return;
                 ring[(u + AQ + 1) % RS] = lds4(gp + 4 * (u + AQ + 1));
                 xr[(u + 2) % RS] = lds4(xb + 4 * (RS - u - 2));
                 __builtin_amdgcn_sched_barrier(0);
                 fir_win_step<OPL, AQ, RS>(ring, xr[u % RS], u, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        }();
     }
 }
 
