@@ -8,6 +8,10 @@
 // usage: walk_step [lds_pad_bytes] [reps] [CUs to fill]
 #include "../../ddsp_piano_amd/csrc/noise_win.hip"
 
+#ifndef WPE
+#define WPE 3          // wavefronts per SIMD the walk kernel is compiled for (-DWPE=4: without the magnitude tile, four workgroups per CU)
+#endif
+
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -15,7 +19,7 @@
 using namespace ddspp;
 
 template <int OPL, int BPF, int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 walk_kernel(WinGeom g, int reps, float* __restrict__ sink, long long* __restrict__ cyc) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     constexpr int D = WIN_D;
@@ -53,7 +57,7 @@ int main(int argc, char** argv) {
     const int delay = (Lw - 1) / 2 - 1;
     WinGeom g;
     if (!win_tvfir_supported(N, T, Lw, delay, &g)) return 1;
-    const size_t lds = win_lds_bytes(g, 0) + 12288 + pad;      // + the fused kernel's magnitude tile
+    const size_t lds = win_lds_bytes(g, 0) + (WPE >= 4 ? 0 : 12288) + pad;      // + the fused kernel's magnitude tile (not with -DWPE=4)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_kernel<12, 24, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<12, 24, 0>, 256, lds);
