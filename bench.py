@@ -182,6 +182,38 @@ def build_default_model_group(dp, P, sr, frame_rate=250):
     return dp.ProcessorGroup(dag)
 
 
+def build_shipped_group(dp, cfg, P, sr, frame_rate=250):
+    """The processor group of one of the reference's shipped gin files: the flags that reach the
+    hot path, the reverb node the file names."""
+    ctl = ['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz']
+    reverb_controls = ['reverb_ir']
+    if cfg in ('ENSTDkCl-8kHz', 'ENSTDkCl-32kHz'):       # exp_tanh, no re-normalisation, an FDN that holds its parameters
+        additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True,
+                                      scale_fn=dp.exp_tanh, normalize_after_nyquist_cut=False)
+        noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr, scale_fn=dp.exp_tanh)
+        reverb = dp.FeedbackDelayNetwork(trainable=True, delay_trainable=True, delay_lines=8 if sr == 8000 else 6,
+                                         sampling_rate=sr, name='fdn', seed=11)
+        reverb_controls = []
+    elif cfg == 'multi_instruments':
+        additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True,
+                                      scale_fn=dp.exp_tanh, normalize_after_nyquist_cut=False)
+        noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr, scale_fn=dp.exp_tanh)
+        reverb = dp.Reverb(name='reverb', trainable=False, add_dry=False)
+    elif cfg == 'surrogate':
+        additive = dp.SurrogateAdditive(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True,
+                                        scale_fn=dp.exp_tanh, normalize_harm_distribution=False)
+        noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr, scale_fn=dp.exp_tanh)
+        reverb = dp.Reverb(name='reverb', trainable=False)
+        ctl = ['amplitudes', 'decays', 'decay_time', 'harmonic_distribution', 'inharm_coef', 'f0_hz']
+    else:                                                # maestro-v2, dafx22-24kHz: the defaults
+        additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True)
+        noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr)
+        reverb = dp.Reverb(name='reverb', trainable=False)
+    dag = dp.polyphonic_dag(additive, noise, reverb, additive_controls=ctl, noise_controls=['magnitudes'],
+                            reverb_controls=reverb_controls, n_synths=P)
+    return dp.ProcessorGroup(dag)
+
+
 # ----------------------------------------------------------------------------------------------------
 # timing
 # ----------------------------------------------------------------------------------------------------
@@ -756,6 +788,32 @@ def main():
                 del pgd
             del fx, pgx
             torch.cuda.empty_cache()
+        # every shipped gin file at its own dims and flags (dafx22.gin is `dafx22_dims` above)
+        shipped = {}
+        for cfg, (b_, h_, k_, s_, sr_, l_) in {
+                'maestro-v2': (B, 128, 96, 1, 24000, 48000), 'dafx22-24kHz': (B, 128, 96, 2, 24000, 36000),
+                'ENSTDkCl-8kHz': (B, 48, 32, 1, 8000, 16000), 'ENSTDkCl-32kHz': (B, 192, 128, 1, 32000, 64000),
+                'multi_instruments': (B, 96, 64, 1, 16000, 24000), 'surrogate': (B, 96, 64, 1, 16000, 16000)}.items():
+            u_ = sr_ // 250
+            fx, bx = make_features(b_, 16, T, h_, k_, s_, l_, device, seed=43)
+            if cfg == 'surrogate':          # per-partial decay rates and the frames since the note's onset
+                gq = torch.Generator(device=device)
+                gq.manual_seed(44)
+                dec = 0.9990 + 0.0012 * torch.rand(b_, 16, T, h_, generator=gq, device=device)
+                dt = torch.arange(T, device=device, dtype=torch.float32).view(1, 1, T, 1).expand(b_, 16, T, 1).contiguous()
+                for i in range(16):
+                    fx[f'decays_{i}'], fx[f'decay_time_{i}'] = dec[:, i], dt[:, i]
+            pgx = build_shipped_group(dp, cfg, 16, sr_)
+            ts = event_times(lambda: call(pgx, fx), 10, warmup=2)
+            shipped[cfg] = {'workload': f'batch={b_} x {args.seconds:g} s, poly=16, {sr_} Hz, H={h_}, K={k_}, S={s_}, '
+                                        f'IR {l_} samples' + (' (FDN node holding its parameters: their impulse response is designed at the first call and kept)'
+                                                              if cfg.startswith('ENST') else '') +
+                                        (' (SurrogateAdditive: per-voice rows through the fused decay kernel, batched '
+                                         'route since round 4)' if cfg == 'surrogate' else ''),
+                            'ms_per_step': ms_summary(ts), 'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+            del fx, bx, pgx
+            torch.cuda.empty_cache()
+        extra['shipped_configs'] = shipped
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)

@@ -14,6 +14,7 @@ the current HIP stream.
 from __future__ import annotations
 
 import atexit
+import os
 import ctypes
 import functools
 import math
@@ -774,6 +775,29 @@ def surrogate_harmonic_synthesis(frequencies, amplitudes, decays=None, decay_tim
         n_harmonics = int(tf_float32(harmonic_shifts).shape[-1])
     else:
         n_harmonics = 1
+    # fused route (round 4): straight from the frame controls, the decay term inside the oscillator kernel
+    # (ddspp_surrogate_harmonic_synthesis) -- no [B, N, H] envelope is formed
+    if (decays is not None and decay_time is not None and amp_resample_method == 'window'
+            and os.environ.get('DDSPP_SURROGATE_MATERIALISED', '0') != '1'       # A/B switch: the three-operator route
+            and frequencies.shape[-1] == 1 and amplitudes.shape[-1] == 1 and n_harmonics <= 512 and upsampling % 8 == 0
+            and fused_synthesis_supported(t, n_samples)
+            and (harmonic_shifts is None or tuple(harmonic_shifts.shape) == (b, t, n_harmonics))):
+        dev = frequencies.device
+        hd = harmonic_distribution.expand(b, t, n_harmonics).contiguous() if harmonic_distribution is not None else \
+            torch.ones((b, t, n_harmonics), dtype=torch.float32, device=dev)
+        sh = tf_float32(harmonic_shifts).contiguous() if harmonic_shifts is not None else None
+        dec = tf_float32(decays).expand(b, t, n_harmonics).contiguous()
+        dtm = tf_float32(decay_time).reshape(b, t).contiguous()
+        out = torch.empty((b, n_samples), dtype=torch.float32, device=dev)
+        wlin = walk_weights(t, n_samples, dev)
+        whann = hann_window(2 * int(upsampling), dev)
+        ws, nbytes = _osc_workspace(b, n_samples, n_harmonics, dev)
+        _lib.check(_lib_().ddspp_surrogate_harmonic_synthesis(
+            _ptr(frequencies.contiguous()), _ptr(amplitudes.reshape(b, t).contiguous()), _ptr(hd),
+            _ptr(sh) if sh is not None else ctypes.c_void_p(0), _ptr(dec), _ptr(dtm), _ptr(wlin), _ptr(whann), _ptr(out),
+            b, t, n_harmonics, int(upsampling), float(sample_rate), int(bool(use_angular_cumsum)), 0, _ptr(ws), nbytes,
+            _stream()))
+        return out
     harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)
     if harmonic_shifts is not None:
         harmonic_frequencies = harmonic_frequencies * (1.0 + tf_float32(harmonic_shifts))

@@ -48,6 +48,10 @@ struct OscParams {
     // the span-start walk normally leaves out 64-oscillator groups that are silent in every frame of the call (nothing
     // reads their start phases); need_all = 1 walks them too: a carried phase state must cover every oscillator
     int need_all;
+    // SurrogateAdditive (surrogate_synth.py:76-95): per-harmonic exponential decay of the amplitude envelopes,
+    // |decays[t, k]| ** (decay_time[t] * U + n % U) with t = n / U (the frame's values repeated, not interpolated); null = none
+    const float* __restrict__ decays;      // [R, T, H]
+    const float* __restrict__ decay_time;  // [R, T]
 };
 
 enum { MODE_MAIN = 0, MODE_PREPASS = 1, MODE_PLAIN = 2 };

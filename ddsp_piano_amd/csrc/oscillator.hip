@@ -28,8 +28,14 @@
 
 namespace ddspp {
 
-template <int VPL, bool FUSED, int MODE, bool SUM>
+// DECAY (fused source, SurrogateAdditive): the amplitude of oscillator k in frame t is multiplied by
+// |decays[t, k]| ** (decay_time[t] U + r), r = sample in the frame (surrogate_synth.py:76-95: tf.repeat of the frame's
+// values, a sample counter, tf.math.pow).  The power is evaluated by powf once per frame and lane (and where a span
+// starts inside a frame); inside the frame it advances block by block with d ** 8 and sample by sample with d: at most
+// U / 8 + 10 roundings behind the per-sample pow of the reference (2e-6 relative at hop 192), on an amplitude only.
+template <int VPL, bool FUSED, int MODE, bool SUM, bool DECAY = false>
 __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
+    static_assert(!DECAY || (FUSED && MODE != MODE_PREPASS && SUM), "the decay term belongs to the fused, summed source");
     // one workgroup = the `groups` wavefronts of one (row, span): they walk the same samples, so
     // their per-tile partial sums can be combined through LDS behind a single barrier per tile
     extern __shared__ float lds_dyn[];
@@ -113,11 +119,19 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
     float a1_raw[VPL];                 // frame t + 1's amplitude before classify_frame's whole-pair Nyquist mask: the NEXT pair starts from it
     float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
+    // DECAY: d0 / dt0 = frame t's decay factor and time, d1 / dt1 = frame t + 1's, q_d / q_dt those of the frame
+    // requested ahead; e_blk = d0 ** (dt0 U + r) at the start of the current block, d0_8 = d0 ** 8
+    float d0[DECAY ? VPL : 1], d1[DECAY ? VPL : 1], q_d[DECAY ? VPL : 1], e_blk[DECAY ? VPL : 1], d0_8[DECAY ? VPL : 1];
+    float dt0 = 0.0f, dt1 = 0.0f, q_dt = 0.0f;
     int t = 0, r = 0;
     auto frame_request = [&](int tt) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const size_t fr = (size_t)row * T + tt;
+            if constexpr (DECAY) {
+                q_d[j] = fabsf(p.decays[fr * H + vk[j]]);
+                q_dt = p.decay_time[fr];
+            }
             q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
             q_sh[j] = p.shifts ? p.shifts[fr * H + vk[j]] : (p.inh ? p.inh[fr] : 0.0f);
@@ -181,8 +195,32 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
         frame_finish(x1, a1);
 #pragma unroll
         for (int j = 0; j < VPL; ++j) a1_raw[j] = a1[j];
+        if constexpr (DECAY) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) d1[j] = q_d[j];
+            dt1 = q_dt;
+        }
         frame_request(min(t + 2, T - 1));
         classify_frame();
+    }
+    // DECAY: the power at sample r0 of the frame whose factors are in d0 / dt0
+    auto decay_start = [&](int r0) {
+        if constexpr (DECAY) {
+            const float x = dt0 * (float)U + (float)r0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                e_blk[j] = powf(d0[j], x);
+                const float d2 = d0[j] * d0[j], d4 = d2 * d2;
+                d0_8[j] = d4 * d4;
+            }
+        }
+    };
+    if constexpr (FUSED && DECAY) {
+        // frame t's own factors (the requests above were for frames t, t + 1 and t + 2)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) d0[j] = fabsf(p.decays[((size_t)row * T + t) * H + vk[j]]);
+        dt0 = p.decay_time[(size_t)row * T + t];
+        decay_start(r);
     }
 
     float* out_row = p.out + (size_t)row * N;
@@ -251,6 +289,15 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                     // a0 w[U + r] + a1 w[r] with w[U + r] + w[r] = 1 (to 1 ulp) is the cross-fade
                     // a0 + (a1 - a0) w[r]; <= 2 ulp on an amplitude, never on a phase.
                     if (MODE != MODE_PREPASS && act[j]) ae[i][j] = __builtin_fmaf(a1[j] - a0[j], w1[i], a0[j]);
+                }
+                if constexpr (DECAY) {     // amplitude_envelopes *= |decays| ** (decay_time U + r)   surrogate_synth.py:91-95
+                    float e = e_blk[j];
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i) {
+                        if (act[j]) ae[i][j] = ae[i][j] * e;
+                        e = e * d0[j];
+                    }
+                    e_blk[j] = e_blk[j] * d0_8[j];
                 }
             }
             if (!CFREQ) {
@@ -455,6 +502,16 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                 frame_finish(x1, a1);                       // raw values requested one frame ago
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) a1_raw[j] = a1[j];
+                if constexpr (DECAY) {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        d0[j] = d1[j];
+                        d1[j] = q_d[j];
+                    }
+                    dt0 = dt1;
+                    dt1 = q_dt;
+                    decay_start(0);
+                }
                 frame_request(min(t + 2, T - 1));
                 classify_frame();
             }
@@ -1348,7 +1405,7 @@ static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* 
     }
 }
 
-template <int VPL, bool FUSED>
+template <int VPL, bool FUSED, bool DECAY = false>
 static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t stream) {
     const int nblk_main = p.R * p.spans;
     const dim3 blk(64 * p.groups);
@@ -1369,13 +1426,17 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
                                stream, p);
             launch_offset_scan(p.ework, const_cast<float*>(p.astart), p.R, p.npre, p.VP, p.spans, p.cps, stream);
         }
-        if (sum)
+        if constexpr (DECAY)               // (phases do not depend on the decay term: the pre-pass is the plain one)
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true, true>), dim3(nblk_main), blk, lds, stream, p);
+        else if (sum)
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true>), dim3(nblk_main), blk, lds, stream, p);
         else
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, false>), dim3(nblk_main), blk, lds, stream,
                                p);
     } else {
-        if (sum)
+        if constexpr (DECAY)
+            hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, true, true>), dim3(nblk_main), blk, lds, stream, p);
+        else if (sum)
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_PLAIN, true>), dim3(nblk_main), blk, lds, stream,
                                p);
         else
@@ -1384,15 +1445,15 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
     }
 }
 
-template <bool FUSED>
+template <bool FUSED, bool DECAY = false>
 static int dispatch_vpl(int vpl, const OscParams& p, bool angular, bool sum, hipStream_t stream) {
     switch (vpl) {
-        case 1: launch_all<1, FUSED>(p, angular, sum, stream); break;
-        case 2: launch_all<2, FUSED>(p, angular, sum, stream); break;
-        case 3: launch_all<3, FUSED>(p, angular, sum, stream); break;
-        case 4: launch_all<4, FUSED>(p, angular, sum, stream); break;
-        case 6: launch_all<6, FUSED>(p, angular, sum, stream); break;
-        case 8: launch_all<8, FUSED>(p, angular, sum, stream); break;
+        case 1: launch_all<1, FUSED, DECAY>(p, angular, sum, stream); break;
+        case 2: launch_all<2, FUSED, DECAY>(p, angular, sum, stream); break;
+        case 3: launch_all<3, FUSED, DECAY>(p, angular, sum, stream); break;
+        case 4: launch_all<4, FUSED, DECAY>(p, angular, sum, stream); break;
+        case 6: launch_all<6, FUSED, DECAY>(p, angular, sum, stream); break;
+        case 8: launch_all<8, FUSED, DECAY>(p, angular, sum, stream); break;
         default: return DDSPP_EINVAL;
     }
     return DDSPP_OK;
@@ -1504,11 +1565,12 @@ int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amp
 // harmonic_synthesis(...) summed over the substrings of MultiInharmonic.get_signal, straight from
 // the frame-rate controls -- inharm_synth.py:87-127, :272-293.  `wlin` and `whann` come from
 // ddspp_resample_tables (resample.hip); the [R, N, H] envelopes are never materialised.
-int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
-                             const float* harmonic_distribution, const float* harmonic_shifts,
-                             const float* wlin, const float* whann, float* audio, int R, int T, int S,
-                             int H, int U, float sample_rate, int use_angular_cumsum, int spans,
-                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int harmonic_synthesis_impl(const float* f0_hz, const float* amplitudes,
+                                   const float* harmonic_distribution, const float* harmonic_shifts,
+                                   const float* decays, const float* decay_time,
+                                   const float* wlin, const float* whann, float* audio, int R, int T, int S,
+                                   int H, int U, float sample_rate, int use_angular_cumsum, int spans,
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio,
                   "harmonic_synthesis: null buffer");
     DDSPP_REQUIRE(R > 0 && T > 0 && S > 0 && H > 0 && U > 0, "harmonic_synthesis: bad dims");
@@ -1536,10 +1598,37 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
     p.spans = pl.spans; p.cps = pl.cps; p.nchunks = pl.nchunks; p.npre = pl.npre;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
-    int rc = dispatch_vpl<true>(pl.vpl, p, use_angular_cumsum != 0, true, stream);
+    p.decays = decays; p.decay_time = decay_time;
+    int rc = decays ? dispatch_vpl<true, true>(pl.vpl, p, use_angular_cumsum != 0, true, stream)
+                    : dispatch_vpl<true>(pl.vpl, p, use_angular_cumsum != 0, true, stream);
     DDSPP_REQUIRE(rc == DDSPP_OK, "harmonic_synthesis: dispatch failed");
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
+}
+
+int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
+                             const float* harmonic_distribution, const float* harmonic_shifts,
+                             const float* wlin, const float* whann, float* audio, int R, int T, int S,
+                             int H, int U, float sample_rate, int use_angular_cumsum, int spans,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return harmonic_synthesis_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, nullptr, nullptr, wlin, whann,
+                                   audio, R, T, S, H, U, sample_rate, use_angular_cumsum, spans, workspace, workspace_bytes,
+                                   stream);
+}
+
+// surrogate_harmonic_synthesis -- ddsp_piano/modules/surrogate_synth.py:11-104 (SurrogateAdditive.get_signal, :203-214):
+// harmonic_synthesis with the amplitude envelopes multiplied by |decays[t, k]| ** (decay_time[t] U + n % U), t = n / U
+// (:76-95), straight from the frame-rate controls.  Same tables, workspace and spans as ddspp_harmonic_synthesis (S = 1);
+// decays [R, T, H], decay_time [R, T].
+int ddspp_surrogate_harmonic_synthesis(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                                       const float* harmonic_shifts, const float* decays, const float* decay_time,
+                                       const float* wlin, const float* whann, float* audio, int R, int T, int H, int U,
+                                       float sample_rate, int use_angular_cumsum, int spans, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(decays && decay_time, "surrogate_harmonic_synthesis: null decay buffers");
+    return harmonic_synthesis_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, decays, decay_time, wlin, whann,
+                                   audio, R, T, 1, H, U, sample_rate, use_angular_cumsum, spans, workspace, workspace_bytes,
+                                   stream);
 }
 
 // The additive branch of the whole polyphonic group in one call: sum over the P voices of a segment

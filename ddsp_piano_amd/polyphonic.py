@@ -18,7 +18,7 @@ import torch
 from . import _lib, core
 from .core import _lib_, _ptr, _stream
 from .effects import FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb
-from .synths import FilteredNoise, InHarmonic, MultiAdd
+from .synths import FilteredNoise, InHarmonic, MultiAdd, SurrogateAdditive
 
 
 class Plan:
@@ -69,14 +69,18 @@ def _recognise_gin(dag):
         return None
     p = n // 3
     additive, noise, add = dag[0][0], dag[1][0], dag[2][0]
-    if not (isinstance(additive, InHarmonic) and isinstance(noise, FilteredNoise) and isinstance(add, MultiAdd)):
+    # (SurrogateAdditive, configs/surrogate.gin: six controls -- amplitudes, decays, decay_time, harmonic_distribution,
+    # inharm_coef, f0_hz -- and per-voice rows through the fused decay kernel; round 4)
+    if not (isinstance(additive, (InHarmonic, SurrogateAdditive)) and isinstance(noise, FilteredNoise)
+            and isinstance(add, MultiAdd)):
         return None
+    n_add = 6 if isinstance(additive, SurrogateAdditive) else 4
     additive_keys, noise_keys = [], []
     for i in range(p):
         a, z, m = dag[3 * i], dag[3 * i + 1], dag[3 * i + 2]
         if a[0] is not additive or z[0] is not noise or m[0] is not add:
             return None
-        if not _plain_keys(a[1], 4) or not _plain_keys(z[1], 1):
+        if not _plain_keys(a[1], n_add) or not _plain_keys(z[1], 1):
             return None
         expect = [noise.name + '/signal', additive.name + '/signal']
         if i > 0:
@@ -245,11 +249,20 @@ def run(plan, inputs, noise=None, need_stems=True):
     need_stems=True / 'all': every voice's stems ([B, P, N] under outputs['voices']), per-voice kernels."""
     P = plan.n_synths
     default_shape = plan.shape == 'default_model'
-    add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(4)]
+    surrogate = isinstance(plan.additive, SurrogateAdditive)
+    add_ctl = [[inputs[k[j]] for k in plan.additive_keys] for j in range(6 if surrogate else 4)]
+    if surrogate:                                    # (amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz)
+        dec_in, dtm_in = add_ctl[1], add_ctl[2]
+        add_ctl = [add_ctl[0], add_ctl[3], add_ctl[4], add_ctl[5]]
+        if any(x is None for x in dec_in + dtm_in):
+            return None
     hd, vm = _stack_voices(add_ctl[1])               # [R, T, H]; the widest control decides the row order
     amp, _ = _stack_voices(add_ctl[0], vm)           # [R, T, 1]
     inh, _ = _stack_voices(add_ctl[2], vm)           # [R, T, 1]
     f0, _ = _stack_voices(add_ctl[3], vm)            # [R, T, S]
+    if surrogate:
+        dec, _ = _stack_voices(dec_in, vm)           # [R, T, H]
+        dtm, _ = _stack_voices(dtm_in, vm)           # [R, T, 1]
     mags, _ = _stack_voices([inputs[k] for k in plan.noise_keys], vm)    # [R, T, K]
     R, T, H = hd.shape
     B = R // P
@@ -258,9 +271,11 @@ def run(plan, inputs, noise=None, need_stems=True):
     if amp.shape[-1] != 1 or inh.shape[-1] != 1 or mags.shape[1] != T:
         return None
     additive, noise_p = plan.additive, plan.noise
-    if not isinstance(additive, InHarmonic):
+    if not isinstance(additive, (InHarmonic, SurrogateAdditive)):
         return None
-    U = additive.upsampling
+    if surrogate and (S != 1 or tuple(dec.shape) != (R, T, H) or tuple(dtm.shape) != (R, T, 1) or not additive.inference):
+        return None
+    U = int(additive.sample_rate / additive.frame_rate) if surrogate else additive.upsampling
     N = U * T
     if not core.fused_synthesis_supported(T, N):
         return None
@@ -273,7 +288,7 @@ def run(plan, inputs, noise=None, need_stems=True):
 
     want_all = need_stems is True or need_stems == 'all'
     want_last = need_stems == 'last'
-    compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
+    compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0 and not surrogate
     # --- noise branch ---------------------------------------------------------------------------
     fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
@@ -326,10 +341,17 @@ def run(plan, inputs, noise=None, need_stems=True):
         nctl, noise_sig, noise_vq = noise_branch(noise)
     # --- additive branch ------------------------------------------------------------------------
     # compacted route: harmonic_shifts are never written (the bank forms them from inharm_coef per lane and frame)
-    ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
-                             last_voice_of=(P, vm) if want_last else None)
+    if surrogate:
+        # SurrogateAdditive: its get_controls over all rows at once, per-voice rows straight from the frame controls with
+        # the decay term inside the oscillator kernel (core.surrogate_harmonic_synthesis -> ddspp_surrogate_harmonic_synthesis)
+        ctl = additive.get_controls(amp, dec, dtm, hd, inh, f0)
+    else:
+        ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
+                                 last_voice_of=(P, vm) if want_last else None)
     additive_last = None
-    if compact:
+    if surrogate:
+        additive_sig = additive.get_signal(**ctl)
+    elif compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                 ctl['harmonic_distribution'], None, B, N,
                                                 additive.sample_rate, voice_major=vm, audible=ctl['_audible'],
@@ -460,6 +482,9 @@ def run(plan, inputs, noise=None, need_stems=True):
                      'harmonic_distribution': voice(ctl['harmonic_distribution'], (T, H)),
                      'harmonic_shifts': voice(ctl['harmonic_shifts'], (T, H)),
                      'f0_hz': voice(ctl['f0_hz'], (T, S))}}
+    if surrogate:
+        outputs[additive.name]['controls'].update(decays=voice(ctl['decays'], (T, H)),
+                                                  decay_time=voice(ctl['decay_time'], (T, 1)))
     outputs[noise_p.name] = {'signal': noise_sig[:, last],
                              'controls': {'magnitudes': voice(nctl['magnitudes'], (T, K))}}
     if not default_shape:

@@ -128,6 +128,19 @@ int ddspp_harmonic_synthesis(const float* f0_hz, const float* amplitudes,
                              int H, int U, float sample_rate, int use_angular_cumsum, int spans,
                              void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* surrogate_harmonic_synthesis(...) = SurrogateAdditive.get_signal -- ddsp_piano/modules/surrogate_synth.py:11-104,
+ * :203-214 (configs/surrogate.gin): harmonic_synthesis with every partial's amplitude envelope multiplied by
+ * |decays[t,k]| ** (decay_time[t] * U + n % U), t = n / U (:76-95), straight from the frame-rate controls (the [R,N,H]
+ * envelopes are never formed; ddspp_decay_envelope is the materialised form of the same term).
+ * f0_hz[R,T,1], amplitudes[R,T], harmonic_distribution[R,T,H], harmonic_shifts[R,T,H] (or NULL), decays[R,T,H],
+ * decay_time[R,T] -> audio[R, T*U].  Tables, workspace (ddspp_osc_workspace_bytes(R, T*U, H)) and spans as
+ * ddspp_harmonic_synthesis. */
+int ddspp_surrogate_harmonic_synthesis(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                                       const float* harmonic_shifts, const float* decays, const float* decay_time,
+                                       const float* wlin, const float* whann, float* audio, int R, int T, int H, int U,
+                                       float sample_rate, int use_angular_cumsum, int spans, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream);
+
 /* The additive branch of the whole polyphonic group: audio[B, T*U] = sum over the P voices of a segment
  * of MultiInharmonic.get_signal (the `additive/signal` terms of polyphonic_dag.py:28-37); rows of the
  * controls are [B * P] segment major (voice_major = 0), or [P * B] voice major (voice_major = 1): the layout the

@@ -305,6 +305,52 @@ def test_surrogate_additive_matches_oracle():
     assert rms_err(got, ref) < TOL * max(1.0, rms(ref))
 
 
+@pytest.mark.parametrize('B,T,H,sr,shifts', [
+    (2, 40, 96, 16000, True),        # configs/surrogate.gin dims
+    (3, 260, 96, 16000, True),       # 17 chunks: spans start inside frames (1000 % 64 != 0) -> the power is re-seeded mid-frame
+    (2, 60, 130, 24000, False),      # three oscillators per lane, no harmonic_shifts
+    (1, 25, 40, 48000, True),        # hop 192
+])
+def test_surrogate_fused_route_matches_oracle_and_the_operator_route(B, T, H, sr, shifts, monkeypatch):
+    """Round 4: SurrogateAdditive.get_signal straight from the frame controls (ddspp_surrogate_harmonic_synthesis: the decay
+    term inside the oscillator kernel) against the oracle and against the three-operator route over materialised envelopes."""
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(1000 * B + T + H)
+    U = sr // 250
+    raw = synth_controls(rng, B, T, H, silent_frac=0.0, midi_lo=30, midi_hi=80)
+    decays = rng.uniform(0.9985, 1.0, [B, T, H]).astype(np.float32)
+    decays[:, :, ::7] *= -1.0                                            # |decays|
+    decays[0, :, 3] = 1e-5                                               # the clip's lower end: underflows within a frame
+    decay_time = np.tile((np.arange(T, dtype=np.float32) % 37)[None, :, None], [B, 1, 1])
+    o = O.SurrogateAdditive(sample_rate=sr, scale_fn=O.exp_tanh, normalize_harm_distribution=False, inference=True)
+    octl = o.get_controls(raw['amplitudes'], np.abs(decays), decay_time, raw['harmonic_distribution'], raw['inharm_coef'],
+                          raw['f0_hz'])
+    octl['decays'] = np.where(octl['decays'] == np.abs(decays), decays, octl['decays']).astype(np.float32)   # signs back in
+    if not shifts:
+        octl['harmonic_shifts'] = None
+    ref = O.surrogate_harmonic_synthesis(octl['f0_hz'], octl['amplitudes'], octl['decays'], octl['decay_time'],
+                                         octl['harmonic_shifts'], octl['harmonic_distribution'], upsampling=U, sample_rate=sr,
+                                         use_angular_cumsum=True)
+    args = dict(frequencies=_dev(octl['f0_hz']), amplitudes=_dev(octl['amplitudes']), decays=_dev(octl['decays']),
+                decay_time=_dev(octl['decay_time']), harmonic_shifts=_dev(octl['harmonic_shifts']) if shifts else None,
+                harmonic_distribution=_dev(octl['harmonic_distribution']), upsampling=U, sample_rate=sr,
+                use_angular_cumsum=True)
+    monkeypatch.setenv('DDSPP_SURROGATE_MATERIALISED', '1')
+    slow = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
+    monkeypatch.delenv('DDSPP_SURROGATE_MATERIALISED')
+    fast = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
+    assert fast.shape == ref.shape == (B, T * U)
+    assert rms_err(slow, ref) < TOL * max(1.0, rms(ref))
+    assert rms_err(fast, ref) < TOL * max(1.0, rms(ref)), rms_err(fast, ref)
+    assert np.abs(fast - slow).max() < 2e-5 * max(1.0, np.abs(slow).max())
+    # plain cumsum (training-time form) takes the same kernel
+    args['use_angular_cumsum'] = False
+    fast_p = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
+    monkeypatch.setenv('DDSPP_SURROGATE_MATERIALISED', '1')
+    slow_p = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
+    assert np.abs(fast_p - slow_p).max() < 5e-4 * max(1.0, np.abs(slow_p).max())
+
+
 @pytest.mark.parametrize('B,T,H,S,sr,fr', [
     (2, 30, 64, 1, 16000, 160),     # U = 100: not a multiple of 8 -> resample + cos_oscillator_bank route
     (1, 1, 32, 1, 16000, 250),      # a single control frame

@@ -1,0 +1,51 @@
+"""Every gin file the reference ships as bench.py builds it for its `shipped_configs` extra: the
+group runs at small dims, the batched route takes it (SurrogateAdditive too since round 4), and the batched
+route agrees with the node-by-node walk on the same noise."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONFIGS = {'maestro-v2': (128, 96, 1, 24000, 4800), 'dafx22-24kHz': (128, 96, 2, 24000, 3600),
+           'ENSTDkCl-8kHz': (48, 32, 1, 8000, 1600), 'ENSTDkCl-32kHz': (192, 128, 1, 32000, 6400),
+           'multi_instruments': (96, 64, 1, 16000, 2400), 'surrogate': (96, 64, 1, 16000, 1600)}
+
+
+@pytest.mark.parametrize('cfg', sorted(CONFIGS))
+def test_shipped_config_group(cfg):
+    import bench
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import polyphonic
+    H, K, S, sr, L = CONFIGS[cfg]
+    B, P, T = 2, 3, 24
+    dev = torch.device('cuda', 0)
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=5, silent_frac=0.0, midi_lo=40, midi_hi=90)
+    if cfg == 'surrogate':
+        g = torch.Generator(device=dev)
+        g.manual_seed(6)
+        for i in range(P):
+            feats[f'decays_{i}'] = 0.9990 + 0.0012 * torch.rand(B, T, H, generator=g, device=dev)
+            feats[f'decay_time_{i}'] = torch.arange(T, device=dev, dtype=torch.float32).view(1, T, 1).expand(B, T, 1).contiguous()
+    N = T * (sr // 250)
+    noise = [2.0 * torch.rand(B, N, device=dev) - 1.0 for _ in range(P)]
+    pg = bench.build_shipped_group(dp, cfg, P, sr)
+    assert polyphonic.recognise(pg.dag) is not None
+    out = pg(feats, return_outputs_dict=True, noise=noise)
+    assert out['signal'].shape == (B, N) and bool(torch.isfinite(out['signal']).all())
+    assert float(out['signal'].abs().max()) > 0.0
+    walk = dp.ProcessorGroup(bench.build_shipped_group(dp, cfg, P, sr).dag, fast_path=False)
+    if cfg.startswith('ENST'):           # the same network parameters in both groups
+        walk.processors[-1].load_parameters(pg.processors[-1].parameters())
+    ref = walk(feats, return_outputs_dict=True, noise=noise)['signal']
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((out['signal'] - ref).abs().max()) < 2e-5 * scale
+    if cfg == 'surrogate':               # the dictionary of the batched route holds what the walk's holds for the re-used processors
+        walk_out = walk(feats, return_outputs_dict=True, noise=noise)
+        for k, v in walk_out['controls']['additive']['controls'].items():
+            got = out['controls']['additive']['controls'][k]
+            assert got.shape == v.shape and float((got - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+        assert float((out['controls']['additive']['signal'] - walk_out['controls']['additive']['signal']).abs().max()) < 2e-5
