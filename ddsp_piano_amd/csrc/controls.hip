@@ -154,7 +154,7 @@ __device__ __forceinline__ void inharmonic_controls_body(const InharmParams& p) 
                 }
             }
         }
-        if (!p.normalize_after_nyquist_cut) {                                // :194-198
+        if (p.normalize_after_nyquist_cut == 0) {                            // :194-198   (2 = never: SurrogateAdditive)
             const float tot = row_sum(sum);
             const float den = tot == 0.0f ? 1e-7f : tot;                     // core.safe_divide
             const float rden = 1.0f / den;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void inharmonic_controls_body(const InharmParams& p) 
             }
             amp = amp * (f0 > p.min_frequency ? 1.0f : 0.0f);
         }
-        if (p.normalize_after_nyquist_cut) {                                 // :210-214
+        if (p.normalize_after_nyquist_cut == 1) {                            // :210-214
             const float tot = row_sum(sum);
             const float den = tot == 0.0f ? 1e-7f : tot;
             const float rden = 1.0f / den;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void inharmonic_controls_wide_body(const InharmParams
         float hd = 0.0f, shift;
         bool above = false;
         if (k < H) element(k, hd, shift, above);
-        if (p.normalize_after_nyquist_cut && p.normalize_below_nyquist && above) hd = 0.0f;
+        if (p.normalize_after_nyquist_cut == 1 && p.normalize_below_nyquist && above) hd = 0.0f;
         if (k < H) sum += hd;
     }
     const float tot = row_sum(sum);
@@ -278,9 +278,9 @@ __device__ __forceinline__ void inharmonic_controls_wide_body(const InharmParams
         float hd, shift;
         bool above;
         element(k, hd, shift, above);
-        if (!p.normalize_after_nyquist_cut) hd = hd / den;
+        if (p.normalize_after_nyquist_cut == 0) hd = hd / den;
         if (p.normalize_below_nyquist && above) hd = 0.0f;
-        if (p.normalize_after_nyquist_cut) hd = hd / den;
+        if (p.normalize_after_nyquist_cut == 1) hd = hd / den;
         if (live) {
             p.hd_out[frame * H + k] = hd;
             if (p.shifts_out) p.shifts_out[frame * H + k] = shift;
@@ -586,6 +586,9 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     DDSPP_REQUIRE(R > 0 && T > 0 && H > 0 && S > 0, "inharmonic_controls: bad dims");
     DDSPP_REQUIRE(H <= 512, "inharmonic_controls: n_harmonics=%d exceeds 512", H);
     DDSPP_REQUIRE(scale_kind >= 0 && scale_kind <= 2, "inharmonic_controls: unknown scale_fn %d", scale_kind);
+    DDSPP_REQUIRE(normalize_after_nyquist_cut >= 0 && normalize_after_nyquist_cut <= 2,
+                  "inharmonic_controls: normalize_after_nyquist_cut=%d (0 before the cut, 1 after it, 2 never)", normalize_after_nyquist_cut);
+    const bool norm_after = normalize_after_nyquist_cut == 1;
     InharmParams p{};
     p.amplitudes = amplitudes; p.harmonic_distribution = harmonic_distribution;
     p.inharm_coef = inharm_coef; p.f0_hz = f0_hz;
@@ -601,12 +604,12 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     p.scale = ScaleFn{scale_kind, logf(exponent), max_value, threshold, gain};
     const size_t frames = (size_t)R * T;
     const int nj = (H + 15) / 16;
-    const bool two_pass = nj <= 8 || (nj == 12 && normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 &&
+    const bool two_pass = nj <= 8 || (nj == 12 && norm_after && normalize_below_nyquist && H % 16 == 0 &&
                                       !ddspp_option("DDSPP_CONTROLS_GENERIC", 0));          // (the lean kernel: always two)
     const size_t per_wg = (size_t)4 * 4 * (two_pass ? 2 : 1);           // four wavefronts of 4 * CTL_PASS frames
     const dim3 grid((unsigned)((frames + per_wg - 1) / per_wg)), block(256);
     // every shipped model: 48 / 64 / 96 / 128 / 192 harmonics (8, 16, 16 / 24, 24 / 48, 32 kHz) with the default flags
-    const bool lean = normalize_after_nyquist_cut && normalize_below_nyquist && H % 16 == 0 &&
+    const bool lean = norm_after && normalize_below_nyquist && H % 16 == 0 &&
                       (nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12) && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0);
 #define DDSPP_LEAN(NJ)                                                                                              \
     do {                                                                                                            \
@@ -663,6 +666,37 @@ int ddspp_inharmonic_controls_group(const float* amplitudes, const float* harmon
                                     min_frequency, scale_kind, exponent, max_value, threshold, gain,
                                     normalize_after_nyquist_cut, normalize_below_nyquist, shifts_last_out, n_voices,
                                     voice_major, stream);
+}
+
+// SurrogateAdditive.get_controls' decay factors -- ddsp_piano/modules/surrogate_synth.py:163-171:
+// decays_out = where(inharmonic_freq >= sample_rate / 2, 1, clip(decays, 1e-5, 1)), inharmonic_freq = (f0 k) g with
+// g = sqrt(k^2 max(inharm_coef, 0) + 1) formed as get_inharmonic_freq does (inharm_synth.py:37-42, osc_common.h).
+__global__ void __launch_bounds__(256) surrogate_decays_kernel(const float* __restrict__ decays, const float* __restrict__ inharm_coef,
+                                                             const float* __restrict__ f0_hz, float* __restrict__ out, size_t frames,
+                                                             int H, float nyquist) {
+    const size_t total = frames * (size_t)H;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t fr = g / (size_t)H;
+        const float m = (float)(int)(g - fr * (size_t)H + 1);
+        const float inharm = fmaxf(inharm_coef[fr], 0.0f);
+        float q = m * m;
+        q = q * inharm + 1.0f;
+        q = sqrtf(q);
+        const float freq = (f0_hz[fr] * m) * q;
+        const float d = fmaxf(fminf(decays[g], 1.0f), 1e-5f);                     // :165-166 (minimum, then maximum)
+        out[g] = freq >= nyquist ? 1.0f : d;
+    }
+}
+
+int ddspp_surrogate_decays(const float* decays, const float* inharm_coef, const float* f0_hz, float* decays_out, int R, int T,
+                           int H, float sample_rate, hipStream_t stream) {
+    DDSPP_REQUIRE(decays && inharm_coef && f0_hz && decays_out, "surrogate_decays: null buffer");
+    DDSPP_REQUIRE(R > 0 && T > 0 && H > 0, "surrogate_decays: bad dims");
+    const size_t frames = (size_t)R * T;
+    hipLaunchKernelGGL(surrogate_decays_kernel, dim3(stream_grid(frames * (size_t)H)), dim3(256), 0, stream, decays, inharm_coef,
+                       f0_hz, decays_out, frames, H, sample_rate / 2.0f);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
 }
 
 // ddsp.synths.FilteredNoise.get_controls: magnitudes = scale_fn(magnitudes + initial_bias)

@@ -150,8 +150,37 @@ class SurrogateAdditive(Processor):
         self.inference = inference
 
     def get_controls(self, amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz):
+        """surrogate_synth.py:140-197.  Two kernels when the shapes are the plain ones: ddspp_inharmonic_controls (scale,
+        shifts, Nyquist cut, audibility gate, normalisation -- mode 2 = none for normalize_harm_distribution=False) and
+        ddspp_surrogate_decays; anything else is composed from the library's primitives as before."""
         amplitudes, harmonic_distribution = core.tf_float32(amplitudes), core.tf_float32(harmonic_distribution)
         f0_hz = core.tf_float32(f0_hz)
+        kind = core.scale_kind(self.scale_fn)
+        if (kind is not None and harmonic_distribution.dim() == 3 and harmonic_distribution.is_cuda
+                and harmonic_distribution.shape[-1] <= 512
+                and tuple(amplitudes.shape) == tuple(harmonic_distribution.shape[:2]) + (1,)
+                and tuple(f0_hz.shape) == tuple(amplitudes.shape)
+                and inharm_coef is not None and tuple(inharm_coef.shape) == tuple(amplitudes.shape)
+                and (decays is None or tuple(decays.shape) == tuple(harmonic_distribution.shape))):
+            b, t, h = harmonic_distribution.shape
+            code, prm = kind
+            amplitudes, harmonic_distribution = amplitudes.contiguous(), harmonic_distribution.contiguous()
+            inharm_coef, f0_hz = core.tf_float32(inharm_coef).contiguous(), f0_hz.contiguous()
+            amp_out, hd_out = torch.empty_like(amplitudes), torch.empty_like(harmonic_distribution)
+            shifts_out = torch.empty_like(harmonic_distribution)
+            _lib.check(_lib_().ddspp_inharmonic_controls(
+                _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out), _ptr(hd_out),
+                _ptr(shifts_out), None, b, t, h, 1, float(self.sample_rate), float(self.min_frequency), code,
+                prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
+                1 if self.normalize_harm_distribution else 2, int(bool(self.normalize_below_nyquist)), _stream()))
+            if decays is not None:
+                decays = core.tf_float32(decays).contiguous()
+                dec_out = torch.empty_like(decays)
+                _lib.check(_lib_().ddspp_surrogate_decays(_ptr(decays), _ptr(inharm_coef), _ptr(f0_hz), _ptr(dec_out), b, t, h,
+                                                          float(self.sample_rate), _stream()))
+                decays = dec_out
+            return {'amplitudes': amp_out, 'decays': decays, 'decay_time': decay_time,
+                    'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out, 'f0_hz': f0_hz}
         if self.scale_fn is not None:                                                   # :152-154
             amplitudes = core.tf_float32(self.scale_fn(amplitudes))
             harmonic_distribution = core.tf_float32(self.scale_fn(harmonic_distribution))

@@ -188,7 +188,10 @@ int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shift
  * ddspp_polyphonic_additive); audible_out[R,T] (int32, may be NULL): bits 0-15 = 1 + index of the last harmonic
  * with amplitudes_out * harmonic_distribution_out != 0 in the frame, bit 16 = some f0_hz sub-string or the clamped
  * inharm_coef differs from the previous frame's (the harmonic frequencies may have moved).
- * ddspp_polyphonic_additive accepts it as `audible`, so that it need not scan the [R,T,H] tensors again. */
+ * ddspp_polyphonic_additive accepts it as `audible`, so that it need not scan the [R,T,H] tensors again.
+ * normalize_after_nyquist_cut: 1 = the distribution is normalised after the Nyquist cut (:210-214), 0 = before it
+ * (:194-198), 2 = never -- SurrogateAdditive.get_controls with normalize_harm_distribution=False
+ * (surrogate_synth.py:152-187 is this function with that flag and the decays of ddspp_surrogate_decays). */
 int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_distribution,
                               const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
                               float* harmonic_distribution_out, float* harmonic_shifts_out, int* audible_out,
@@ -196,6 +199,12 @@ int ddspp_inharmonic_controls(const float* amplitudes, const float* harmonic_dis
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
                               hipStream_t stream);
+/* SurrogateAdditive.get_controls' decay factors -- ddsp_piano/modules/surrogate_synth.py:163-171:
+ * decays_out[R,T,H] = where(inharmonic_freq >= sample_rate / 2, 1, clip(decays, 1e-5, 1)), the inharmonic frequencies formed
+ * from f0_hz[R,T] and inharm_coef[R,T] as get_inharmonic_freq does. */
+int ddspp_surrogate_decays(const float* decays, const float* inharm_coef, const float* f0_hz, float* decays_out, int R, int T,
+                           int H, float sample_rate, hipStream_t stream);
+
 /* The same over the R = n_segments * n_voices rows of a polyphonic group (segment major, or voice major as
  * ddspp_polyphonic_additive), writing harmonic_shifts only for every segment's LAST voice (shifts_last_out
  * [R / n_voices, T, H], may be NULL): ddspp_polyphonic_additive forms the shifts of all voices itself from inharm_coef,

@@ -9,7 +9,7 @@ f=$(find $R/gpurun_out/$TAG/$c -name "*kernel_stats.csv" | head -1)
 python - "$f" <<PY
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:8]:
+for r in rows[:24]:
     print('%-90s calls %5s avg_us %9.1f pct %5s' % (r['Name'][:90], r['Calls'], float(r['AverageNs'])/1e3, r['Percentage']))
 PY
 find $R/gpurun_out/$TAG/$c -name "*.csv" ! -name "*kernel_stats.csv" -delete

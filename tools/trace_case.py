@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one bench input case a few times (for rocprofv3 --kernel-trace --stats).
-usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22|dafx24|multi|enst8k|enst32k|file|one] [audio|dict] [reps]"""
+usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22|dafx24|multi|surrogate|enst8k|enst32k|file|one] [audio|dict] [reps]"""
 import os
 import sys
 
@@ -24,6 +24,8 @@ elif case == 'dafx24':      # configs/dafx22-24kHz.gin dims: two sub-strings at 
     B, P, H, K, S, sr, L = 64, 16, 128, 96, 2, 24000, 36000
 elif case == 'multi':       # configs/multi_instruments.gin dims
     B, P, H, K, S, sr, L = 64, 16, 96, 64, 1, 16000, 24000
+elif case == 'surrogate':   # configs/surrogate.gin dims and flags (bench.py: shipped_configs)
+    B, P, H, K, S, sr, L = 64, 16, 96, 64, 1, 16000, 16000
 elif case == 'file':        # bench.py whole_file: 136 s as one segment
     B, T, L = 1, 34000, 48000
 elif case == 'one':         # bench.py single_stream: one 3 s segment
@@ -32,10 +34,18 @@ elif case == 'enst8k':      # configs/ENSTDkCl-8kHz.gin dims (here with ddsp.eff
     B, P, H, K, S, sr, L = 64, 16, 48, 32, 1, 8000, 16000
 elif case == 'enst32k':     # configs/ENSTDkCl-32kHz.gin dims
     B, P, H, K, S, sr, L = 64, 16, 192, 128, 1, 32000, 64000
-kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
+kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'surrogate': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
       'dense': dict(silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)}[case]
 feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
 pg = bench.build_group(dp, P, sr)
+if case == 'surrogate':
+    g = torch.Generator(device=dev)
+    g.manual_seed(44)
+    dec = 0.9990 + 0.0012 * torch.rand(B, P, T, H, generator=g, device=dev)
+    dt = torch.arange(T, device=dev, dtype=torch.float32).view(1, 1, T, 1).expand(B, P, T, 1).contiguous()
+    for i in range(P):
+        feats[f'decays_{i}'], feats[f'decay_time_{i}'] = dec[:, i], dt[:, i]
+    pg = bench.build_shipped_group(dp, 'surrogate', P, sr)
 fn = (lambda: pg(feats, return_outputs_dict=True)) if form == 'dict' else (lambda: pg(feats))
 ts = bench.event_times(fn, reps, warmup=2)
 print(case, form, 'ms per step:', bench.ms_summary(ts))
