@@ -130,6 +130,8 @@ SIGNATURES = {
     'ddspp_surrogate_decays': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
     'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
     'ddspp_polyphonic_additive': (c_int, [c_void_p] * 11 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_surrogate_additive': (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_float, c_int, c_int, c_void_p, c_size_t,
+                                                    c_void_p]),
     'ddspp_oscillator_phase_state_workspace_bytes': (c_size_t, [c_int] * 4),
     'ddspp_oscillator_phase_state': (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_inharmonic_controls': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

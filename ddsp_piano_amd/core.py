@@ -658,7 +658,7 @@ def harmonic_synthesis_fused(f0_hz, amplitudes, harmonic_distribution, harmonic_
 
 def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples,
                         sample_rate, spans=0, voice_major=False, audible=None, split_last=False, inharm_coef=None,
-                        phase_state=None, sample_offset=0):
+                        phase_state=None, sample_offset=0, decays=None, decay_time=None):
     """Sum over the voices of each segment of MultiInharmonic.get_signal: rows [B * P, T, .] -> [B, N]
     (rows ordered [B, P], or [P, B] with voice_major=True).
 
@@ -669,7 +669,9 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     reference's DAG holds for the re-used additive processor (polyphonic_dag.py:28-37).
     harmonic_shifts=None with inharm_coef [R, T] (raw): the kernels form the shifts themselves (get_inharmonic_freq).
     phase_state [R, S * H]: streaming -- the oscillators continue from the state oscillator_phase_state left;
-    sample_offset: absolute position of the first sample in the streamed signal (linear_weights)."""
+    sample_offset: absolute position of the first sample in the streamed signal (linear_weights).
+    decays [R, T, H] + decay_time [R, T]: SurrogateAdditive voices (ddspp_polyphonic_surrogate_additive; one sub-string,
+    no streaming state)."""
     r, t, s = f0_hz.shape
     h = harmonic_distribution.shape[-1]
     b = int(n_segments)
@@ -686,6 +688,17 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     null = ctypes.c_void_p(0)
     if audible is not None and (audible.dtype != torch.int32 or audible.numel() != r * t or not audible.is_contiguous()):
         raise ValueError('audible must be a contiguous int32 tensor of R * T frame counts')
+    if decays is not None:
+        if s != 1 or phase_state is not None or decay_time is None:
+            raise ValueError('polyphonic_additive: decays need decay_time, one sub-string and no streaming state')
+        _lib.check(lib.ddspp_polyphonic_surrogate_additive(
+            _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
+            _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
+            _ptr(inharm_coef) if (inharm_coef is not None and harmonic_shifts is None) else null,
+            ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(decays), _ptr(decay_time),
+            _ptr(wlin), _ptr(whann), _ptr(out), _ptr(last), b, p, t, h, u, float(sample_rate), int(spans),
+            int(bool(voice_major)), _ptr(ws), nbytes, _stream()))
+        return (out, last) if split_last else out
     _lib.check(lib.ddspp_polyphonic_additive(
         _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
         _ptr(harmonic_shifts) if harmonic_shifts is not None else null,

@@ -36,7 +36,10 @@ struct SlotCtx {
 // The walk of one slot with VPL oscillators per lane (64 VPL oscillators from `first`).  A slot of the VPL = 2 kernel
 // that has 64 or fewer oscillators left -- the last slot of a segment half the time, and always the slot(s) of the
 // last voice when the caller wants that voice's stem on its own -- runs the VPL = 1 body: half the instructions.
-template <int VPL>
+// DECAY (SurrogateAdditive, surrogate_synth.py:76-95): the amplitude of oscillator k in frame t is multiplied by
+// |decays[t, k]| ** (decay_time[t] U + r); as in osc_kernel<..., DECAY> the power is evaluated by powf once per frame and
+// lane and advances by d ** 8 per block and d per sample.  The next frame's factors are requested one frame ahead.
+template <int VPL, bool DECAY = false>
 __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const SlotCtx& c) {
     const int lane = c.lane, row = c.row, span = c.span, cw_all = c.cw_all;
     const int n_begin = c.n_begin, n_end = c.n_end, qlo = c.qlo, qhi = c.qhi, total = c.total;
@@ -104,6 +107,30 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     //   ha(t, v) = amp[t] * hd[t, k]                      inharm_synth.py:112
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
     float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
+    // DECAY: d0 = |decays| of the current frame, e_blk = d0 ** (decay_time U + r) at the start of the current block,
+    // d0_8 = d0 ** 8; nd / ndt = the next frame's raw factor and time (requested when the current frame starts)
+    float d0[DECAY ? VPL : 1], e_blk[DECAY ? VPL : 1], d0_8[DECAY ? VPL : 1], nd[DECAY ? VPL : 1], ndt[DECAY ? VPL : 1];
+    auto decay_request = [&](int tt) {
+        if constexpr (DECAY) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const size_t fr = (size_t)lrow[j] * T + tt;
+                nd[j] = p.decays[fr * H + vk[j]];
+                ndt[j] = p.decay_time[fr];
+            }
+        }
+    };
+    auto decay_start = [&](int r0) {       // the requested frame becomes the current one, at its sample r0
+        if constexpr (DECAY) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                d0[j] = fabsf(nd[j]);
+                e_blk[j] = powf(d0[j], ndt[j] * (float)U + (float)r0);
+                const float d2 = d0[j] * d0[j], d4 = d2 * d2;
+                d0_8[j] = d4 * d4;
+            }
+        }
+    };
     const bool has_shifts = p.shifts != nullptr, from_inh = !has_shifts && p.inh != nullptr;
     auto frame_request = [&](int tt) {
 #pragma unroll
@@ -165,6 +192,9 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     frame_finish(x1, a1);
     frame_request(min(t + 2, T - 1));
     classify_frame();
+    decay_request(t);
+    decay_start(r);
+    decay_request(min(t + 1, T - 1));
 
     float* out_row = p.out + ((size_t)row * p.wmax + cw_all) * N;
     int cpos = 0, tpos = 0, tile_n0 = n_begin;
@@ -236,9 +266,18 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
         // ---- stage 4: Hann cross-fade of the amplitudes (core.upsample_with_windows: a0 w[U + r] + a1 w[r] with
         // w[U + r] + w[r] = 1 to an ulp = a0 + (a1 - a0) w[r]), Nyquist mask, harmonic sum over the lane's own -------
         float acc[BLK];
+        float er[DECAY ? VPL : 1];         // DECAY: the power at sample i of the block
+        if constexpr (DECAY) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) er[j] = e_blk[j];
+        }
 #pragma unroll
         for (int i = 0; i < BLK; ++i) {
             float a = __builtin_fmaf(da[0], w1[i], am0[0]);
+            if constexpr (DECAY) {
+                a = a * er[0];                                             // surrogate_synth.py:91-95
+                er[0] = er[0] * d0[0];
+            }
             if (MASK) a = (fe[i][0] >= nyq) ? 0.0f : a;                    // remove_above_nyquist
             acc[i] = a * pv[i][0];
         }
@@ -247,9 +286,17 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
             for (int i = 0; i < BLK; ++i) {
                 float a = __builtin_fmaf(da[j], w1[i], am0[j]);
+                if constexpr (DECAY) {
+                    a = a * er[j];
+                    er[j] = er[j] * d0[j];
+                }
                 if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
                 acc[i] = __builtin_fmaf(a, pv[i][j], acc[i]);
             }
+        if constexpr (DECAY) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) e_blk[j] = e_blk[j] * d0_8[j];
+        }
 #if defined(DDSPP_BANK_ABLATE) && (DDSPP_BANK_ABLATE & 2)
         float keep = 0.f;
 #pragma unroll
@@ -382,7 +429,12 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 for (int j = 0; j < VPL; ++j) {
                     const float f = (wli == WALK_NEXT_ROW) ? x1[j] : x0[j] + (x1[j] - x0[j]) * wli;
                     ph[j] = ph[j] + omega_of<false>(f, sr, rsr);
-                    const float a = (f >= nyq) ? 0.0f : __builtin_fmaf(da[j], whi, am0[j]);
+                    float a = __builtin_fmaf(da[j], whi, am0[j]);
+                    if constexpr (DECAY) {
+                        a = a * e_blk[j];
+                        e_blk[j] = e_blk[j] * d0[j];
+                    }
+                    a = (f >= nyq) ? 0.0f : a;
                     acc = __builtin_fmaf(a, cos_reduced(mod_2pi(ph[j] + off[j])), acc);
                 }
                 tile[(tpos + i) * TSTRIDE + lane] = acc;
@@ -397,6 +449,8 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
         // A held note: the frame pair before was constant (x0 == x1 in every lane) and the next frame's raw f0_hz and
         // inharm_coef (or shifts) are the very same numbers -> the new pair is the old one.  Only the amplitudes move:
         // no per-lane square root (shift_from_inharm), no classification, om_c / fast / need_mask stay.
+        decay_start(0);                              // (DECAY) the frame requested one frame ago becomes the current one
+        decay_request(min(t + 1, T - 1));
         bool same = const_freq;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) same = same && (q_f0[j] == r_f0[j]) && (q_sh[j] == r_sh[j]);
@@ -426,7 +480,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 }
 
 // One wavefront per workgroup: slots past the audible set exit at once and give their place to the next workgroup.
-template <int VPL>
+template <int VPL, bool DECAY = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bank_compact_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
@@ -481,9 +535,9 @@ bank_compact_kernel(const OscParams p) {
         (q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE))[i & 3] = p.whann[i];
     }
     if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
-        bank_slot<2>(p, tile, c);
+        bank_slot<2, DECAY>(p, tile, c);
     else
-        bank_slot<1>(p, tile, c);
+        bank_slot<1, DECAY>(p, tile, c);
 }
 
 // audio[b, n] = sum over the wavefront slots that were used, in slot order (deterministic); with split_last the last
@@ -520,6 +574,11 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
 void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
     const size_t lds = (size_t)(TILE * TSTRIDE + (p.U > 4 * TILE ? p.U - 4 * TILE : 0)) * sizeof(float);   // tile (+ what of the Hann window its padding cannot hold)
     const dim3 grid((unsigned)((size_t)p.R * p.spans * p.wmax)), blk(64);
+    if (p.decays) {                        // SurrogateAdditive: the decay term rides in the block's amplitude stage
+        if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1, true>), grid, blk, lds, stream, p);
+        else hipLaunchKernelGGL((bank_compact_kernel<2, true>), grid, blk, lds, stream, p);
+        return;
+    }
     if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1>), grid, blk, lds, stream, p);
     else hipLaunchKernelGGL((bank_compact_kernel<2>), grid, blk, lds, stream, p);
 }

@@ -1649,11 +1649,12 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
-int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
-                              const float* harmonic_shifts, const float* inharm_coef, const int* audible,
-                              const float* wlin, const float* whann, const float* phase_state_in, float* audio,
-                              float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
-                              int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                                    const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                                    const float* decays, const float* decay_time,
+                                    const float* wlin, const float* whann, const float* phase_state_in, float* audio,
+                                    float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                                    int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
                   "polyphonic_additive: null buffer");
     DDSPP_REQUIRE(B > 0 && P > 0 && T > 0 && S > 0 && H > 0 && U > 0, "polyphonic_additive: bad dims");
@@ -1695,6 +1696,7 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     p.inh = harmonic_shifts ? nullptr : inharm_coef;       // shifts formed in the kernels from the raw inharm_coef
     p.audible = audible;
     p.state_in = phase_state_in;
+    p.decays = decays; p.decay_time = decay_time;           // SurrogateAdditive (null: none)
     p.dbg_noflags = env_int("DDSPP_OSC_NO_FLAGS", 0);
     p.wlin = wlin; p.whann = whann;
     p.N = N; p.T = T; p.U = U; p.H = H; p.S = S; p.V = V; p.VP = VP;
@@ -1737,6 +1739,31 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     }
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
+}
+
+int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                              const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                              const float* wlin, const float* whann, const float* phase_state_in, float* audio,
+                              float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
+                              int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return polyphonic_additive_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, inharm_coef, audible, nullptr,
+                                    nullptr, wlin, whann, phase_state_in, audio, audio_last, B, P, T, S, H, U, sample_rate,
+                                    spans, voice_major, workspace, workspace_bytes, stream);
+}
+
+// The same for SurrogateAdditive voices (surrogate_synth.py:11-104, configs/surrogate.gin): every partial's amplitude
+// multiplied by |decays[t, k]| ** (decay_time[t] U + n % U) inside the compacted bank.  decays [B * P, T, H] as
+// ddspp_surrogate_decays leaves them, decay_time [B * P, T]; one sub-string.
+int ddspp_polyphonic_surrogate_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                                        const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                                        const float* decays, const float* decay_time, const float* wlin, const float* whann,
+                                        float* audio, float* audio_last, int B, int P, int T, int H, int U, float sample_rate,
+                                        int spans, int voice_major, void* workspace, size_t workspace_bytes,
+                                        hipStream_t stream) {
+    DDSPP_REQUIRE(decays && decay_time, "polyphonic_surrogate_additive: null decay buffers");
+    return polyphonic_additive_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, inharm_coef, audible, decays,
+                                    decay_time, wlin, whann, nullptr, audio, audio_last, B, P, T, 1, H, U, sample_rate, spans,
+                                    voice_major, workspace, workspace_bytes, stream);
 }
 
 // Streaming: the state an oscillator bank carries from one call to the next.  ddsp.core.angular_cumsum restarts the

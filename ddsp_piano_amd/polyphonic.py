@@ -288,7 +288,9 @@ def run(plan, inputs, noise=None, need_stems=True):
 
     want_all = need_stems is True or need_stems == 'all'
     want_last = need_stems == 'last'
-    compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0 and not surrogate
+    compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
+    if surrogate:                  # (the compacted bank takes the decay term when get_controls runs as kernels)
+        compact = compact and core.scale_kind(additive.scale_fn) is not None and H <= 512
     # --- noise branch ---------------------------------------------------------------------------
     fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
@@ -344,13 +346,25 @@ def run(plan, inputs, noise=None, need_stems=True):
     if surrogate:
         # SurrogateAdditive: its get_controls over all rows at once, per-voice rows straight from the frame controls with
         # the decay term inside the oscillator kernel (core.surrogate_harmonic_synthesis -> ddspp_surrogate_harmonic_synthesis)
-        ctl = additive.get_controls(amp, dec, dtm, hd, inh, f0)
+        ctl = additive.get_controls(amp, dec, dtm, hd, inh, f0, _want_counts=compact)
+        if compact and '_audible' not in ctl:          # get_controls did not run as kernels: the caller walks the DAG
+            return None
     else:
         ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
                                  last_voice_of=(P, vm) if want_last else None)
     additive_last = None
-    if surrogate:
-        additive_sig = additive.get_signal(**ctl)
+    if surrogate and compact:
+        additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
+                                                ctl['harmonic_distribution'], None, B, N,
+                                                additive.sample_rate, voice_major=vm, audible=ctl['_audible'],
+                                                split_last=want_last, inharm_coef=ctl['_inharm_coef'].reshape(R, T),
+                                                decays=ctl['decays'],
+                                                decay_time=core.tf_float32(ctl['decay_time']).reshape(R, T).contiguous())
+        if want_last:
+            additive_mix, additive_last = additive_mix
+        additive_sig = None
+    elif surrogate:
+        additive_sig = additive.get_signal(**{k: v for k, v in ctl.items() if not k.startswith('_')})
     elif compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                 ctl['harmonic_distribution'], None, B, N,
@@ -422,7 +436,11 @@ def run(plan, inputs, noise=None, need_stems=True):
                 dry = core.add_signals([noise_last, additive_last])
             lc = {k: voice(ctl[k], sh) for k, sh in (('amplitudes', (T, 1)), ('harmonic_distribution', (T, H)),
                                                      ('f0_hz', (T, S)))}
-            lc['harmonic_shifts'] = ctl['_shifts_last']       # written by the get_controls kernel for the last voice only
+            if surrogate:
+                lc.update(harmonic_shifts=voice(ctl['harmonic_shifts'], (T, H)), decays=voice(ctl['decays'], (T, H)),
+                          decay_time=voice(ctl['decay_time'], (T, 1)))
+            else:
+                lc['harmonic_shifts'] = ctl['_shifts_last']   # written by the get_controls kernel for the last voice only
             mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
                 noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
             outputs[additive.name] = {'signal': additive_last, 'controls': lc}

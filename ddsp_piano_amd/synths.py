@@ -149,8 +149,10 @@ class SurrogateAdditive(Processor):
         self.normalize_below_nyquist = normalize_below_nyquist
         self.inference = inference
 
-    def get_controls(self, amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz):
-        """surrogate_synth.py:140-197.  Two kernels when the shapes are the plain ones: ddspp_inharmonic_controls (scale,
+    def get_controls(self, amplitudes, decays, decay_time, harmonic_distribution, inharm_coef, f0_hz, _want_counts=False):
+        """surrogate_synth.py:140-197.  (_want_counts, batched route only: '_audible' = the per-frame counts of leading
+        non-silent harmonics and '_inharm_coef' = the raw coefficients, as InHarmonic._controls leaves them for the
+        compacted bank; None when the kernels did not run.)  Two kernels when the shapes are the plain ones: ddspp_inharmonic_controls (scale,
         shifts, Nyquist cut, audibility gate, normalisation -- mode 2 = none for normalize_harm_distribution=False) and
         ddspp_surrogate_decays; anything else is composed from the library's primitives as before."""
         amplitudes, harmonic_distribution = core.tf_float32(amplitudes), core.tf_float32(harmonic_distribution)
@@ -168,9 +170,11 @@ class SurrogateAdditive(Processor):
             inharm_coef, f0_hz = core.tf_float32(inharm_coef).contiguous(), f0_hz.contiguous()
             amp_out, hd_out = torch.empty_like(amplitudes), torch.empty_like(harmonic_distribution)
             shifts_out = torch.empty_like(harmonic_distribution)
+            counts = torch.empty((b, t), dtype=torch.int32, device=amplitudes.device) if _want_counts else None
             _lib.check(_lib_().ddspp_inharmonic_controls(
                 _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out), _ptr(hd_out),
-                _ptr(shifts_out), None, b, t, h, 1, float(self.sample_rate), float(self.min_frequency), code,
+                _ptr(shifts_out), counts.data_ptr() if counts is not None else None, b, t, h, 1, float(self.sample_rate),
+                float(self.min_frequency), code,
                 prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
                 1 if self.normalize_harm_distribution else 2, int(bool(self.normalize_below_nyquist)), _stream()))
             if decays is not None:
@@ -179,8 +183,11 @@ class SurrogateAdditive(Processor):
                 _lib.check(_lib_().ddspp_surrogate_decays(_ptr(decays), _ptr(inharm_coef), _ptr(f0_hz), _ptr(dec_out), b, t, h,
                                                           float(self.sample_rate), _stream()))
                 decays = dec_out
-            return {'amplitudes': amp_out, 'decays': decays, 'decay_time': decay_time,
-                    'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out, 'f0_hz': f0_hz}
+            ctl = {'amplitudes': amp_out, 'decays': decays, 'decay_time': decay_time,
+                   'harmonic_distribution': hd_out, 'harmonic_shifts': shifts_out, 'f0_hz': f0_hz}
+            if _want_counts:
+                ctl['_audible'], ctl['_inharm_coef'] = counts, inharm_coef
+            return ctl
         if self.scale_fn is not None:                                                   # :152-154
             amplitudes = core.tf_float32(self.scale_fn(amplitudes))
             harmonic_distribution = core.tf_float32(self.scale_fn(harmonic_distribution))

@@ -165,6 +165,16 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
                               float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* The same for SurrogateAdditive voices (surrogate_synth.py:11-104, configs/surrogate.gin through polyphonic_dag.py): every
+ * partial's amplitude multiplied by |decays[t,k]| ** (decay_time[t] * U + n % U) inside the compacted bank.  decays[B*P,T,H]
+ * as ddspp_surrogate_decays leaves them, decay_time[B*P,T]; one sub-string; workspace as ddspp_polyphonic_additive (S = 1). */
+int ddspp_polyphonic_surrogate_additive(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                                        const float* harmonic_shifts, const float* inharm_coef, const int* audible,
+                                        const float* decays, const float* decay_time, const float* wlin, const float* whann,
+                                        float* audio, float* audio_last, int B, int P, int T, int H, int U, float sample_rate,
+                                        int spans, int voice_major, void* workspace, size_t workspace_bytes,
+                                        hipStream_t stream);
+
 /* Streaming state of the oscillator banks (synthesize_midi_file.py:41-73 renders minutes of audio; this lets a caller do
  * it piecewise, or shard one file's TIME over several GPUs).  ddsp.core.angular_cumsum restarts the phase every 1000
  * samples and adds the float32 running sum of the chunks' end phases, so the only thing a later piece of the same signal

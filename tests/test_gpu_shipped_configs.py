@@ -49,3 +49,62 @@ def test_shipped_config_group(cfg):
             got = out['controls']['additive']['controls'][k]
             assert got.shape == v.shape and float((got - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
         assert float((out['controls']['additive']['signal'] - walk_out['controls']['additive']['signal']).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('B,P,T,H,sr,vibrato', [
+    (3, 5, 130, 96, 16000, 0.0),        # surrogate.gin dims: held notes, spans of 1000 samples start inside frames
+    (2, 4, 60, 128, 24000, 0.003),      # moving frequencies (the bank's moving blocks), two oscillators per lane everywhere
+    (2, 16, 40, 64, 16000, 0.0),        # sixteen voices, 64 harmonics
+])
+def test_surrogate_group_against_the_oracle_and_every_route(B, P, T, H, sr, vibrato):
+    """configs/surrogate.gin through polyphonic_dag: the compacted bank with the decay term (audio only and the outputs
+    dictionary), the every-stem route (per-voice fused kernel) and the node-by-node walk against the numpy oracle."""
+    import numpy as np
+
+    import bench
+    import ddsp_piano_amd as dp
+    from util import O, rms, rms_err
+    dev = torch.device('cuda', 0)
+    K, L = 64, 1600
+    U = sr // 250
+    N = T * U
+    feats, _ = bench.make_features(B, P, T, H, K, 1, L, dev, seed=9, silent_frac=0.2, midi_lo=30, midi_hi=100, vibrato=vibrato)
+    g = torch.Generator(device=dev)
+    g.manual_seed(10)
+    for i in range(P):
+        d = 0.9985 + 0.0017 * torch.rand(B, T, H, generator=g, device=dev)      # some above 1: clipped by get_controls
+        feats[f'decays_{i}'] = d
+        feats[f'decay_time_{i}'] = (torch.arange(T, device=dev, dtype=torch.float32) % 29).view(1, T, 1).expand(B, T, 1).contiguous()
+    noise = [2.0 * torch.rand(B, N, device=dev) - 1.0 for _ in range(P)]
+    pg = bench.build_shipped_group(dp, 'surrogate', P, sr)
+    out = pg(feats, return_outputs_dict=True, noise=noise)                       # compacted bank, last voice apart
+    audio_only = pg(feats, noise=noise)                                          # compacted bank, all voices in one sum
+    from ddsp_piano_amd import polyphonic
+    stems = polyphonic.run(polyphonic.recognise(pg.dag), feats, noise=noise, need_stems=True)   # per-voice fused kernel
+    walk = dp.ProcessorGroup(pg.dag, fast_path=False)(feats, return_outputs_dict=True, noise=noise)
+    # oracle
+    ofeats = {k: v.cpu().numpy() for k, v in feats.items()}
+    additive = O.SurrogateAdditive(name='additive', frame_rate=250, sample_rate=sr, inference=True, scale_fn=O.exp_tanh,
+                                   normalize_harm_distribution=False)
+    onoise = O.FilteredNoise(name='noise', frame_rate=250, sample_rate=sr, scale_fn=O.exp_tanh)
+    dry_ref = np.zeros((B, N), np.float32)
+    for i in range(P):
+        ctl = additive.get_controls(*[ofeats[f'{k}_{i}'] for k in ('amplitudes', 'decays', 'decay_time', 'harmonic_distribution',
+                                                                   'inharm_coef', 'f0_hz')])
+        a = additive.get_signal(**ctl)
+        z = onoise.get_signal(**onoise.get_controls(ofeats[f'magnitudes_{i}']), noise=noise[i].cpu().numpy())
+        dry_ref = (dry_ref + z).astype(np.float32) if i else z.astype(np.float32)
+        dry_ref = (dry_ref + a).astype(np.float32)
+    tol = 1e-5 * max(1.0, rms(dry_ref))
+    for name, got in (('dict', out['controls']['add']['signal']), ('walk', walk['controls']['add']['signal']),
+                      ('stems', stems['add']['signal'])):
+        assert rms_err(got.cpu().numpy(), dry_ref) < tol, (name, rms_err(got.cpu().numpy(), dry_ref), tol)
+    scale = max(1.0, float(walk['signal'].abs().max()))
+    assert float((out['signal'] - walk['signal']).abs().max()) < 2e-5 * scale
+    assert float((audio_only - walk['signal']).abs().max()) < 2e-5 * scale
+    assert float((stems['out']['signal'] - walk['signal']).abs().max()) < 2e-5 * scale
+    last = walk['controls']['additive']
+    assert float((out['controls']['additive']['signal'] - last['signal']).abs().max()) < 2e-5
+    for k, v in last['controls'].items():
+        got = out['controls']['additive']['controls'][k]
+        assert got.shape == v.shape and float((got - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
