@@ -108,3 +108,31 @@ def test_surrogate_group_against_the_oracle_and_every_route(B, P, T, H, sr, vibr
     for k, v in last['controls'].items():
         got = out['controls']['additive']['controls'][k]
         assert got.shape == v.shape and float((got - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+
+
+def test_surrogate_config_at_bench_size_routes_agree():
+    """surrogate.gin at bench.py's size (batch 64 x 3 s, poly 16): the compacted bank with the decay term against the
+    per-voice fused kernel, every sample of every row (GPU against GPU; the oracle anchors both at small sizes above)."""
+    import bench
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import polyphonic
+    dev = torch.device('cuda', 0)
+    B, P, T, H, K, sr, L = 64, 16, 750, 96, 64, 16000, 16000
+    feats, _ = bench.make_features(B, P, T, H, K, 1, L, dev, seed=43)
+    g = torch.Generator(device=dev)
+    g.manual_seed(44)
+    dec = 0.9990 + 0.0012 * torch.rand(B, P, T, H, generator=g, device=dev)
+    dt = torch.arange(T, device=dev, dtype=torch.float32).view(1, 1, T, 1).expand(B, P, T, 1).contiguous()
+    for i in range(P):
+        feats[f'decays_{i}'], feats[f'decay_time_{i}'] = dec[:, i], dt[:, i]
+    N = T * (sr // 250)
+    noise = 2.0 * torch.rand(B, P, N, device=dev) - 1.0
+    pg = bench.build_shipped_group(dp, 'surrogate', P, sr)
+    fast = pg(feats, return_outputs_dict=True, noise=noise)
+    stems = polyphonic.run(polyphonic.recognise(pg.dag), feats, noise=noise, need_stems=True)
+    ref = stems['out']['signal']
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((fast['signal'] - ref).abs().max()) < 2e-5 * scale
+    assert float((fast['controls']['additive']['signal'] - stems['voices']['additive'][:, P - 1]).abs().max()) < 2e-5
+    rms = float(ref.pow(2).mean().sqrt())
+    assert rms > 1e-3 and float((fast['signal'] - ref).pow(2).mean().sqrt()) < 1e-6 * max(1.0, rms)
