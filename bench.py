@@ -723,6 +723,12 @@ def main():
         extra['all_stems_call'] = {'workload': 'the headline batch through group(features, return_outputs_dict=True, '
                                                'need_stems=True): the additive and noise stems of all 16 voices',
                                    'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        # ... and what its --decompose flag needs of them: the sums over the voices (ProcessorGroup.decompose: the compacted
+        # bank and the noise kernel's voice sums form them anyway)
+        ts = event_times(lambda: pg.decompose(feats), 10, warmup=2)
+        extra['decompose_call'] = {'workload': 'the headline batch through group.decompose(features): output, dry mix, sum of '
+                                               'the additive stems, sum of the noise stems (synthesize_from_csv.py:92-120)',
+                                   'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
         # inputs that take none of the data-dependent shortcuts of the oscillator bank: no silent voice, every
         # partial below Nyquist (low notes), every frequency moving in every frame
         fd, _ = make_features(B, P, T, H, K, S, L, device, seed=31, silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)

@@ -246,7 +246,10 @@ def run(plan, inputs, noise=None, need_stems=True):
     need_stems='last' (``group(features, return_outputs_dict=True)``, what PianoModel.call does,
     piano_model.py:160): the same fast mix, plus the entries the reference's dict has -- the re-used processors'
     outputs, i.e. the LAST voice's stems and controls.
-    need_stems=True / 'all': every voice's stems ([B, P, N] under outputs['voices']), per-voice kernels."""
+    need_stems=True / 'all': every voice's stems ([B, P, N] under outputs['voices']), per-voice kernels.
+    need_stems='sums': the audio-only route plus outputs['voices_sum'] = {'additive': sum over the voices of the additive
+    stems, 'noise': sum of the noise stems} -- what synthesize_from_csv.py:99-120 (--decompose) adds up by calling the two
+    processors once per voice; the compacted bank and the noise kernel's voice sums form them anyway."""
     P = plan.n_synths
     default_shape = plan.shape == 'default_model'
     surrogate = isinstance(plan.additive, SurrogateAdditive)
@@ -463,6 +466,9 @@ def run(plan, inputs, noise=None, need_stems=True):
         else:
             _lib.check(_lib_().ddspp_mix_voices(_ptr(additive_mix), 1, _ptr(noise_sig), pz, _ptr(dry), B, N, N, zvm,
                                                 _stream()))
+            if need_stems == 'sums':
+                noise_sum = noise_sig.reshape(pz, B, N).sum(0) if zvm else noise_sig.reshape(B, pz, N).sum(1)
+                outputs['voices_sum'] = {'additive': additive_mix, 'noise': noise_sum}
         outputs[plan.add.name] = {'signal': dry, 'controls': add_controls}
         module_outputs = outputs[plan.add.name]
         if plan.reverb is not None:

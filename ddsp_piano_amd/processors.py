@@ -104,6 +104,42 @@ class ProcessorGroup:
             return dict(signal=signal, controls=outputs)
         return signal
 
+    def decompose(self, inputs, noise=None):
+        """The reference's --decompose flow (synthesize_from_csv.py:92-120) in one call: {'additive': the sum over the voices
+        of the additive synthesiser's signals, 'noise': the sum of the noise synthesiser's, 'dry': the un-reverbed mix,
+        'signal': the group's output}.  On the batched route these sums are what the compacted oscillator bank and the
+        noise kernel's voice sums form anyway (need_stems='sums'); otherwise every voice's stems are rendered and added."""
+        outputs = self.get_controls(inputs, noise=noise, need_stems='sums')
+        sums = outputs.get('voices_sum')
+        if sums is None:
+            if 'voices' in outputs:                         # batched route, per-voice rows
+                sums = {k: v.sum(dim=1) for k, v in outputs['voices'].items()}
+            else:                                           # node-by-node walk: the reference's own loop
+                procs = self.processors
+                additive, noise_p = procs[0], procs[1]
+                from .synths import FilteredNoise
+                if isinstance(additive, FilteredNoise):
+                    additive, noise_p = noise_p, additive
+                add_nodes = [n for n in self.dag if n[0] is additive]
+                noise_nodes = [n for n in self.dag if n[0] is noise_p]
+                a = z = None
+                for i, node in enumerate(add_nodes):
+                    x = additive.get_signal(**additive.get_controls(*[_nested_lookup(k, outputs) for k in node[1]]))
+                    a = x if a is None else a + x
+                for i, node in enumerate(noise_nodes):
+                    kw = {}
+                    if noise is not None:
+                        kw['noise'] = noise[i] if isinstance(noise, (list, tuple)) else (noise[:, i] if noise.dim() == 3 else noise)
+                    x = noise_p.get_signal(**noise_p.get_controls(*[_nested_lookup(k, outputs) for k in node[1]]), **kw)
+                    z = x if z is None else z + x
+                sums = {'additive': a, 'noise': z}
+        signal = self.get_signal(outputs)
+        from .effects import FeedbackDelayNetwork, FeedbackDelayNetworkApply, Reverb
+        last = self.dag[-1]                                 # a reverb as the last node: its first input is the dry mix
+        dry = _nested_lookup(last[1][0], outputs) if isinstance(last[0], (Reverb, FeedbackDelayNetwork,
+                                                                           FeedbackDelayNetworkApply)) else signal
+        return {'additive': sums['additive'], 'noise': sums['noise'], 'dry': dry, 'signal': signal}
+
     def get_controls(self, inputs, noise=None, need_stems=True):
         """Run the DAG; returns the full outputs dict (ddsp.dags.DAGLayer.run_dag).
 

@@ -139,6 +139,40 @@ def test_standalone_processors_like_synthesize_from_csv():
     assert pg.processors[0].sample_rate == 24000        # piano_model.py:70-72
 
 
+@pytest.mark.parametrize('fast', [True, False])
+def test_decompose_equals_the_reference_loop(fast):
+    """synthesize_from_csv.py:92-120 (--decompose): the un-reverbed mix and the sums over the voices of the additive and the
+    noise signals, which the reference gets by calling processors[:2] once per voice -- ProcessorGroup.decompose forms them
+    on the batched route (compacted bank, the noise kernel's voice sums) and, node by node, with the reference's loop."""
+    import ddsp_piano_amd as dp
+    rng = np.random.default_rng(21)
+    B, P, T, H, K, sr = 3, 4, 50, 128, 96, 24000
+    N = T * 96
+    dag, _ = _build(dp, P, sr)
+    pg = dp.ProcessorGroup(dag, fast_path=fast)
+    feats = {}
+    for i in range(P):
+        for k, v in synth_controls(rng, B, T, H, K=K, silent_frac=0.0, midi_lo=40, midi_hi=90).items():
+            feats[f'{k}_{i}'] = torch.as_tensor(v, device='cuda')
+    feats['reverb_ir'] = torch.as_tensor(synth_ir(rng, B, 4800), device='cuda')
+    noise = [torch.as_tensor(rng.uniform(-1, 1, [B, N]).astype(np.float32), device='cuda') for _ in range(P)]
+    d = pg.decompose(feats, noise=noise)
+    additive, noise_p = pg.processors[:2]
+    a = z = None
+    for i in range(P):                                     # the reference's loop
+        x = additive.get_signal(**additive.get_controls(*[feats[f'{k}_{i}'] for k in ('amplitudes', 'harmonic_distribution',
+                                                                                    'inharm_coef', 'f0_hz')]))
+        y = noise_p.get_signal(**noise_p.get_controls(feats[f'magnitudes_{i}']), noise=noise[i])
+        a = x if a is None else a + x
+        z = y if z is None else z + y
+    for k, ref in (('additive', a), ('noise', z), ('dry', a + z)):
+        assert d[k].shape == (B, N)
+        assert float((d[k] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), k
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    assert float((d['signal'] - full['signal']).abs().max()) < 2e-5 * max(1.0, float(full['signal'].abs().max()))
+    assert float((d['dry'] - full['controls']['add']['signal']).abs().max()) < 2e-5
+
+
 def test_long_segment_whole_file_mode():
     """synthesize_midi_file.py feeds the WHOLE file as one segment: many chunks of the
     angular cumsum (long float32 offset sums), many FIR frames, a multi-million point reverb FFT."""
