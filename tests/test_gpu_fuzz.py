@@ -98,8 +98,10 @@ def test_compacted_bank_equals_the_stems(seed, B, P, T, H, S, U, flags):
 
 @pytest.mark.parametrize('seed,B,P,T,H,K,S,U,vm', [(11, 2, 4, 140, 128, 96, 1, 96, False), (12, 3, 3, 75, 96, 64, 2, 64, True),
                                                    (13, 1, 16, 250, 128, 96, 1, 96, False), (14, 17, 16, 40, 128, 96, 1, 96, True)])
-def test_batched_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, S, U, vm, monkeypatch):
-    """The batched route (compacted bank, fused noise with voice sums, split last voice, early IR transform) against the
+def test_batched_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, S, U, vm, monkeypatch, surrogate=False):
+    """(surrogate=True, tools/fuzz_soak.py and the test below: SurrogateAdditive voices -- configs/surrogate.gin -- with random
+    decay factors, the compacted bank's decay variant against the walk.)
+    The batched route (compacted bank, fused noise with voice sums, split last voice, early IR transform) against the
     DAG walked node by node through the per-processor entry points, both call forms, on musical controls; vm: the
     per-voice keys are views of one voice-major [P, B, T, C] buffer (the Parallelizer's un-merge) instead of [B, P, T, C]."""
     import ddsp_piano_amd as dp
@@ -118,8 +120,24 @@ def test_batched_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, S, U, v
     noise = torch.as_tensor(rng.uniform(-1, 1, [B, P, N]).astype(np.float32), device='cuda')
     keys = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
                 noise_controls=['magnitudes'], reverb_controls=['reverb_ir'])
+    if surrogate:
+        assert S == 1
+        keys['additive_controls'] = ['amplitudes', 'decays', 'decay_time', 'harmonic_distribution', 'inharm_coef', 'f0_hz']
+        dec = rng.uniform(0.998, 1.0003, [*((P, B) if vm else (B, P)), T, H]).astype(np.float32)
+        dec[..., ::5] *= -1.0
+        dtm = np.broadcast_to((np.arange(T, dtype=np.float32) % int(rng.integers(3, 60)))[:, None], dec.shape[:2] + (T, 1)).copy()
+        dec_t, dtm_t = torch.as_tensor(dec, device='cuda'), torch.as_tensor(dtm, device='cuda')
+        for i in range(P):
+            feats[f'decays_{i}'] = dec_t[i] if vm else dec_t[:, i]
+            feats[f'decay_time_{i}'] = dtm_t[i] if vm else dtm_t[:, i]
 
     def group(fast):
+        if surrogate:
+            return dp.ProcessorGroup(dp.polyphonic_dag(
+                dp.SurrogateAdditive(name='additive', frame_rate=250, sample_rate=sr, inference=True,
+                                     normalize_harm_distribution=bool(seed % 3)),
+                dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'),
+                n_synths=P, **keys), fast_path=fast)
         return dp.ProcessorGroup(dp.polyphonic_dag(
             dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
             dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'),
@@ -140,9 +158,15 @@ def test_batched_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, S, U, v
     for node in ('additive', 'noise', 'add'):                 # the last voice's stems and the dry mix
         a, b = fast['controls'][node]['signal'], slow['controls'][node]['signal']
         assert (a - b).abs().max().item() < 1e-5 * max(1.0, float(b.abs().max())), node
-    for k in ('amplitudes', 'harmonic_distribution', 'harmonic_shifts', 'f0_hz'):
+    for k in ('amplitudes', 'harmonic_distribution', 'harmonic_shifts', 'f0_hz') + (('decays', 'decay_time') if surrogate else ()):
         a, b = fast['controls']['additive']['controls'][k], slow['controls']['additive']['controls'][k]
         assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-6 * max(1.0, float(b.abs().max())), k
+
+
+@pytest.mark.parametrize('seed,B,P,T,H,K,U,vm', [(31, 2, 4, 140, 96, 64, 64, False), (32, 3, 16, 75, 128, 96, 96, True),
+                                                 (33, 1, 5, 300, 48, 32, 32, False), (34, 5, 7, 60, 192, 96, 192, True)])
+def test_batched_surrogate_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, U, vm, monkeypatch):
+    test_batched_group_equals_the_node_by_node_walk(seed, B, P, T, H, K, 1, U, vm, monkeypatch, surrogate=True)
 
 
 @pytest.mark.parametrize('seed,B,P,T,H,K,S,U', [(21, 1, 6, 500, 128, 96, 1, 96), (22, 16, 16, 375, 128, 96, 1, 96),
