@@ -63,6 +63,10 @@ class StreamingSynthesizer:
     def __init__(self, additive, noise, reverb=None, n_synths=16,
                  additive_controls=('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'),
                  noise_controls=('magnitudes',), reverb_controls=('reverb_ir',)):
+        from .synths import InHarmonic
+        if not isinstance(additive, InHarmonic):
+            raise ValueError('streaming takes InHarmonic / MultiInharmonic as the additive synthesiser (a SurrogateAdditive '
+                             'group renders in one call: ProcessorGroup)')
         if not additive.inference:
             raise ValueError('streaming needs the angular-cumsum oscillator (inference=True): a plain cumsum has no '
                              'bounded state')
