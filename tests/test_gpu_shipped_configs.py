@@ -136,3 +136,78 @@ def test_surrogate_config_at_bench_size_routes_agree():
     assert float((fast['controls']['additive']['signal'] - stems['voices']['additive'][:, P - 1]).abs().max()) < 2e-5
     rms = float(ref.pow(2).mean().sqrt())
     assert rms > 1e-3 and float((fast['signal'] - ref).pow(2).mean().sqrt()) < 1e-6 * max(1.0, rms)
+
+
+BENCH_SIZE = {'maestro-v2': (128, 96, 1, 24000, 48000), 'dafx22-24kHz': (128, 96, 2, 24000, 36000),
+              'ENSTDkCl-8kHz': (48, 32, 1, 8000, 16000), 'ENSTDkCl-32kHz': (192, 128, 1, 32000, 64000),
+              'multi_instruments': (96, 64, 1, 16000, 24000), 'surrogate': (96, 64, 1, 16000, 16000)}
+
+
+@pytest.mark.parametrize('cfg', sorted(BENCH_SIZE))
+def test_shipped_config_at_bench_size_against_the_oracle(cfg):
+    """Every shipped gin file at the size bench.py times it (batch 64 x 3 s, poly 16, its own flags): the un-reverbed mix
+    and the last voice's stems of TWO segments (the one with the lowest note, one at random) against the numpy oracle with
+    the same flags -- one host thread per voice."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    import bench
+    import ddsp_piano_amd as dp
+    from util import O, rms, rms_err
+    H, K, S, sr, L = BENCH_SIZE[cfg]
+    B, P, T = 64, 16, 750
+    U = sr // 250
+    N = T * U
+    dev = torch.device('cuda', 0)
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=43)
+    if cfg == 'surrogate':
+        g = torch.Generator(device=dev)
+        g.manual_seed(44)
+        dec = 0.9990 + 0.0012 * torch.rand(B, P, T, H, generator=g, device=dev)
+        dt = torch.arange(T, device=dev, dtype=torch.float32).view(1, 1, T, 1).expand(B, P, T, 1).contiguous()
+        for i in range(P):
+            feats[f'decays_{i}'], feats[f'decay_time_{i}'] = dec[:, i], dt[:, i]
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_shipped_group(dp, cfg, P, sr)
+    out = pg(feats, return_outputs_dict=True, noise=noise)
+    f0 = torch.stack([feats[f'f0_hz_{i}'][:, 0, 0] for i in range(P)], dim=1).cpu().numpy()
+    lowest = int(np.argmin(np.where(f0 > 0, f0, np.inf).min(axis=1)))
+    segments = sorted({lowest, (lowest + 29) % B})
+    tanh = cfg in ('ENSTDkCl-8kHz', 'ENSTDkCl-32kHz', 'multi_instruments', 'surrogate')
+    scale = {'scale_fn': O.exp_tanh} if tanh else {}
+    if cfg == 'surrogate':
+        additive = O.SurrogateAdditive(name='additive', frame_rate=250, sample_rate=sr, inference=True,
+                                       normalize_harm_distribution=False, **scale)
+        akeys = ('amplitudes', 'decays', 'decay_time', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    else:
+        additive = O.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True,
+                                     **(dict(normalize_after_nyquist_cut=False) if tanh else {}), **scale)
+        akeys = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    onoise = O.FilteredNoise(name='noise', frame_rate=250, sample_rate=sr, **scale)
+    rows = torch.as_tensor(segments, device=dev)
+    fnp = {k: v[rows].cpu().numpy() for k, v in feats.items() if k != 'reverb_ir'}
+    znp = noise[rows].cpu().numpy()
+
+    def voice(task):
+        j, i = task
+        sl = slice(j, j + 1)
+        a = additive.get_signal(**additive.get_controls(*[fnp[f'{k}_{i}'][sl] for k in akeys]))
+        z = onoise.get_signal(**onoise.get_controls(fnp[f'magnitudes_{i}'][sl]), noise=znp[sl, i])
+        return a, z
+    tasks = [(j, i) for j in range(len(segments)) for i in range(P)]
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        sigs = list(ex.map(voice, tasks))
+    for j, b in enumerate(segments):
+        mix = None
+        for a, z in sigs[j * P:(j + 1) * P]:
+            mix = (z + a).astype(np.float32) if mix is None else ((mix + z).astype(np.float32) + a).astype(np.float32)
+        a_last, z_last = sigs[j * P + P - 1]
+        dry = out['controls']['add']['signal'][b:b + 1].cpu().numpy()
+        e = rms_err(dry, mix)
+        assert e < 1e-5 * max(1.0, rms(mix)), f'{cfg}: segment {b}: dry {e:.3e} vs rms {rms(mix):.3e}'
+        assert rms_err(out['controls']['additive']['signal'][b:b + 1].cpu().numpy(), a_last) < 1e-5, (cfg, b)
+        assert rms_err(out['controls']['noise']['signal'][b:b + 1].cpu().numpy(), z_last) < 1e-5, (cfg, b)
