@@ -31,9 +31,13 @@ namespace ddspp {
 constexpr int WIN_D = 32;            // designed frames per window = two MFMA row tiles
 
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-// magnitude tile [D][K] without row padding: the 8-float groups of row s are XOR-swizzled by (s / 2) % 4, so that the
-// 16 rows a matrix-core A-operand read touches fall on 8 different bank groups (2-way instead of 8-way)
-__device__ __forceinline__ int win_mswz(int s) { return ((s >> 1) & 3) << 3; }
+// magnitude tile [D][K + 4]: rows padded by four floats.  The matrix-core A-operand read is a ds_read_b64 per lane,
+// serviced in two groups of 32 lanes = 16 rows x 2 adjacent float pairs, bank = dword address mod 64: with a row stride
+// of K + 4 = 4 or 36 (mod 64) for K = 32 / 64 / 96 / 128 the sixteen rows start 4 banks apart in some order and the 64
+// dwords of a group fall on 64 different banks -- conflict free (rounds 3-4: unpadded rows with their 8-float groups
+// XOR-swizzled by (s / 2) % 4, rows s and s + 8 on the same banks: SQ_LDS_BANK_CONFLICT 16.4 M cycles per launch, 18 %
+// of the LDS cycles).  512 bytes more per workgroup: 53 664 at the headline shape, still three workgroups per CU.
+constexpr int WIN_MPAD = 4;
 
 // One lane's walk, frame by frame (g = frame offset relative to the lane's own frame, from the latest frame that
 // reaches the lane's outputs to the earliest).  The two half-waves are two adjacent output phases A and B = A + 1:
@@ -343,10 +347,11 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     // LDS: [magnitudes D x K, swizzled][padded noise of D frames][D frame images].  Nothing valid ever reads below
     // the first image's tap 0 or above the last image's last tap, so the first image starts `gshift` floats early
-    // (its lower gap overlaps the noise region) and there is no tail: 53 152 bytes at the headline shape -- three
+    // (its lower gap overlaps the noise region) and there is no tail: 53 664 bytes at the headline shape -- three
     // workgroups per CU (the allocation granule makes 53 888 bytes two).
-    float* M = lds_dyn;                                       // [D][K], 8-float groups XOR-swizzled by the row
-    float* Xs = M + D * K;                                    // padded noise of D frames
+    constexpr int MS = K + WIN_MPAD;                          // floats per row of the magnitude tile
+    float* M = lds_dyn;                                       // [D][MS]
+    float* Xs = M + D * MS;                                   // padded noise of D frames
     float* Gtop = Xs + (BPF + 1) * 4 * D;                     // first float of the image region
     float* G = Gtop - g.gshift;                               // image s, tap k: G[s gs + padl + k]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -442,7 +447,7 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                 if (i < D * PER_ROW) {
                     const float4 m = scale4_of<decltype(kind)::value>(scale, mv[u], bias);
                     const int s = i / PER_ROW, c4 = i - s * PER_ROW;
-                    *reinterpret_cast<float4*>(M + s * K + ((4 * c4) ^ win_mswz(s))) = m;
+                    *reinterpret_cast<float4*>(M + s * MS + 4 * c4) = m;
                 }
             }
         });
@@ -487,11 +492,10 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
             load_taps();
             for (int t = tg; t < D / 16; t += TW) {
                 f32x4 accE = f32x4{0.f, 0.f, 0.f, 0.f}, accO = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* arow = M + (16 * t + col) * K + 2 * kq;
-                const int sw = win_mswz(16 * t + col);
+                const float* arow = M + (16 * t + col) * MS + 2 * kq;
 #pragma unroll
                 for (int st = 0; st < KS; ++st) {
-                    const float2 am = *reinterpret_cast<const float2*>(arow + ((8 * st) ^ sw));
+                    const float2 am = *reinterpret_cast<const float2*>(arow + 8 * st);
                     accE = __builtin_amdgcn_mfma_f32_16x16x4f32(am.x, bE[st], accE, 0, 0, 0);
                     accO = __builtin_amdgcn_mfma_f32_16x16x4f32(am.y, bO[st], accO, 0, 0, 0);
                 }
@@ -626,12 +630,12 @@ struct WinDesignRide {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     float bE[KS], bO[KS];          // table fragments of this wavefront's column block
     f32x4 hE[2], hO[2];            // E / O of the two row tiles of the next unit
-    const float* mlane;            // M + col K + 2 kq (row tile 0)
-    int sw, K;                     // swizzle of the lane's row, floats per row
+    const float* mlane;            // M + col MS + 2 kq (row tile 0)
+    int K;                         // floats per row of the magnitude tile (MS)
     float2 am;                     // magnitudes of the next ride step
     __device__ __forceinline__ void reset() {
         hE[0] = hE[1] = hO[0] = hO[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        am = *reinterpret_cast<const float2*>(mlane + (0 ^ sw));
+        am = *reinterpret_cast<const float2*>(mlane);
     }
     template <int SG>
     __device__ __forceinline__ void step() {
@@ -640,7 +644,7 @@ struct WinDesignRide {
             const float2 a = am;
             if constexpr (SG + 1 < 2 * KS) {
                 constexpr int tn = (SG + 1) / KS, sn = (SG + 1) % KS;
-                am = *reinterpret_cast<const float2*>(mlane + 16 * tn * K + ((8 * sn) ^ sw));
+                am = *reinterpret_cast<const float2*>(mlane + 16 * tn * K + 8 * sn);
             }
             hE[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bE[st], hE[t], 0, 0, 0);
             hO[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bO[st], hO[t], 0, 0, 0);
@@ -672,8 +676,9 @@ noise_win_ride_body(const float* __restrict__ x, const float* __restrict__ mags,
     static_assert(U == 8 * (QB - 1), "two groups of QB - 1 output quads per frame");
     static_assert(2 * KS <= (LW + 2) / 4, "the design's steps must fit the walk's");
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    float* M = lds_dyn;                                       // [D][K], 8-float groups XOR-swizzled by the row
-    float* Xs = M + D * K;                                    // padded noise of D frames
+    constexpr int MS = K + WIN_MPAD;                          // floats per row of the magnitude tile
+    float* M = lds_dyn;                                       // [D][MS]
+    float* Xs = M + D * MS;                                   // padded noise of D frames
     float* Gtop = Xs + (BPF + 1) * 4 * D;
     float* G = Gtop - g.gshift;                               // image s, tap k: G[s gs + padl + k]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -688,9 +693,8 @@ noise_win_ride_body(const float* __restrict__ x, const float* __restrict__ mags,
         ride.bE[st] = CE[(4 * st + kq) * NJ + jc];
         ride.bO[st] = CO[(4 * st + kq) * NJ + jc];
     }
-    ride.mlane = M + col * K + 2 * kq;
-    ride.sw = win_mswz(col);
-    ride.K = K;
+    ride.mlane = M + col * MS + 2 * kq;
+    ride.K = MS;
     for (int i = threadIdx.x; i < D * g.gs - g.gshift; i += 256) Gtop[i] = 0.0f;      // the gaps stay zero for ever
 #pragma unroll
     for (int st = 0; st < KS; ++st) asm volatile("" ::"v"(ride.bE[st]), "v"(ride.bO[st]));
@@ -747,7 +751,7 @@ noise_win_ride_body(const float* __restrict__ x, const float* __restrict__ mags,
                 if (i < D * PER_ROW) {
                     const float4 m = scale4_of<decltype(kind)::value>(scale, mv[u], bias);
                     const int sr = i / PER_ROW, c4 = i - sr * PER_ROW;
-                    *reinterpret_cast<float4*>(M + sr * K + ((4 * c4) ^ win_mswz(sr))) = m;
+                    *reinterpret_cast<float4*>(M + sr * MS + 4 * c4) = m;
                 }
             }
         });
@@ -989,7 +993,7 @@ bool win_geometry(int N, int T, int Lw, int delay, WinGeom* g) {
 
 size_t win_lds_bytes(const WinGeom& g, int K_or_0) {
     size_t fl = (size_t)WIN_D * g.gs - g.gshift + (size_t)(g.bpf + 1) * 4 * WIN_D;
-    if (K_or_0 > 0) fl += (size_t)WIN_D * K_or_0;
+    if (K_or_0 > 0) fl += (size_t)WIN_D * (K_or_0 + WIN_MPAD);
     return fl * sizeof(float);
 }
 

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const int delay = (Lw - 1) / 2 - 1;
     WinGeom g;
     if (!win_tvfir_supported(N, T, Lw, delay, &g)) return 1;
-    const size_t lds = win_lds_bytes(g, 0) + (WPE >= 4 ? 0 : 12288) + pad;      // + the fused kernel's magnitude tile (not with -DWPE=4)
+    const size_t lds = win_lds_bytes(g, 0) + (WPE >= 4 ? 0 : 12800) + pad;      // + the fused kernel's magnitude tile, 32 rows of 96 + 4 floats (not with -DWPE=4)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_kernel<12, 24, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<12, 24, 0>, 256, lds);
