@@ -14,7 +14,6 @@ the current HIP stream.
 from __future__ import annotations
 
 import atexit
-import os
 import ctypes
 import functools
 import math
@@ -791,7 +790,7 @@ def surrogate_harmonic_synthesis(frequencies, amplitudes, decays=None, decay_tim
     # fused route (round 4): straight from the frame controls, the decay term inside the oscillator kernel
     # (ddspp_surrogate_harmonic_synthesis) -- no [B, N, H] envelope is formed
     if (decays is not None and decay_time is not None and amp_resample_method == 'window'
-            and os.environ.get('DDSPP_SURROGATE_MATERIALISED', '0') != '1'       # A/B switch: the three-operator route
+            and not _lib.options.surrogate_materialised                          # A/B switch: the three-operator route
             and frequencies.shape[-1] == 1 and amplitudes.shape[-1] == 1 and n_harmonics <= 512 and upsampling % 8 == 0
             and fused_synthesis_supported(t, n_samples)
             and (harmonic_shifts is None or tuple(harmonic_shifts.shape) == (b, t, n_harmonics))):

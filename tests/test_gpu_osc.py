@@ -335,9 +335,9 @@ def test_surrogate_fused_route_matches_oracle_and_the_operator_route(B, T, H, sr
                 decay_time=_dev(octl['decay_time']), harmonic_shifts=_dev(octl['harmonic_shifts']) if shifts else None,
                 harmonic_distribution=_dev(octl['harmonic_distribution']), upsampling=U, sample_rate=sr,
                 use_angular_cumsum=True)
-    monkeypatch.setenv('DDSPP_SURROGATE_MATERIALISED', '1')
+    set_option(monkeypatch, 'DDSPP_SURROGATE_MATERIALISED', 1)
     slow = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
-    monkeypatch.delenv('DDSPP_SURROGATE_MATERIALISED')
+    set_option(monkeypatch, 'DDSPP_SURROGATE_MATERIALISED')
     fast = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
     assert fast.shape == ref.shape == (B, T * U)
     assert rms_err(slow, ref) < TOL * max(1.0, rms(ref))
@@ -346,8 +346,9 @@ def test_surrogate_fused_route_matches_oracle_and_the_operator_route(B, T, H, sr
     # plain cumsum (training-time form) takes the same kernel
     args['use_angular_cumsum'] = False
     fast_p = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
-    monkeypatch.setenv('DDSPP_SURROGATE_MATERIALISED', '1')
+    set_option(monkeypatch, 'DDSPP_SURROGATE_MATERIALISED', 1)
     slow_p = core.surrogate_harmonic_synthesis(**args).cpu().numpy()
+    set_option(monkeypatch, 'DDSPP_SURROGATE_MATERIALISED')
     assert np.abs(fast_p - slow_p).max() < 5e-4 * max(1.0, np.abs(slow_p).max())
 
 
