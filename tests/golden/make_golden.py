@@ -183,6 +183,19 @@ def main():
                         noises=noises, audio=out['signal'].astype(np.float32),
                         dry=out['controls']['add']['signal'].astype(np.float32),
                         **{f'in_{k}': v for k, v in feats.items()}, **tag)
+    # ---- SurrogateAdditive (configs/surrogate.gin: exp_tanh, no normalisation): one voice, 16 kHz, decaying partials ---
+    rng = np.random.default_rng(4321)
+    T, H, sr = 60, 96, 16000
+    raw = synth_controls(rng, 1, T, H, S=1, silent_frac=0.0, midi_lo=50, midi_hi=50)
+    decays = rng.uniform(0.9985, 1.0004, [1, T, H]).astype(np.float32)
+    decay_time = (np.arange(T, dtype=np.float32) % 25)[None, :, None]
+    sur = B_.SurrogateAdditive(frame_rate=250, sample_rate=sr, inference=True, scale_fn=B_.exp_tanh,
+                               normalize_harm_distribution=False)
+    sctl = sur.get_controls(raw['amplitudes'], decays, decay_time, raw['harmonic_distribution'], raw['inharm_coef'], raw['f0_hz'])
+    saudio = sur.get_signal(**sctl)
+    np.savez_compressed(os.path.join(HERE, 'c3_surrogate.npz'), sample_rate=sr, frame_rate=250, raw_decays=decays,
+                        raw_decay_time=decay_time, **{f'raw_{k}': v for k, v in raw.items()},
+                        **{f'ctl_{k}': np.asarray(v, np.float32) for k, v in sctl.items()}, audio=saudio.astype(np.float32), **tag)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

@@ -102,6 +102,7 @@ class TFBackend:
         self.inharm = importlib.import_module('ddsp_piano.modules.inharm_synth')
         self.noise = importlib.import_module('ddsp_piano.modules.filtered_noise_synth')
         self.dag = importlib.import_module('ddsp_piano.modules.polyphonic_dag')
+        self.surrogate = importlib.import_module('ddsp_piano.modules.surrogate_synth')
         self.versions = {'tensorflow': tf.__version__, 'ddsp': getattr(ddsp, '__version__', 'unknown')}
 
     # the constructors make_golden.py calls, keyword for keyword those of the gin files (maestro-v2.gin:155-164)
@@ -110,6 +111,11 @@ class TFBackend:
 
     def FilteredNoise(self, **kw):
         return _Proc(self.noise.DynamicSizeFilteredNoise(**kw), self.tf)
+
+    def SurrogateAdditive(self, **kw):                 # configs/surrogate.gin:121-127
+        if getattr(kw.get('scale_fn'), '__func__', None) is TFBackend.exp_tanh:      # make_golden passes B_.exp_tanh: the reference's own
+            kw['scale_fn'] = self.inharm.exp_tanh
+        return _Proc(self.surrogate.SurrogateAdditive(**kw), self.tf)
 
     def Reverb(self, **kw):
         kw.setdefault('trainable', False)

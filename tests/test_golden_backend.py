@@ -14,7 +14,7 @@ import pytest
 from util import O, rms, rms_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-SYNTH_FIXTURES = ('c1_mono', 'c2_small', 'recalled_details')
+SYNTH_FIXTURES = ('c1_mono', 'c2_small', 'c3_surrogate', 'recalled_details')
 KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
             noise_controls=['magnitudes'], reverb_controls=['reverb_ir'])
 
@@ -52,6 +52,17 @@ def test_oracle_reproduces_config1():
         np.testing.assert_allclose(ctl[k], g[f'ctl_{k}'], rtol=2e-5, atol=1e-8)
     audio = syn.get_signal(**ctl)
     assert rms_err(audio, g['audio']) < _tol(), 'oracle vs golden C1: see test_recalled_details_match for the culprit'
+
+
+def test_oracle_reproduces_the_surrogate_voice():
+    g = _load('c3_surrogate')
+    syn = O.SurrogateAdditive(frame_rate=int(g['frame_rate']), sample_rate=int(g['sample_rate']), inference=True,
+                              scale_fn=O.exp_tanh, normalize_harm_distribution=False)
+    ctl = syn.get_controls(g['raw_amplitudes'], g['raw_decays'], g['raw_decay_time'], g['raw_harmonic_distribution'],
+                           g['raw_inharm_coef'], g['raw_f0_hz'])
+    for k in ('amplitudes', 'decays', 'harmonic_distribution', 'harmonic_shifts'):
+        np.testing.assert_allclose(ctl[k], g[f'ctl_{k}'], rtol=2e-5, atol=1e-8)
+    assert rms_err(syn.get_signal(**ctl), g['audio']) < _tol()
 
 
 def test_oracle_reproduces_small_config2():

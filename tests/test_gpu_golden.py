@@ -38,6 +38,23 @@ def test_config1_mono_note():
     assert rms_err(audio2, g['audio']) < TOL
 
 
+def test_surrogate_voice():
+    """configs/surrogate.gin's synthesiser: get_controls (two kernels) and get_signal (the fused decay kernel) against the
+    golden voice; with TF-made goldens this pins SURVEY.md row f-3 too."""
+    import ddsp_piano_amd as dp
+    g = np.load(os.path.join(GOLD, 'c3_surrogate.npz'))
+    syn = dp.SurrogateAdditive(frame_rate=int(g['frame_rate']), sample_rate=int(g['sample_rate']), inference=True,
+                               scale_fn=dp.exp_tanh, normalize_harm_distribution=False)
+    ctl = syn.get_controls(_dev(g['raw_amplitudes']), _dev(g['raw_decays']), _dev(g['raw_decay_time']),
+                           _dev(g['raw_harmonic_distribution']), _dev(g['raw_inharm_coef']), _dev(g['raw_f0_hz']))
+    for k in ('harmonic_shifts', 'decays'):
+        assert np.array_equal(ctl[k].cpu().numpy(), g[f'ctl_{k}']), k
+    for k in ('amplitudes', 'harmonic_distribution'):
+        np.testing.assert_allclose(ctl[k].cpu().numpy(), g[f'ctl_{k}'], rtol=2e-5, atol=1e-9)
+    audio = syn.get_signal(**ctl).cpu().numpy()
+    assert audio.shape == g['audio'].shape and rms_err(audio, g['audio']) < TOL
+
+
 def test_config2_small_full_chain_with_real_dafx22_ir():
     import ddsp_piano_amd as dp
     g = np.load(os.path.join(GOLD, 'c2_small.npz'))
