@@ -196,6 +196,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'c3_surrogate.npz'), sample_rate=sr, frame_rate=250, raw_decays=decays,
                         raw_decay_time=decay_time, **{f'raw_{k}': v for k, v in raw.items()},
                         **{f'ctl_{k}': np.asarray(v, np.float32) for k, v in sctl.items()}, audio=saudio.astype(np.float32), **tag)
+    # ---- FeedbackDelayNetwork.get_ir: two rooms drawn like sub_modules.py:386-418, one damped, one lively --
+    rng = np.random.default_rng(777)
+    D, E, sr = 8, 200, 16000
+    rooms = dict(input_gain=rng.normal(0.25, 0.1, [2, D]), output_gain=rng.normal(0.25, 0.1, [2, D]),
+                 gain_allpass=rng.normal(0.25, 0.1, [2, D, 4]), delays_allpass=rng.normal(400.0, 60.0, [2, D, 4]),
+                 time_rev_0_sec=np.asarray([0.4, 1.8]), alpha_tone=1.0 / (1.0 + np.exp(-rng.normal(0.0, 0.1, [2]))),
+                 early_ir=rng.normal(0.0, 0.1, [2, E]))
+    rooms = {k: np.asarray(v, np.float32) for k, v in rooms.items()}
+    irs = np.stack([np.asarray(B_.fdn_get_ir(*[rooms[k][i] for k in ('input_gain', 'output_gain', 'gain_allpass',
+                                                                       'delays_allpass', 'time_rev_0_sec', 'alpha_tone',
+                                                                       'early_ir')], sampling_rate=float(sr)), np.float32)
+                    for i in range(2)])
+    np.savez_compressed(os.path.join(HERE, 'c4_fdn_ir.npz'), sample_rate=sr, ir=irs, **{f'p_{k}': v for k, v in rooms.items()}, **tag)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

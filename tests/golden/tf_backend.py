@@ -128,6 +128,18 @@ class TFBackend:
     def ProcessorGroup(self, dag):
         return _Group(dag, self.tf, self.ddsp)
 
+    def fdn_get_ir(self, input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir,
+                   sampling_rate=16000.0):
+        """FeedbackDelayNetwork(trainable=False).get_ir -- fdn_reverb.py:339-360 with the layer's own delay values and mixing
+        matrix (build(), :92-125): one network, the parameters as arrays (input / output gains [D], all-pass gains and delays
+        [D, 4], T60 and tone scalars, early reflections [E])."""
+        fdn = importlib.import_module('ddsp_piano.modules.fdn_reverb')
+        layer = fdn.FeedbackDelayNetwork(trainable=False, sampling_rate=sampling_rate)
+        layer.build(None)
+        t = lambda x: self.tf.convert_to_tensor(np.asarray(x, np.float32))       # noqa: E731
+        return _to_np(layer.get_ir(t(input_gain), t(output_gain), t(gain_allpass), t(delays_allpass), t(time_rev_0_sec),
+                                   t(alpha_tone), t(early_ir)))
+
     # single operators, for the per-detail report (which recollection does the real library match?)
     def frequency_filter(self, audio, magnitudes, window_size):
         t = self.tf.convert_to_tensor

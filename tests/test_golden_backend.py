@@ -14,7 +14,7 @@ import pytest
 from util import O, rms, rms_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-SYNTH_FIXTURES = ('c1_mono', 'c2_small', 'c3_surrogate', 'recalled_details')
+SYNTH_FIXTURES = ('c1_mono', 'c2_small', 'c3_surrogate', 'c4_fdn_ir', 'recalled_details')
 KEYS = dict(additive_controls=['amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz'],
             noise_controls=['magnitudes'], reverb_controls=['reverb_ir'])
 
@@ -63,6 +63,21 @@ def test_oracle_reproduces_the_surrogate_voice():
     for k in ('amplitudes', 'decays', 'harmonic_distribution', 'harmonic_shifts'):
         np.testing.assert_allclose(ctl[k], g[f'ctl_{k}'], rtol=2e-5, atol=1e-8)
     assert rms_err(syn.get_signal(**ctl), g['audio']) < _tol()
+
+
+def test_oracle_reproduces_the_fdn_impulse_responses():
+    """FeedbackDelayNetwork.get_ir for a damped and a lively room.  Restatement goldens are the oracle's
+    complex64-faithful mode; TF-made ones measure how far TensorFlow's complex64 inverse is from it (the lively room is
+    ill-conditioned near its resonances: the float64 solve is what both approximate)."""
+    g = _load('c4_fdn_ir')
+    for i in range(2):
+        args = [g[f'p_{k}'][i] for k in ('input_gain', 'output_gain', 'gain_allpass', 'delays_allpass', 'time_rev_0_sec',
+                                         'alpha_tone', 'early_ir')]
+        got = O.fdn_get_ir(*args, sampling_rate=float(g['sample_rate']))
+        exact = O.fdn_get_ir(*args, sampling_rate=float(g['sample_rate']), exact_solve=True)
+        tol = 1e-6 if _tol() < 1e-5 else 5e-3
+        assert rms_err(got, g['ir'][i]) < tol * rms(g['ir'][i]), i
+        assert rms_err(exact, g['ir'][i]) < 5e-3 * rms(g['ir'][i]), i
 
 
 def test_oracle_reproduces_small_config2():
