@@ -63,6 +63,29 @@ def test_argument_errors_do_not_reach_the_gpu(lib):
         raise AssertionError('EINVAL must map to ValueError')
 
 
+def test_argument_errors_of_the_surrogate_entry_points(lib):
+    """SurrogateAdditive's entry points (late round 4) refuse bad arguments before any launch."""
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(256)
+    rc = lib.ddspp_surrogate_harmonic_synthesis(one, one, one, one, null, null, one, one, one, 1, 10, 8, 96, 24000.0, 1, 0,
+                                                null, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'decay' in lib.ddspp_last_error()
+    rc = lib.ddspp_surrogate_harmonic_synthesis(one, one, one, one, one, one, one, one, one, 1, 10, 8, 100, 24000.0, 1, 0,
+                                                null, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'upsampling' in lib.ddspp_last_error()
+    rc = lib.ddspp_surrogate_decays(null, one, one, one, 1, 10, 8, 24000.0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'null' in lib.ddspp_last_error()
+    rc = lib.ddspp_surrogate_decays(one, one, one, one, 1, 0, 8, 24000.0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'bad dims' in lib.ddspp_last_error()
+    rc = lib.ddspp_polyphonic_surrogate_additive(one, one, one, null, one, null, null, null, one, one, one, null, 1, 2, 10, 8,
+                                                 96, 24000.0, 0, 0, one, 1 << 20, null)
+    assert rc == _lib.DDSPP_EINVAL and b'decay' in lib.ddspp_last_error()
+    # normalisation mode of ddspp_inharmonic_controls: 0 before the cut, 1 after it, 2 never -- nothing else
+    rc = lib.ddspp_inharmonic_controls(one, one, one, one, one, one, one, None, 1, 10, 8, 1, 24000.0, 20.0, 1, 10.0, 2.0, 1e-7,
+                                       1.0, 3, 1, null)
+    assert rc == _lib.DDSPP_EINVAL and b'normalize_after_nyquist_cut' in lib.ddspp_last_error()
+
+
 def test_argument_errors_of_the_fused_and_split_entry_points(lib):
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(256)
