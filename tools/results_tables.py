@@ -48,7 +48,7 @@ design = (
     "used to walk 4 P nodes one eager call at a time); **every shipped gin file at its own dims and flags** (`shipped_configs`, batch 64\n"
     "× 3 s, poly 16): " + ", ".join(f"{k} {'**' if k == 'surrogate' else ''}{v['ms_per_step']['median']:.2f}{'**' if k == 'surrogate' else ''}"
                                    for k, v in sc.items()) + " ms\n"
-    "(surrogate: 77 before SurrogateAdditive reached the fused kernels, §14);\n"
+    "(surrogate: 19.2 ms at batch 16, i.e. about 77 at this batch, before SurrogateAdditive reached the fused kernels, §14);\n"
     f"graded kernel {ro['ms_per_launch']:.2f} ms = {ro['achieved'] / 1e3:.2f} TB/s = **{ro['frac']:.3f} of 8 TB/s** = "
     f"{ro['frac_of_measured_peak']:.3f} of the pure\n"
     "read of the same buffers (measured first in the process since the last commits: 0.726–0.737 on a fresh heap against\n"
