@@ -146,7 +146,7 @@ BENCH_SIZE = {'maestro-v2': (128, 96, 1, 24000, 48000), 'dafx22-24kHz': (128, 96
 @pytest.mark.parametrize('cfg', sorted(BENCH_SIZE))
 def test_shipped_config_at_bench_size_against_the_oracle(cfg):
     """Every shipped gin file at the size bench.py times it (batch 64 x 3 s, poly 16, its own flags): the un-reverbed mix
-    and the last voice's stems of TWO segments (the one with the lowest note, one at random) against the numpy oracle with
+    and the last voice's stems of FOUR segments (the lowest note, the highest, a silent voice, one at random) against the numpy oracle with
     the same flags -- one host thread per voice."""
     import os
     from concurrent.futures import ThreadPoolExecutor
@@ -174,9 +174,9 @@ def test_shipped_config_at_bench_size_against_the_oracle(cfg):
     noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
     pg = bench.build_shipped_group(dp, cfg, P, sr)
     out = pg(feats, return_outputs_dict=True, noise=noise)
-    f0 = torch.stack([feats[f'f0_hz_{i}'][:, 0, 0] for i in range(P)], dim=1).cpu().numpy()
-    lowest = int(np.argmin(np.where(f0 > 0, f0, np.inf).min(axis=1)))
-    segments = sorted({lowest, (lowest + 29) % B})
+    from test_gpu_full_size import _pick_segments
+    segments, info = _pick_segments(feats, P, 4, 5)      # the lowest note, the highest, a silent voice, one at random
+    assert info['silent_rows'] > 0
     tanh = cfg in ('ENSTDkCl-8kHz', 'ENSTDkCl-32kHz', 'multi_instruments', 'surrogate')
     scale = {'scale_fn': O.exp_tanh} if tanh else {}
     if cfg == 'surrogate':
