@@ -345,7 +345,7 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
     constexpr int TW = 4 / JT;                                   // wavefront groups that share the tiles of a window
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    // LDS: [magnitudes D x K, swizzled][padded noise of D frames][D frame images].  Nothing valid ever reads below
+    // LDS: [magnitudes D x (K + 4): padded rows][padded noise of D frames][D frame images].  Nothing valid ever reads below
     // the first image's tap 0 or above the last image's last tap, so the first image starts `gshift` floats early
     // (its lower gap overlaps the noise region) and there is no tail: 53 664 bytes at the headline shape -- three
     // workgroups per CU (the allocation granule makes 53 888 bytes two).
