@@ -31,7 +31,7 @@ B, N = 64, 72000
 design = (
     f"**{d['ms_per_step']:.3f} ms per step** = {d['value'] / 1e9:.2f}e9 samples/s = {d['rtf'] / 1e3:.1f}k × real time (`pipelined` "
     f"{d['pipelined']['ms_per_step']:.2f} ms; earlier trees of the round on other boxes:\n"
-    "1.624, 1.629, 1.657; mid-round, before the lean get_controls kernel, the trimmed walk, the reverb's prefetches, the hoisted scale_fn\n"
+    "1.624, 1.626, 1.629, 1.657; mid-round, before the lean get_controls kernel, the trimmed walk, the reverb's prefetches, the hoisted scale_fn\n"
     "dispatch and the bank's per-path block loops: 1.850);\n"
     f"audio only {ms('audio_only_call'):.3f} ms; the `--decompose` sums (`group.decompose`) {ms('decompose_call'):.3f} ms; every voice's stems "
     f"(`need_stems=True`: per-voice rows, nothing compacted) {ms('all_stems_call'):.2f} ms; every f0 moving\n"
@@ -77,7 +77,7 @@ def row(label, form, t_ms, samples, note, bold=False):
 c5, dx = d['c5_per_gpu_share'], d['dafx22_dims']
 rows = [
     row('C3 B=64 (SURVEY §8d inputs)', 'outputs dict (headline, synchronised median)', d['ms_per_step'], B * N,
-        f"`pipelined`: {d['pipelined']['ms_per_step']:.2f} ms; earlier trees of the round on other boxes 1.624, 1.629, 1.657; mid-round 1.850; "
+        f"`pipelined`: {d['pipelined']['ms_per_step']:.2f} ms; earlier trees of the round on other boxes 1.624, 1.626, 1.629, 1.657; mid-round 1.850; "
         "round 3 on its (fast) box: 1.825", True),
     row('C3 B=64', 'audio only', ms('audio_only_call'), B * N, ''),
     row('C3 B=64', '`group.decompose(features)`: output, dry mix, the two sums over the voices', ms('decompose_call'), B * N,
