@@ -173,6 +173,36 @@ def test_decompose_equals_the_reference_loop(fast):
     assert float((d['dry'] - full['controls']['add']['signal']).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize('shape', ['default_model', 'surrogate'])
+def test_decompose_on_the_other_node_lists(shape):
+    """ProcessorGroup.decompose on default_model.py's node list (noise node first, explicit Add nodes) and on a
+    SurrogateAdditive group: the sums over the voices against the stems of the every-stem route."""
+    import bench
+    import ddsp_piano_amd as dp
+    dev = torch.device('cuda', 0)
+    B, P, T, H, K, sr = 3, 5, 60, 96, 64, 16000
+    N = T * 64
+    feats, _ = bench.make_features(B, P, T, H, K, 1, 2400, dev, seed=77, silent_frac=0.2)
+    if shape == 'surrogate':
+        g = torch.Generator(device=dev)
+        g.manual_seed(78)
+        for i in range(P):
+            feats[f'decays_{i}'] = 0.9985 + 0.0015 * torch.rand(B, T, H, generator=g, device=dev)
+            feats[f'decay_time_{i}'] = (torch.arange(T, device=dev, dtype=torch.float32) % 17).view(1, T, 1).expand(B, T, 1).contiguous()
+        pg = bench.build_shipped_group(dp, 'surrogate', P, sr)
+    else:
+        pg = bench.build_default_model_group(dp, P, sr)
+    noise = 2.0 * torch.rand(B, P, N, device=dev) - 1.0
+    d = pg.decompose(feats, noise=noise)
+    stems = pg(feats, return_outputs_dict=True, need_stems=True, noise=noise)['controls']['voices']
+    for k in ('additive', 'noise'):
+        ref = stems[k].sum(dim=1)
+        assert d[k].shape == (B, N) and float((d[k] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), k
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    assert float((d['signal'] - full['signal']).abs().max()) < 2e-5 * max(1.0, float(full['signal'].abs().max()))
+    assert float((d['dry'] - (d['additive'] + d['noise'])).abs().max()) < 2e-5 * max(1.0, float(d['dry'].abs().max()))
+
+
 def test_long_segment_whole_file_mode():
     """synthesize_midi_file.py feeds the WHOLE file as one segment: many chunks of the
     angular cumsum (long float32 offset sums), many FIR frames, a multi-million point reverb FFT."""
