@@ -253,6 +253,19 @@ class Options:
         self.surrogate_materialised = env.get('DDSPP_SURROGATE_MATERIALISED') == '1'   # SurrogateAdditive: the three-operator route (A/B)
         if _library and _lib is not None:
             _lib.ddspp_reload_options()
+            for name, value in _persistent_options.items():         # settings that are not tuning (core.set_recalled)
+                _lib.ddspp_set_option(name.encode(), int(value))
+
+
+_persistent_options = {}
+
+
+def set_option(name, value, persistent=False):
+    """ddspp_set_option; persistent=True: re-applied after every Options.reload() (which makes the library forget its
+    cache): the recalled-detail switches (core.set_recalled) are settings, not A/B variables."""
+    if persistent:
+        _persistent_options[name] = int(value)
+    check(load().ddspp_set_option(name.encode(), int(value)))
 
 
 options = Options()

@@ -37,6 +37,9 @@ _TWO_PI_F32 = F32(2.0 * np.pi)
 #   resize       core.resample(method='linear'): 'legacy' (TF1 bilinear, pos = n * T/N) | 'half_pixel'.
 #                Host tables; the fused oscillator path needs 'legacy' (else the three-operator route runs).
 #   window_crop  apply_window_to_impulse_response, window_size < ir_size: 'ddsp370' | 'centred'.  Host matrix.
+#   angular_offsets  core.angular_cumsum's running sum of chunk end phases: 'wrapped' (`tf.cumsum(offsets, axis=1) %
+#                (2 pi)`) | 'plain' (the sum is added to the chunk as it is).  Library option
+#                DDSPP_ANGULAR_OFFSETS_PLAIN (ddspp_set_option; every oscillator kernel reads it at launch, round 5).
 # One more switch of the same kind is not about ddsp but about TensorFlow's arithmetic:
 #   fdn_solve    FeedbackDelayNetwork.get_late_ir's per-bin 8 x 8 system: 'float64' (solved in double: the value the
 #                reference's recipe approximates) | 'complex64' (tf.linalg.inv + matmuls in complex64 as
@@ -44,9 +47,11 @@ _TWO_PI_F32 = F32(2.0 * np.pi)
 # The other three recalled items are ordinary arguments here (exp_sigmoid's exponent / max_value / threshold,
 # FilteredNoise(initial_bias=)) or oracle-only (the inclusive scan of angular_cumsum is what the kernels implement).
 # ----------------------------------------------------------------------------------------------------
-RECALLED = {'auto_delay': 'ddsp370', 'resize': 'legacy', 'window_crop': 'ddsp370', 'fdn_solve': 'float64'}
+RECALLED = {'auto_delay': 'ddsp370', 'resize': 'legacy', 'window_crop': 'ddsp370', 'fdn_solve': 'float64',
+            'angular_offsets': 'wrapped'}
 _RECALLED_CHOICES = {'auto_delay': ('ddsp370', 'half'), 'resize': ('legacy', 'half_pixel'),
-                     'window_crop': ('ddsp370', 'centred'), 'fdn_solve': ('float64', 'complex64')}
+                     'window_crop': ('ddsp370', 'centred'), 'fdn_solve': ('float64', 'complex64'),
+                     'angular_offsets': ('wrapped', 'plain')}
 
 
 def set_recalled(**rules):
@@ -58,6 +63,8 @@ def set_recalled(**rules):
             raise ValueError(f'{k} must be one of {_RECALLED_CHOICES[k]}, got {v!r}')
     previous = dict(RECALLED)
     RECALLED.update(rules)
+    if 'angular_offsets' in rules:
+        _lib.set_option('DDSPP_ANGULAR_OFFSETS_PLAIN', 1 if rules['angular_offsets'] == 'plain' else 0, persistent=True)
     return previous
 
 

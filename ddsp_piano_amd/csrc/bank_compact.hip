@@ -97,7 +97,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             asum[j] = p.astart[((size_t)lrow[j] * p.spans + span) * p.VP + vidx[j]];
-            off[j] = mod_2pi(asum[j]);
+            off[j] = chunk_offset(asum[j], p.off_plain);
         }
     }
 
@@ -333,7 +333,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
             for (int j = 0; j < VPL; ++j) {
                 const float e = mod_2pi(ph[j]);      // phase[:, :, -1] % 2pi
                 asum[j] = asum[j] + e;               // cumsum over chunks (float32, sequential)
-                off[j] = mod_2pi(asum[j]);           // % 2pi
+                off[j] = chunk_offset(asum[j], p.off_plain);           // % 2pi
                 ph[j] = 0.0f;
             }
         }

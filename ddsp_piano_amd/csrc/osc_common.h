@@ -30,6 +30,11 @@ struct OscParams {
     int spans, cps, nchunks, npre;
     float sr, rsr, nyq;
     int fastdiv;                       // sample rate is in the exhaustively checked list
+    // ddsp.core.angular_cumsum adds the running sum A of the chunks' end phases to every chunk.  Recalled detail
+    // (`angular_offsets`): 0 = `offsets = tf.cumsum(offsets, axis=1) % (2 pi)` (wrapped, the default),
+    // 1 = the sum is added as it is (DDSPP_ANGULAR_OFFSETS_PLAIN=1 / ddspp_set_option).  A itself is the same float32
+    // running sum either way.
+    int off_plain;
     // compacted polyphonic mode (osc_kernel<1, true, MODE_MAIN, true, true>): R = segments, each with
     // P voices; only oscillators with a non-zero amplitude somewhere in the span are given a lane
     const int* __restrict__ nk;        // [B, spans, P] audible harmonics per voice and span
@@ -76,6 +81,12 @@ __device__ __forceinline__ float shift_from_inharm(float inharm_raw, float m) {
     g = g * inharm + 1.0f;                         //                                        :38
     g = sqrtf(g);                                  //                                        :39
     return g - 1.0f;                               //                                        :44
+}
+
+// the chunk offset from the running sum of chunk end phases (see OscParams::off_plain)
+__device__ __forceinline__ float chunk_offset(float asum, int off_plain) {
+    const float w = mod_2pi(asum);
+    return off_plain ? asum : w;
 }
 
 template <bool FAST>

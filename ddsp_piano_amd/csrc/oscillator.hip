@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             asum[j] = p.astart[((size_t)row * p.spans + span) * p.VP + vidx[j]];
-            off[j] = mod_2pi(asum[j]);
+            off[j] = chunk_offset(asum[j], p.off_plain);
         }
     }
 
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
                     for (int j = 0; j < VPL; ++j) {
                         const float e = mod_2pi(ph[j]);      // phase[:, :, -1] % 2pi
                         asum[j] = asum[j] + e;               // cumsum over chunks (float32, sequential)
-                        off[j] = mod_2pi(asum[j]);           // % 2pi
+                        off[j] = chunk_offset(asum[j], p.off_plain);           // % 2pi
                         ph[j] = 0.0f;
                     }
                 }
@@ -1556,6 +1556,7 @@ int ddspp_cos_oscillator_bank(const float* frequency_envelopes, const float* amp
     p.spans = pl.spans; p.cps = pl.cps; p.nchunks = pl.nchunks; p.npre = pl.npre;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.off_plain = env_int("DDSPP_ANGULAR_OFFSETS_PLAIN", 0) ? 1 : 0;
     int rc = dispatch_vpl<false>(pl.vpl, p, use_angular_cumsum != 0, sum_sinusoids != 0, stream);
     DDSPP_REQUIRE(rc == DDSPP_OK, "cos_oscillator_bank: dispatch failed");
     DDSPP_LAUNCH_CHECK();
@@ -1598,6 +1599,7 @@ static int harmonic_synthesis_impl(const float* f0_hz, const float* amplitudes,
     p.spans = pl.spans; p.cps = pl.cps; p.nchunks = pl.nchunks; p.npre = pl.npre;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.off_plain = env_int("DDSPP_ANGULAR_OFFSETS_PLAIN", 0) ? 1 : 0;
     p.decays = decays; p.decay_time = decay_time;
     int rc = decays ? dispatch_vpl<true, true>(pl.vpl, p, use_angular_cumsum != 0, true, stream)
                     : dispatch_vpl<true>(pl.vpl, p, use_angular_cumsum != 0, true, stream);
@@ -1703,6 +1705,7 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     p.spans = sp; p.cps = cps; p.nchunks = nchunks; p.npre = sp > 1 ? (sp - 1) * cps : 0;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.off_plain = env_int("DDSPP_ANGULAR_OFFSETS_PLAIN", 0) ? 1 : 0;
     p.astart = astart;
 
     // 1. span start offsets for every (row, oscillator) over rows = B * P
@@ -1805,6 +1808,7 @@ int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shift
     p.spans = n_chunks + 1; p.cps = 1; p.nchunks = n_chunks + 1; p.npre = n_chunks;
     p.sr = sample_rate; p.rsr = 1.0f / sample_rate; p.nyq = sample_rate / 2.0f;
     p.fastdiv = sample_rate_is_checked(sample_rate) && !env_int("DDSPP_NO_FASTDIV", 0);
+    p.off_plain = env_int("DDSPP_ANGULAR_OFFSETS_PLAIN", 0) ? 1 : 0;
     p.astart = astart;
     span_starts(p, R, V, vpl_pre, astart, ework, stream);
     DDSPP_LAUNCH_CHECK();

@@ -94,10 +94,22 @@ class ProcessorGroup:
         """Unique processors in first-seen DAG order (synthesize_from_csv.py:99 takes [:2])."""
         return list(self._processors)
 
+    def _batched_plan(self):
+        if self.fast_path and self._plan is None:
+            from . import polyphonic
+            self._plan = polyphonic.recognise(self.dag) or False
+        return self._plan if self.fast_path else False
+
     def __call__(self, inputs, return_outputs_dict=False, **kwargs):
-        # audio only: the batched route skips the voice stems; outputs dict: it adds what the reference's dict holds
-        # (the last voice's stems, polyphonic_dag.py re-uses the processors); need_stems=True: every voice's stems
-        kwargs.setdefault('need_stems', 'last' if return_outputs_dict else False)
+        # audio only: the batched route skips the voice stems; outputs dict: it adds what the reference's dict holds.  For
+        # polyphonic_dag's node list that is the LAST voice's stems (polyphonic_dag.py re-uses three processor objects, so
+        # every earlier voice is overwritten): need_stems='last'.  default_model.py:44-80 names every Add node (`add_i`,
+        # `sub_add_i`), so the reference's dictionary holds every running sum: the complete dictionary needs every voice's
+        # stems (need_stems=True); the reduced one (last pair + dry mix only) is an explicit opt-in, need_stems='last'.
+        if 'need_stems' not in kwargs:
+            plan = self._batched_plan()
+            complete = bool(plan) and plan.shape == 'default_model'
+            kwargs['need_stems'] = (True if complete else 'last') if return_outputs_dict else False
         outputs = self.get_controls(inputs, **kwargs)
         signal = self.get_signal(outputs)
         if return_outputs_dict:
@@ -115,11 +127,17 @@ class ProcessorGroup:
             if 'voices' in outputs:                         # batched route, per-voice rows
                 sums = {k: v.sum(dim=1) for k, v in outputs['voices'].items()}
             else:                                           # node-by-node walk: the reference's own loop
-                procs = self.processors
-                additive, noise_p = procs[0], procs[1]
-                from .synths import FilteredNoise
-                if isinstance(additive, FilteredNoise):
-                    additive, noise_p = noise_p, additive
+                # (synthesize_from_csv.py:99-120 re-runs processors[:2] once per voice, so -- as there -- the noise stems
+                # are FRESH draws unless `noise` is given: 'noise' + 'additive' then differs from 'dry' by the draw.  The
+                # batched route's sums are the very stems inside 'dry'.)
+                from .synths import FilteredNoise, InHarmonic, SurrogateAdditive
+                adds_ = [q for q in self.processors if isinstance(q, (InHarmonic, SurrogateAdditive))]
+                noises_ = [q for q in self.processors if isinstance(q, FilteredNoise)]
+                if len(adds_) != 1 or len(noises_) != 1:
+                    raise TypeError('decompose() needs a polyphonic group: exactly one additive synthesiser (InHarmonic / '
+                                    'MultiInharmonic / SurrogateAdditive) and one FilteredNoise among its processors, found '
+                                    f'{[type(q).__name__ for q in self.processors]}')
+                additive, noise_p = adds_[0], noises_[0]
                 add_nodes = [n for n in self.dag if n[0] is additive]
                 noise_nodes = [n for n in self.dag if n[0] is noise_p]
                 a = z = None
@@ -147,14 +165,12 @@ class ProcessorGroup:
         sequence of P tensors [B, N], voice i = the i-th FilteredNoise node of the DAG (the reference draws them
         unseeded, filtered_noise_synth.py:39-40; parity tests and reproducible renders pass them in).
         need_stems only concerns the batched polyphonic route (polyphonic.run)."""
-        if self.fast_path:
+        plan = self._batched_plan()
+        if plan:
             from . import polyphonic
-            if self._plan is None:
-                self._plan = polyphonic.recognise(self.dag) or False
-            if self._plan:
-                outputs = polyphonic.run(self._plan, inputs, noise=noise, need_stems=need_stems)
-                if outputs is not None:
-                    return outputs
+            outputs = polyphonic.run(plan, inputs, noise=noise, need_stems=need_stems)
+            if outputs is not None:
+                return outputs
         return self._run_dag(inputs, noise=noise)
 
     def _run_dag(self, inputs, noise=None):

@@ -37,7 +37,7 @@ F32 = np.float32
 TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2.0 * pi`
 
 # ----------------------------------------------------------------------------------------------
-# The six details of ddsp 3.7.0 that are RECALLED, not read (SURVEY.md 8(c) "VERIFY" list).  Each is ONE
+# The seven details of ddsp 3.7.0 that are RECALLED, not read (SURVEY.md 8(c) "VERIFY" list).  Each is ONE
 # switchable entry here; every function below reads it at call time.  The defaults are the builder's
 # recollection of ddsp 3.7.0; the alternatives are what a different recollection would give.  A host with
 # TensorFlow + ddsp settles them: tests/golden/make_golden.py (DDSP_GOLDEN_BACKEND=tf) regenerates the
@@ -53,6 +53,10 @@ TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2
 #   angular_cumsum  core.angular_cumsum:
 #                     'ddsp370'    inclusive cumsum in the chunk, chunk offsets shifted right by one chunk
 #                     'exclusive'  exclusive cumsum in the chunk (first sample has phase 0)
+#   angular_offsets core.angular_cumsum, the running sum of the chunks' end phases that is added to every chunk:
+#                     'wrapped'  offsets = tf.cumsum(offsets, axis=1) % (2 pi)   
+#                     'plain'    offsets = tf.cumsum(offsets, axis=1)            (the sum grows by up to 2 pi per chunk;
+#                                `phase + offsets` is then rounded at the magnitude of the sum: ulp(2 pi n_chunks))
 #   exp_sigmoid     defaults (exponent, max_value, threshold) of core.exp_sigmoid
 #   initial_bias    default of synths.FilteredNoise(initial_bias=)
 # ----------------------------------------------------------------------------------------------
@@ -61,6 +65,7 @@ RECALLED_DEFAULTS = {
     'window_crop': 'ddsp370',
     'resize': 'legacy',
     'angular_cumsum': 'ddsp370',
+    'angular_offsets': 'wrapped',
     'exp_sigmoid': (10.0, 2.0, 1e-7),
     'initial_bias': -5.0,
 }
@@ -69,6 +74,7 @@ RECALLED_CHOICES = {
     'window_crop': ('ddsp370', 'centred'),
     'resize': ('legacy', 'half_pixel'),
     'angular_cumsum': ('ddsp370', 'exclusive'),
+    'angular_offsets': ('wrapped', 'plain'),
 }
 RECALLED = dict(RECALLED_DEFAULTS)
 
@@ -304,7 +310,9 @@ def angular_cumsum(angular_frequency, chunk_size=1000):
         phase = np.concatenate([np.zeros_like(phase[:, :, :1]), phase[:, :, :-1]], axis=2)
     offsets = np.mod(last, TWO_PI_F32).astype(F32)
     offsets = np.concatenate([np.zeros_like(offsets[:, :1]), offsets[:, :-1]], axis=1)
-    offsets = np.mod(np.cumsum(offsets, axis=1, dtype=F32), TWO_PI_F32).astype(F32)
+    offsets = np.cumsum(offsets, axis=1, dtype=F32)                    # sequential float32 scan over the chunks
+    if RECALLED['angular_offsets'] == 'wrapped':
+        offsets = np.mod(offsets, TWO_PI_F32).astype(F32)
     phase = (phase + offsets).astype(F32)
     phase = np.mod(phase, TWO_PI_F32).astype(F32)
     phase = phase.reshape((n_batch, length_p) + rest)

@@ -66,6 +66,31 @@ def recalled_cases(B_):
     out['ramp_linear'] = B_.resample(ramp, 12 * 96)                                            # resize
     out['ramp_window'] = B_.resample(ramp, 12 * 96, method='window')
     out['phase'] = B_.angular_cumsum(omega)                                                    # angular_cumsum
+    # ... and the case that can tell the variants of angular_cumsum apart: 301 chunks, three
+    # oscillators -- omega near pi (a partial just below Nyquist), near 0, and in between -- piecewise constant over 250
+    # samples.  After 300 chunks the running offset sum is ~2 pi x 150: `phase + offsets` is rounded at ulp(940) = 6e-5 rad
+    # under 'plain' offsets and at ulp(2 pi) under 'wrapped' ones, and float32 scans are deterministic, so the stored
+    # phases are compared BITWISE.  Kept: every 41st sample and the whole last chunk.
+    rng2 = np.random.default_rng(78)         # (a generator of its own: the draws of the older cases stay what they were)
+    blocks = np.stack([rng2.uniform(2.9, 3.14, 1204), rng2.uniform(1e-5, 1e-3, 1204), rng2.uniform(0.05, 0.5, 1204)], -1)
+    # (the values are omegas an oscillator bank can be driven to: omega = fl(fl(fe * fl(2 pi)) / 24000) of float32
+    # frequencies fe, inharm_synth.py:69-70, so the GPU test feeds `fe_long_blocks` to cos_oscillator_bank and lands on
+    # exactly these phases)
+    fe_blocks = (blocks * (24000.0 / (2.0 * np.pi))).astype(np.float32)
+    blocks = ((fe_blocks * O.TWO_PI_F32).astype(np.float32) / np.float32(24000.0)).astype(np.float32)
+    omega_long = np.repeat(blocks, 250, axis=0)[None]                                          # [1, 301000, 3]
+    out['fe_long_blocks'] = fe_blocks
+    out['omega_long'] = omega_long
+    ph = np.asarray(B_.angular_cumsum(omega_long), np.float32)
+    out['phase_long_strided'] = ph[:, ::41]
+    out['phase_long_tail'] = ph[:, -1000:]
+    # bitwise cases for the two upsamplers at a hop that is NOT a power of two (w = frac(float32(n) * float32(T / N)) is
+    # quantised by the product) and past the end-point handling of both
+    rs_in = rng2.normal(0, 1, [2, 37, 3]).astype(np.float32)
+    out['rs_in'] = rs_in
+    out['rs_linear_96'] = B_.resample(rs_in, 37 * 96)
+    out['rs_linear_nonint'] = B_.resample(rs_in, 1000)                                         # N % T != 0
+    out['rs_window_96'] = B_.resample(rs_in, 37 * 96, method='window')
     out['exp_sigmoid'] = B_.exp_sigmoid(x)                                                     # exp_sigmoid constants
     out['noise_controls'] = B_.FilteredNoise(frame_rate=250, sample_rate=24000).get_controls(raw_mag)['magnitudes']
     # ---- not switches, but recalled all the same: one run on a TF host settles these too
@@ -115,6 +140,24 @@ def report_recalled(cases):
     for rule in O.RECALLED_CHOICES['angular_cumsum']:
         with O.recalled(angular_cumsum=rule):
             rows.append(('angular_cumsum', rule, err(O.angular_cumsum(cases['omega']), cases['phase'])))
+    # the long case decides both scan details at once, bitwise (float32 scans are deterministic; TF's CPU cumsum is
+    # sequential per lane -- if the real library shows a few-ulp cloud around ONE of the four variants instead of an exact
+    # match, its scan order differs from the sequential one and that variant is still the one)
+    for scan in O.RECALLED_CHOICES['angular_cumsum']:
+        for offs in O.RECALLED_CHOICES['angular_offsets']:
+            with O.recalled(angular_cumsum=scan, angular_offsets=offs):
+                ph = O.angular_cumsum(cases['omega_long'])
+            got = np.concatenate([ph[:, ::41].ravel(), ph[:, -1000:].ravel()])
+            want = np.concatenate([cases['phase_long_strided'].ravel(), cases['phase_long_tail'].ravel()])
+            d = np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - want.astype(np.float64)))))
+            rows.append((f'angular_offsets (scan={scan})', offs, float(np.sqrt(np.mean(d ** 2))),
+                         f'{int((got != want).sum())} of {got.size} phases differ bitwise, max {d.max():.2e} rad'))
+    for key, fn in (('rs_linear_96', lambda: O.resample(cases['rs_in'], 37 * 96)),
+                    ('rs_linear_nonint', lambda: O.resample(cases['rs_in'], 1000)),
+                    ('rs_window_96', lambda: O.resample(cases['rs_in'], 37 * 96, method='window'))):
+        got = fn()
+        rows.append((f'bitwise: {key}', '-', err(got, cases[key]),
+                     f'{int((got != cases[key]).sum())} of {got.size} values differ bitwise'))
     rows.append(('exp_sigmoid', str(O.RECALLED['exp_sigmoid']), err(O.exp_sigmoid(cases['x']), cases['exp_sigmoid'])))
     rows.append(('initial_bias', str(O.RECALLED['initial_bias']),
                  err(O.FilteredNoise().get_controls(cases['raw_mag'])['magnitudes'], cases['noise_controls'])))
@@ -126,8 +169,8 @@ def report_recalled(cases):
     rows.append(('exp_tanh', '-', err(O.exp_tanh(cases['x']), cases['exp_tanh'])))
     rows.append(('MultiAdd order', '((s0+s1)+s2)+s3', err(O.multi_add(list(cases['ma_in'])), cases['ma_sum'])))
     print('recalled detail                      oracle setting        rms error vs backend output')
-    for name, rule, e in rows:
-        print(f'{name:36s} {rule:20s} {e:.3e}' + ('   <-- matches' if e < 1e-5 else ''))
+    for name, rule, e, *note in rows:
+        print(f'{name:36s} {rule:20s} {e:.3e}' + ('   <-- matches' if e < 1e-5 else '') + (f'   [{note[0]}]' if note else ''))
 
 
 def dafx22_ir():
@@ -139,6 +182,9 @@ def dafx22_ir():
 
 
 def main():
+    global HERE
+    committed = HERE
+    HERE = os.environ.get('DDSP_GOLDEN_OUT') or HERE        # (tests/test_tf_backend_plumbing.py writes into a temp dir)
     B_, bname, bver = backend()
     tag = dict(backend=np.array(bname), backend_versions=np.array(bver))
     if os.path.exists(REF_CKPT):
@@ -146,7 +192,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'dafx22_reverb_ir.npz'), ir=ir, rows=np.array([0, 9]),
                             backend=np.array('reference-data'), backend_versions=np.array('dafx22/ckpt-0'))
     else:                      # a TF host without the checkpoint blob: the committed rows are the same data
-        ir = np.load(os.path.join(HERE, 'dafx22_reverb_ir.npz'))['ir']
+        ir = np.load(os.path.join(committed, 'dafx22_reverb_ir.npz'))['ir']
     cases = recalled_cases(B_)
     np.savez_compressed(os.path.join(HERE, 'recalled_details.npz'), **cases, **tag)
     report_recalled(cases)

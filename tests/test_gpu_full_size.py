@@ -7,6 +7,9 @@
   C2  one 3 s poly-16 segment, full chain, H=96/K=64 and H=128/K=96, against the oracle.
   C5  the per-GPU share of config 5: batch 32, 48 kHz, poly 32, H=128, 3 s, 10 s IR (2^20-point FFT): all rows
       against the every-stem route, FOUR segments against the oracle.
+  C5  at its STATED batch (BASELINE.json configs[4]: batch=256 on one MI355X): 8 192 voice rows x 144 000 samples, the
+      2^20-point reverb on 256 rows; all rows against the every-stem route, FOUR segments against the oracle, peak HBM
+      use asserted to stay inside one GPU.
 The oracle legs are a few tens of seconds of numpy each (one thread per voice)."""
 import os
 import sys
@@ -140,3 +143,43 @@ def test_config5_per_gpu_share_48k_poly32():
     del stems
     segments, info = _pick_segments(feats, P, 4, 9)             # round 4: 4 of the 32 segments
     _check_against_oracle(full, feats, noise, segments, P, sr, 'C5')
+
+
+def test_config5_stated_batch256_48k_poly32():
+    """BASELINE.json configs[4] as written: batch=256, 48 kHz, poly 32, H=128, K=96, 10 s IR -- on ONE GPU.
+    Index arithmetic past 2^30 elements per tensor ([8192, 144000] noise rows = 4.7 GB) is what this case adds."""
+    bench = _bench()
+    import ddsp_piano_amd as dp
+    B, P, T, H, K, S, sr, L = 256, 32, 750, 128, 96, 1, 48000, 480000
+    N = T * 192
+    dev = torch.device('cuda', 0)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    feats, base = bench.make_features(B, P, T, H, K, S, L, dev, seed=5)
+    del base
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_group(dp, P, sr)
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    torch.cuda.synchronize()
+    assert full['signal'].shape == (B, N) and torch.isfinite(full['signal']).all()
+    # the first rows and the last rows are the per-GPU-share problem again: the same values as a batch-32 call on them
+    for sl in (slice(0, 32), slice(B - 32, B)):
+        sub = {k: v[sl].contiguous() for k, v in feats.items()}
+        part = pg(sub, return_outputs_dict=True, noise=noise[sl].contiguous())
+        d = (part['signal'] - full['signal'][sl]).abs().max().item()
+        assert d == 0.0, f'rows {sl}: the batch-256 call differs from the batch-32 call on the same rows by {d:.3e}'
+        assert torch.equal(part['controls']['add']['signal'], full['controls']['add']['signal'][sl]), sl
+        del sub, part
+    stems = pg(feats, return_outputs_dict=True, need_stems=True, noise=noise)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(stems['signal'].abs().max()))
+    assert (full['signal'] - stems['signal']).abs().max().item() < 3e-5 * scale
+    assert (full['controls']['add']['signal'] - stems['controls']['add']['signal']).abs().max().item() < 3e-5 * scale
+    del stems
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert peak < 200.0, f'peak HBM use {peak:.1f} GiB'
+    segments, info = _pick_segments(feats, P, 4, 13)
+    assert max(segments) >= 32, segments            # at least one segment the batch-32 case cannot reach
+    _check_against_oracle(full, feats, noise, segments, P, sr, 'C5 batch 256')

@@ -112,6 +112,19 @@ def test_recalled_detail_cases():
     fe = torch.full((1, 2500 + 4, 1), om * 24000.0 / 6.2831855, device='cuda')          # omega = fe * 2 pi / sr
     got = core.cos_oscillator_bank(fe, torch.ones_like(fe), 24000, True, True).cpu().numpy()[0, :2500]
     assert np.abs(got - np.cos(g['phase'][0, :, 0].astype(np.float64))).max() < 2e-3, 'angular_cumsum'
+    # ... and the case that separates the variants of angular_cumsum (301 chunks, omega near pi / near 0 / in between,
+    # make_golden.py): the oscillator bank driven with the frequencies whose omegas the golden phases were scanned from
+    fe = torch.repeat_interleave(_dev(g['fe_long_blocks']), 250, dim=0)[None].contiguous()         # [1, 301000, 3]
+    cosines = core.cos_oscillator_bank(fe, torch.ones_like(fe), 24000, False, True).cpu().numpy()
+    n = fe.shape[1]
+    assert np.abs(cosines[:, ::41] - np.cos(g['phase_long_strided'].astype(np.float64))).max() < 3e-6, 'angular_offsets / angular_cumsum'
+    assert np.abs(cosines[:, n - 1000:] - np.cos(g['phase_long_tail'].astype(np.float64))).max() < 3e-6, 'angular_offsets / angular_cumsum'
+    # bitwise where bitwise is possible: the legacy bilinear resize (three float32 operations per value, one order)
+    rs = _dev(g['rs_in'])
+    assert np.array_equal(core.resample(rs, 37 * 96).cpu().numpy(), g['rs_linear_96']), 'resize, bitwise'
+    assert np.array_equal(core.resample(rs, 1000).cpu().numpy(), g['rs_linear_nonint']), 'resize (N % T != 0), bitwise'
+    up = core.resample(rs, 37 * 96, method='window').cpu().numpy()
+    assert np.abs(up - g['rs_window_96']).max() <= 2.4e-7 * np.abs(g['rs_window_96']).max(), 'upsample_with_windows (the cross-fade is one FMA: 1 ulp)'
 
 
 def test_full_size_properties_config3_shape():

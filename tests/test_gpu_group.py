@@ -263,8 +263,29 @@ def test_default_model_dag_shape():
     assert [a.name for a in plan.adds] == ['add_0', 'add_1', 'add_2'] and [s.name for s in plan.subs[1:]] == ['sub_add_1', 'sub_add_2']
     pg = dp.ProcessorGroup(gdag)
     walk = dp.ProcessorGroup(gdag, fast_path=False)(gfeats, return_outputs_dict=True, noise=gnoises)
-    # the reference's call form: the last voice's pair, the mix before it and the dry mix
-    out = pg(gfeats, return_outputs_dict=True, noise=gnoises)
+    # the reference's call form: the dictionary holds what run_dag leaves -- every `add_i` / `sub_add_i` (round 5: this
+    # node list names every Add node, so the call form takes every voice's stems)
+    def keys_of(d, prefix=''):
+        ks = set()
+        for k, v in d.items():
+            if k == 'inputs' or k in gfeats:
+                continue
+            ks.add(prefix + k)
+            if isinstance(v, dict):
+                ks |= keys_of(v, prefix + k + '/')
+        return ks
+    whole = pg(gfeats, return_outputs_dict=True, noise=gnoises)
+    assert keys_of(walk['controls']) <= keys_of(whole['controls']), keys_of(walk['controls']) - keys_of(whole['controls'])
+    for i in range(P):
+        for k in ([f'add_{i}/signal', f'add_{i}/controls/signal_one'] + ([f'sub_add_{i}/signal', f'sub_add_{i}/controls/signal_one'] if i else [])):
+            a = whole['controls']
+            b = ref['controls']
+            for part in k.split('/'):
+                a, b = a[part], b[part]
+            assert rms_err(a.cpu().numpy(), b) < TOL, k
+    assert rms_err(whole['signal'].cpu().numpy(), ref['signal']) < TOL * max(1.0, rms(ref['signal']))
+    # the reduced dictionary (explicit opt-in): the last voice's pair, the mix before it and the dry mix
+    out = pg(gfeats, return_outputs_dict=True, noise=gnoises, need_stems='last')
     assert pg._plan is plan or pg._plan.shape == 'default_model'
     assert rms_err(out['signal'].cpu().numpy(), ref['signal']) < TOL * max(1.0, rms(ref['signal']))
     ctl = out['controls']

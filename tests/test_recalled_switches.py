@@ -16,6 +16,11 @@ def core():
     saved = dict(c.RECALLED)
     yield c
     c.RECALLED.update(saved)
+    if saved.get('angular_offsets') is not None:          # (a library option as well: restore it there too)
+        try:
+            c.set_recalled(angular_offsets=saved['angular_offsets'])
+        except RuntimeError:                              # no libddspp.so built: nothing to restore
+            pass
 
 
 @pytest.mark.parametrize('rule', ['legacy', 'half_pixel'])
@@ -52,6 +57,32 @@ def test_set_recalled_validates(core):
     assert prev['auto_delay'] == 'ddsp370' and core._auto_delay(-1) == -2 and core._auto_delay(7) == 7
     core.set_recalled(**prev)
     assert core._auto_delay(-1) == -1
+
+
+def test_angular_offsets_variants_of_the_oracle():
+    """angular_cumsum under both recollections of the offset sum (round 5): both are the exact phase mod 2 pi up to
+    float32 round-off; they part ways from the third chunk on, by the rounding of `phase + offsets` at the magnitude of the sum."""
+    rng = np.random.default_rng(9)
+    n_chunks = 300
+    om = np.repeat(rng.uniform(0.0, 3.1, [n_chunks * 4, 2]).astype(np.float32), 250, axis=0)[None]
+    first = np.mod(np.cumsum(om[:, :1000], axis=1, dtype=np.float32), np.float32(2 * np.pi))
+    with O.recalled(angular_offsets='plain'):
+        a = O.angular_cumsum(om)
+    b = O.angular_cumsum(om)
+    for ph in (a, b):
+        assert ph.shape == om.shape and (ph >= 0).all() and (ph < 6.2831855).all()
+        assert np.array_equal(ph[:, :1000], first)                    # the first chunk has no offset
+    # the second chunk's offset is one end phase (< 2 pi) under both; from then on the rounding of `phase + offsets` differs:
+    # at the magnitude of the running sum (~ pi x chunks) under 'plain', at that of 2 pi under 'wrapped'
+    assert np.array_equal(a[:, :2000], b[:, :2000]) and not np.array_equal(a[:, -1000:], b[:, -1000:])
+    d = np.abs(np.angle(np.exp(1j * (a.astype(np.float64) - b.astype(np.float64)))))
+    late = d[:, -50000:]
+    assert late.max() > 0.5 * np.spacing(np.float32(np.pi * n_chunks)) and late.max() < 1e-3
+    # (a chunk's own phase reaches 3100 rad at omega ~ pi, so `phase + offsets` is rounded at ulp(3100) = 2.4e-4 rad under
+    # either rule; the rules differ in WHICH multiple of float32(2 pi) rides along, i.e. in that rounding -- ~5e-5 rad rms)
+    assert 1e-6 < np.sqrt(np.mean(late ** 2)) < 2e-4
+    # (both are float32 restatements of the same exact phase: ~0.07 rad away from it after 300 000 samples, SURVEY.md fact 8,
+    # and 1e-4 rad from each other -- which recollection is right only shows against the real library)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -125,3 +156,50 @@ def test_harmonic_synthesis_under_both_resize_rules(core, rule):
         x = rng.normal(size=[B, T, 5]).astype(np.float32)
         assert np.array_equal(core.resample(_dev(x), T * 96).cpu().numpy(), O.resample(x, T * 96))
     assert rms_err(got, ref) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rule', ['wrapped', 'plain'])
+def test_oscillator_kernels_under_both_offset_rules(core, rule):
+    """ddsp.core.angular_cumsum's offset sum, wrapped or not (round 5, the seventh switch): the materialised kernel, the
+    fused per-voice kernel, the compacted bank and a streamed render against the oracle under the same rule -- and, so that
+    the case decides something, NOT against the oracle under the other rule.  340 chunks, partials up to Nyquist."""
+    import ddsp_piano_amd as dp
+    other = 'plain' if rule == 'wrapped' else 'wrapped'
+    rng = np.random.default_rng(21)
+    sr, U = 24000, 96
+    # (1) cos_oscillator_bank on materialised envelopes, unsummed: cos(phase) per oscillator
+    N, H = 340000, 4
+    fe = np.repeat(rng.uniform(20.0, 11990.0, [N // 250, H]).astype(np.float32), 250, axis=0)[None]
+    fe[..., 0] = np.float32(11950.0)                                   # omega ~ 3.128 all along
+    ae = np.ones_like(fe)
+    core.set_recalled(angular_offsets=rule)
+    got = core.cos_oscillator_bank(_dev(fe), _dev(ae), sr, False, True).cpu().numpy()
+    with O.recalled(angular_offsets=rule):
+        ref = O.cos_oscillator_bank(fe, ae, sr, sum_sinusoids=False, use_angular_cumsum=True)
+    with O.recalled(angular_offsets=other):
+        ref_other = O.cos_oscillator_bank(fe, ae, sr, sum_sinusoids=False, use_angular_cumsum=True)
+    assert np.abs(got - ref).max() < 3e-6, np.abs(got - ref).max()
+    assert np.abs(got - ref_other)[:, -100000:].max() > 5e-5                   # the variants are 1e-4 apart late in the signal
+    # (2) fused per-voice kernel, (3) compacted bank: a long poly-3 segment, high notes (partials up to Nyquist)
+    B, P, T, Hh = 1, 3, 3542, 64                                               # 340 032 samples = 341 chunks
+    from util import synth_controls
+    voices = [synth_controls(rng, B, T, Hh, S=1, K=8, silent_frac=0.0, midi_lo=80, midi_hi=100) for _ in range(P)]
+    syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+    osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
+    keys = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    with O.recalled(angular_offsets=rule):
+        refs = [osyn(*[v[k] for k in keys]) for v in voices]
+    with O.recalled(angular_offsets=other):
+        ref0_other = osyn(*[voices[0][k] for k in keys])
+    g0 = syn(*[_dev(voices[0][k]) for k in keys]).cpu().numpy()
+    assert rms_err(g0, refs[0]) < 1e-5 * max(1.0, float(np.sqrt(np.mean(refs[0] ** 2))))
+    assert rms_err(g0, ref0_other) > 10 * rms_err(g0, refs[0])
+    stacked = {k: _dev(np.concatenate([v[k] for v in voices], axis=0)) for k in keys}        # rows [B * P] with B = 1
+    ctl = syn._controls(stacked['amplitudes'], stacked['harmonic_distribution'], stacked['inharm_coef'], stacked['f0_hz'],
+                        want_counts=True, want_shifts=False)
+    mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(P, T), ctl['harmonic_distribution'], None, B, T * U,
+                                   sr, voice_major=False, audible=ctl['_audible'],
+                                   inharm_coef=ctl['_inharm_coef'].reshape(P, T)).cpu().numpy()
+    want = (refs[0] + refs[1]) + refs[2]
+    assert rms_err(mix, want) < 1e-5 * max(1.0, float(np.sqrt(np.mean(want ** 2))))
