@@ -29,7 +29,19 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
   * counters_stale : true when profiles/step_valu.json / osc_traffic.json describe another build of the kernels
                      (their csrc hash differs): frac_mix / traffic are then dropped;
   * step_ms        : per-step HIP-event times (median / min / max) of the headline call;
-  * audio_only_call, dense_worst_case, moving_f0, single_stream (+ hipGraph replay), whole_file: other call forms / inputs.
+  * sustained      : >= 5 s of back-to-back headline steps (one HIP event per step, no synchronisation inside), the median
+                     of the LAST HALF of the per-step times, with the shader clock and the socket power sampled meanwhile
+                     (round 5: the K timed steps are 30 ms of GPU time -- this is what the step costs once power and
+                     thermals have settled);
+  * audio_only_call, all_stems_call, decompose_call, dense_worst_case, moving_f0, single_stream, c5_per_gpu_share, c5_full
+    (BASELINE config 5 at its STATED batch of 256 on this one GPU, peak HBM use next to it), dafx22_dims, default_model_dag,
+    shipped_configs (every gin file of the reference; the ENSTDkCl rows with the FDN impulse response kept AND designed per
+    call): other call forms / inputs.  --extras full adds the hipGraph / one-call-driver forms of a single stream, the
+    whole-file renders (136 s, 20 min) and the torch-CPU leg of cpu_baseline; --extras none drops them all;
+  * phase_seconds  : wall clock of the sections of this script (the default run is sized to finish in well under a minute
+                     after `import torch`, so that the driver's GPU-busy sampler sees the GPU at work);
+  * with N > 1: per_rank (every rank's own median step and pipelined step), gather_to_rank0 / allgather alone, and
+    gather_hidden (pipelined step against the synchronised one minus the collective: does the async gather hide?).
 Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no torchrun environment the script
 starts the N ranks itself (torch.distributed.run, one process per GPU) and fails loudly when the box has fewer
 than N GPUs.
@@ -76,8 +88,12 @@ def parse(argv=None):
                     help='the call the timed step makes: the reference\'s (piano_model.py:160) or group(features)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--extras', choices=['default', 'full', 'none'], default='default',
+                    help='the other call forms / workloads reported next to the headline: the quick set, everything, nothing')
     ap.add_argument('--no-extras', '--no-single-stream', dest='no_extras', action='store_true',
-                    help='skip the other call forms / workloads reported next to the headline')
+                    help='same as --extras none')
+    ap.add_argument('--sustain-seconds', type=float, default=5.0,
+                    help='length of the `sustained` measurement (0: skip)')
     ap.add_argument('--cpu-voices', type=int, default=16)
     return ap.parse_args(argv)
 
@@ -255,6 +271,124 @@ def event_times(fn, reps, warmup=2):
 
 def ms_summary(ts):
     return {'median': float(np.median(ts)), 'min': float(np.min(ts)), 'max': float(np.max(ts)), 'n': len(ts)}
+
+
+class GpuSampler:
+    """Shader clock (MHz) and socket power (W) of one GPU, read from a thread while a measurement runs: the amdgpu hwmon
+    files when they are readable (cheap), `rocm-smi --showpower --showclocks --json` otherwise."""
+
+    def __init__(self, index, period=0.25):
+        import glob
+        import threading
+        self.index, self.period = index, period
+        self.samples, self._stop, self._thread = [], threading.Event(), None
+        self.source, self._power, self._freq = None, None, None
+        cards = []
+        for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+            pw = next((os.path.join(hw, f) for f in ('power1_average', 'power1_input') if os.path.exists(os.path.join(hw, f))), None)
+            fq = os.path.join(hw, 'freq1_input')
+            if pw and os.path.exists(fq):
+                try:
+                    slot = open(os.path.join(hw, '..', '..', 'uevent')).read()
+                    slot = next((ln.split('=', 1)[1] for ln in slot.splitlines() if ln.startswith('PCI_SLOT_NAME=')), hw)
+                except OSError:
+                    slot = hw
+                cards.append((slot, pw, fq))
+        cards.sort()
+        # the card of THIS torch device: by PCI address (a box may show more cards in sysfs than HIP exposes)
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        except Exception:  # noqa: BLE001
+            pass
+        pick = next((c for c in cards if want and c[0].lower() == want), None)
+        if pick is None and want is None and index < len(cards):
+            pick = cards[index]
+        if pick is not None:
+            try:
+                float(open(pick[1]).read())
+                float(open(pick[2]).read())
+                self._power, self._freq, self.source = pick[1], pick[2], 'sysfs hwmon ' + pick[0]
+            except (OSError, ValueError):
+                pass
+        self.cards_seen = [c[0] for c in cards]
+        if self.source is None:
+            self.source = 'rocm-smi'
+
+    def _read(self):
+        if self._power:
+            return float(open(self._freq).read()) * 1e-6, float(open(self._power).read()) * 1e-6
+        import re
+        out = subprocess.run(['rocm-smi', '-d', str(self.index), '--showpower', '--showclocks', '--json'],
+                             capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out).values()))
+        clk = next((float(re.search(r'(\d+)\s*Mhz', str(v), re.I).group(1)) for k, v in card.items()
+                    if 'sclk' in k.lower() and re.search(r'(\d+)\s*Mhz', str(v), re.I)), float('nan'))
+        pwr = next((float(v) for k, v in card.items() if 'power' in k.lower() and '(w)' in k.lower()), float('nan'))
+        return clk, pwr
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            try:
+                clk, pwr = self._read()
+                self.samples.append((t, clk, pwr))
+            except Exception:  # noqa: BLE001  (a sampler that cannot read reports nothing; the timing does not depend on it)
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+        return False
+
+    def summary(self, t_from=None):
+        rows = [r for r in self.samples if t_from is None or r[0] >= t_from]
+        out = {'source': self.source, 'n': len(rows)}
+        if t_from is None and len(getattr(self, 'cards_seen', [])) > 1:
+            out['cards_in_sysfs'] = len(self.cards_seen)
+        for name, col, unit in (('sclk_mhz', 1, 'MHz'), ('socket_power_w', 2, 'W')):
+            vals = [r[col] for r in rows if r[col] == r[col]]
+            if vals:
+                out[name] = {'median': float(np.median(vals)), 'min': float(np.min(vals)), 'max': float(np.max(vals))}
+        return out
+
+
+def measure_sustained(step_fn, seconds, est_ms, device_index, units_per_step, sr, drain=None):
+    """`seconds` of back-to-back steps: one HIP event after every step on the launch stream, nothing synchronised inside
+    the loop (the host runs ahead of the GPU as far as the launch queue lets it), clock and power sampled from a thread.
+    Reported: the median of the LAST HALF of the per-step times -- the state the GPU settles in -- next to the first half's."""
+    n = int(min(20000, max(200, seconds * 1e3 / max(est_ms, 1e-3) * 1.05)))
+    stream = torch.cuda.current_stream()
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize()
+    with GpuSampler(device_index) as smp:
+        t0 = time.perf_counter()
+        events[0].record(stream)
+        for i in range(n):
+            step_fn()
+            events[i + 1].record(stream)
+        if drain is not None:
+            drain()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    ts = np.asarray([events[i].elapsed_time(events[i + 1]) for i in range(n)])
+    half = ts[n // 2:]
+    med = float(np.median(half))
+    return {'workload': f'{n} headline steps back to back ({t1 - t0:.2f} s of wall clock), one HIP event per step, no '
+                        'synchronisation inside the loop',
+            'ms_per_step': med, 'value': units_per_step / (med * 1e-3), 'rtf': units_per_step / (med * 1e-3) / sr,
+            'last_half': ms_summary(half), 'first_half': ms_summary(ts[:n // 2]),
+            'first_100_median': float(np.median(ts[:100])), 'last_100_median': float(np.median(ts[-100:])),
+            'wall_ms_per_step': (t1 - t0) / n * 1e3, 'seconds': t1 - t0, 'n': n,
+            'gpu': smp.summary(), 'gpu_last_half': smp.summary(t_from=t0 + 0.5 * (t1 - t0))}
 
 
 def measure_device_peaks(device, nbytes=1 << 30):
@@ -456,8 +590,10 @@ def measure_roofline_noise(dp, base, args, T, U, device):
     return out
 
 
-def measure_cpu_baseline(args, T, U):
-    """The oracle (float32-faithful numpy restatement of the TF/ddsp reference -- TF itself cannot be
+def measure_cpu_baseline(args, T, U, full=False):
+    """(full=False, the default run: the numpy oracle on 32 threads only, ~6 s; full=True adds a second thread count and the
+    torch-CPU leg, whose 256-thread probe alone is half a minute on the GPU box's host.)
+    The oracle (float32-faithful numpy restatement of the TF/ddsp reference -- TF itself cannot be
     installed here) on a bounded sample of the same workload: whole 3 s, poly-16 segments, one
     thread per voice task, sized for roughly 10 s of wall clock on this host; and the op-by-op torch-CPU
     chain (oracle/torch_cpu_chain.py) with torch's intra-op pool on all cores, the stand-in for TF's."""
@@ -499,12 +635,12 @@ def measure_cpu_baseline(args, T, U):
         return time.perf_counter() - t0
 
     t1 = run([make_segment()])                                   # also warms numpy / scipy up
-    n_seg = int(max(1, min(32, round(8.0 / max(t1, 1e-3)))))
+    n_seg = int(max(1, min(32, round((8.0 if full else 6.0) / max(t1, 1e-3)))))
     segs = [make_segment() for _ in range(n_seg)]
     # one thread per voice task scales as far as the tasks and the host's cores go (numpy releases the GIL in its inner
     # loops): the sample is timed with 32 threads and with as many as it has tasks (up to 128), the faster one is reported
     tried = {}
-    for nthr in sorted({threads, max(1, min(os.cpu_count() or 1, 128, n_seg * P))}):
+    for nthr in sorted({threads, max(1, min(os.cpu_count() or 1, 128, n_seg * P))} if full else {threads}):
         tried[nthr] = run(segs, nthr)
     threads = min(tried, key=tried.get)
     dt = tried[threads]
@@ -515,6 +651,12 @@ def measure_cpu_baseline(args, T, U):
                             ', '.join(f'{k} threads {v:.1f} s' for k, v in tried.items()) + ')',
                   'rtf': n_seg * N / dt / sr}
 
+    if not full:
+        out = dict(numpy_port)
+        out['numpy_oracle'] = numpy_port
+        out['note'] = ('TensorFlow / ddsp are not installable on this host: the float32-faithful numpy restatement of the '
+                       'reference chain stands in (bench.py --extras full adds the op-by-op torch-CPU chain)')
+        return out
     # torch-CPU: whole segments through the vectorised operator sequence, intra-op pool on all cores (and on 32, where
     # oversubscribing tiny ops hurts less; the faster of the two is reported).  Bounded: a probe on one voice x 0.5 s
     # sizes the sample to ~8 s of wall clock.
@@ -604,6 +746,15 @@ def main():
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import parallel
 
+    extras_level = 'none' if args.no_extras else args.extras
+    phase_s, _t_phase = {}, [time.perf_counter()]
+
+    def phase_done(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        phase_s[name] = phase_s.get(name, 0.0) + now - _t_phase[0]
+        _t_phase[0] = now
+
     sr = args.sample_rate
     U = sr // 250
     T = int(round(args.seconds * 250))
@@ -617,6 +768,7 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = measure_roofline(dp, base, args, T, U, device)
+    phase_done('inputs_and_graded_kernel')
     pg = build_group(dp, P, sr)
     want_dict = args.call_form == 'outputs_dict'
     # the final gather: to rank 0 (the reference's strategy.gather(outputs, axis=0), evaluate_model.py:45 -- one program
@@ -717,7 +869,46 @@ def main():
                            'note': 'the collective alone, synchronous (median of 5, max over ranks)'}
     if rank == 0:
         extra['step_ms'] = ms_summary(step_ts)   # the timed steps themselves (this rank)
-    if rank == 0 and not args.no_extras:
+    if use_dist:
+        # every rank's own view, and whether the asynchronous gather hides under the next step's kernels (DESIGN.md
+        # section 8's open question): compute_only = the step without any collective, on this rank
+        comp_ts = event_times(lambda: call(pg, feats), args.steps, warmup=2)
+        mine = torch.tensor([float(np.median(step_ts)), float(np.median(comp_ts)), dt / args.steps * 1e3],
+                            dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = [[float(x) for x in t.tolist()] for t in allr]
+        extra['per_rank'] = {'ms_step_with_sync_gather': [p_[0] for p_ in per], 'ms_step_compute_only': [p_[1] for p_ in per],
+                             'ms_step_pipelined': [p_[2] for p_ in per],
+                             'note': 'median over the timed steps of each rank, in rank order; pipelined = wall clock / steps'}
+        comp, sync_, pipe = max(p_[1] for p_ in per), max(p_[0] for p_ in per), max(p_[2] for p_ in per)
+        cost = sync_ - comp
+        extra['gather_hidden'] = {'compute_only_ms': comp, 'with_synchronous_gather_ms': sync_, 'pipelined_ms': pipe,
+                                  'gather_cost_in_a_synchronous_step_ms': cost,
+                                  'hidden_fraction': (float(np.clip((sync_ - pipe) / cost, 0.0, 1.0)) if cost > 1e-3 else None),
+                                  'hidden': bool(pipe <= comp * 1.03),
+                                  'note': 'max over ranks; hidden = the pipelined step (gather of step i on RCCL\'s stream while '
+                                          'step i + 1 synthesises, two landing buffers) costs no more than the step without any '
+                                          'collective (+ 3 %)'}
+    phase_done('timed_steps_and_collectives')
+    if args.sustain_seconds > 0:
+        sus = measure_sustained(step, args.sustain_seconds, med * 1e3, dev_index, world * B * N, sr, drain if use_dist else None)
+        if use_dist:
+            tt = torch.tensor([sus['ms_per_step']], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sus['ms_per_step'] = float(tt.item())
+            sus['value'] = world * B * N / (sus['ms_per_step'] * 1e-3)
+            sus['rtf'] = sus['value'] / sr
+        if rank == 0:
+            ref = float(np.median(step_ts)) if not use_dist else med * 1e3
+            sus['vs_step_ms_median'] = sus['ms_per_step'] / ref
+            sus['note'] = ('last-half median / median of the K synchronised steps = %.3f' % sus['vs_step_ms_median'] +
+                           ('; steps include their gather (pipelined)' if use_dist else '') +
+                           '; the synchronised steps pay an event wait and an idle gap each, the sustained ones run into each '
+                           'other and run at whatever clock the socket power limit leaves (gpu_last_half)')
+            extra['sustained'] = sus
+        phase_done('sustained')
+    if rank == 0 and extras_level != 'none':
         other = 'audio_only_call' if want_dict else 'outputs_dict_call'
         fn = (lambda: pg(feats)) if want_dict else (lambda: pg(feats, return_outputs_dict=True))
         ts = event_times(fn, 20, warmup=3)
@@ -757,53 +948,72 @@ def main():
         d1 = min(time_steps(lambda: call(pg1, f1), 20, 3) for _ in range(3))          # best of three runs of 20
         extra['single_stream'] = {'workload': f'B=1 x {args.seconds:g} s, poly={P}', 'ms_per_segment': d1 / 20 * 1e3,
                                   'rtf': (N * 20 / d1) / sr}
-        # the same call captured once as a HIP graph and replayed (inputs copied into the captured buffers, fresh
-        # noise drawn, per call): what a launch-bound caller -- one stream, streaming blocks -- would use
-        from ddsp_piano_amd.graph import CapturedGroup
-        cg = CapturedGroup(pg1, f1, return_outputs_dict=(args.call_form == 'outputs_dict'))
-        dg = min(time_steps(lambda: cg(f1), 20, 3) for _ in range(3))
-        extra['single_stream_graph'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay',
-                                        'ms_per_segment': dg / 20 * 1e3, 'rtf': (N * 20 / dg) / sr}
-        del cg
-        # ... and the form that pays neither the Python layer nor the input copies: the one-call driver's kernels captured,
-        # controls written in place into the captured buffers (CapturedGroup.inputs), fresh noise drawn per replay
-        cgn = CapturedGroup(dp.NativeGroup(pg1, f1), f1, return_outputs_dict=(args.call_form == 'outputs_dict'))
-        dgn = min(time_steps(lambda: cgn(), 20, 3) for _ in range(3))
-        extra['single_stream_graph_native'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay of '
-                                               'ddspp_group_run, controls written in place (no per-replay input copies)',
-                                               'ms_per_segment': dgn / 20 * 1e3, 'rtf': (N * 20 / dgn) / sr}
-        del cgn
-        # the library's one-call driver (ddspp_group_run behind ddsp_piano_amd.NativeGroup): the same kernels enqueued
-        # from C++ instead of a dozen ctypes calls -- what a caller without the Python layer gets
-        ng1 = dp.NativeGroup(pg1, f1)
-        dn = min(time_steps(lambda: ng1(f1, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, 3) for _ in range(3))
-        extra['single_stream_native'] = {'workload': extra['single_stream']['workload'] + ', ddspp_group_run',
-                                         'ms_per_segment': dn / 20 * 1e3, 'rtf': (N * 20 / dn) / sr}
-        del ng1
-        ngb = dp.NativeGroup(pg, feats)
-        ts = event_times(lambda: ngb(feats, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, warmup=3)
-        extra['native_group_call'] = {'workload': 'the headline batch and call form through ddspp_group_run',
-                                      'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
-        del ngb
+        phase_done('extras_call_forms_and_inputs')
+        if extras_level == 'full':
+            # the same call captured once as a HIP graph and replayed (inputs copied into the captured buffers, fresh
+            # noise drawn, per call): what a launch-bound caller -- one stream, streaming blocks -- would use
+            from ddsp_piano_amd.graph import CapturedGroup
+            cg = CapturedGroup(pg1, f1, return_outputs_dict=(args.call_form == 'outputs_dict'))
+            dg = min(time_steps(lambda: cg(f1), 20, 3) for _ in range(3))
+            extra['single_stream_graph'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay',
+                                            'ms_per_segment': dg / 20 * 1e3, 'rtf': (N * 20 / dg) / sr}
+            del cg
+            # ... and the form that pays neither the Python layer nor the input copies: the one-call driver's kernels captured,
+            # controls written in place into the captured buffers (CapturedGroup.inputs), fresh noise drawn per replay
+            cgn = CapturedGroup(dp.NativeGroup(pg1, f1), f1, return_outputs_dict=(args.call_form == 'outputs_dict'))
+            dgn = min(time_steps(lambda: cgn(), 20, 3) for _ in range(3))
+            extra['single_stream_graph_native'] = {'workload': extra['single_stream']['workload'] + ', hipGraph replay of '
+                                                   'ddspp_group_run, controls written in place (no per-replay input copies)',
+                                                   'ms_per_segment': dgn / 20 * 1e3, 'rtf': (N * 20 / dgn) / sr}
+            del cgn
+            # the library's one-call driver (ddspp_group_run behind ddsp_piano_amd.NativeGroup): the same kernels enqueued
+            # from C++ instead of a dozen ctypes calls -- what a caller without the Python layer gets
+            ng1 = dp.NativeGroup(pg1, f1)
+            dn = min(time_steps(lambda: ng1(f1, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, 3) for _ in range(3))
+            extra['single_stream_native'] = {'workload': extra['single_stream']['workload'] + ', ddspp_group_run',
+                                             'ms_per_segment': dn / 20 * 1e3, 'rtf': (N * 20 / dn) / sr}
+            del ng1
+            ngb = dp.NativeGroup(pg, feats)
+            ts = event_times(lambda: ngb(feats, return_outputs_dict=(args.call_form == 'outputs_dict')), 20, warmup=3)
+            extra['native_group_call'] = {'workload': 'the headline batch and call form through ddspp_group_run',
+                                          'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+            del ngb
+            phase_done('extras_full_single_stream_forms')
         # the other shipped shapes, driver-run: BASELINE config 5's per-GPU share and the dafx22 model
         for key, (b_, p_, h_, k_, s_, sr_, ir_s, note) in {
                 'c5_per_gpu_share': (32, 32, 128, 96, 1, 48000, 10.0, 'BASELINE config 5 per GPU (batch 256 / 8): 48 kHz, poly 32, 10 s IR'),
+                'c5_full': (256, 32, 128, 96, 1, 48000, 10.0, 'BASELINE config 5 at its STATED batch on ONE MI355X: 48 kHz, poly 32, 10 s IR (2^20-point reverb on 256 rows, 8192 voice rows)'),
                 'dafx22_dims': (B, 16, 96, 64, 2, 16000, 1.5, 'configs/dafx22.gin dims: 16 kHz, two sub-strings, 1.5 s IR')}.items():
             u_ = sr_ // 250
-            fx, _ = make_features(b_, p_, T, h_, k_, s_, int(ir_s * sr_), device, seed=41)
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            fx, bx = make_features(b_, p_, T, h_, k_, s_, int(ir_s * sr_), device, seed=41)
+            del bx
             pgx = build_group(dp, p_, sr_)
-            ts = event_times(lambda: call(pgx, fx), 10, warmup=3)
+            ts = event_times(lambda: call(pgx, fx), 6 if key == 'c5_full' else 10, warmup=3)
             extra[key] = {'workload': f'{note}; batch={b_} x {args.seconds:g} s, H={h_}, K={k_}, S={s_}',
                           'ms_per_step': ms_summary(ts), 'value': b_ * T * u_ / (float(np.median(ts)) * 1e-3),
                           'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+            if key == 'c5_full':
+                extra[key]['peak_hbm_gib'] = torch.cuda.max_memory_allocated() / 2 ** 30
+                extra[key]['peak_hbm_note'] = ('torch allocator peak (inputs 15 GiB of controls + every workspace and output of the '
+                                               'call) of the 288 GB on the GPU')
             if key == 'dafx22_dims':
                 # the same inputs through the node list default_model.py itself builds (explicit Add nodes, noise first)
                 pgd = build_default_model_group(dp, p_, sr_)
                 ts = event_times(lambda: call(pgd, fx), 10, warmup=3)
                 extra['default_model_dag'] = {'workload': 'ddsp_piano/default_model.py:44-80 node list at the dafx22 dims, '
-                                                          f'batch={b_} x {args.seconds:g} s (batched route since round 4)',
+                                                          f'batch={b_} x {args.seconds:g} s; with return_outputs_dict=True the '
+                                                          'dictionary holds every add_i / sub_add_i as the reference\'s does '
+                                                          '(round 5: every voice\'s stems are rendered for it)',
                                               'ms_per_step': ms_summary(ts),
                                               'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+                if want_dict:
+                    ts = event_times(lambda: pgd(fx, return_outputs_dict=True, need_stems='last'), 10, warmup=3)
+                    extra['default_model_dag_reduced_dict'] = {
+                        'workload': 'the same with need_stems=\'last\' (opt-in): only the last voice\'s pair, the mix before it and '
+                                    'the dry mix are written (the compacted route, round 4\'s behaviour)',
+                        'ms_per_step': ms_summary(ts), 'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
                 del pgd
             del fx, pgx
             torch.cuda.empty_cache()
@@ -830,9 +1040,19 @@ def main():
                                         (' (SurrogateAdditive: per-voice rows through the fused decay kernel, batched '
                                          'route since round 4)' if cfg == 'surrogate' else ''),
                             'ms_per_step': ms_summary(ts), 'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
+            if cfg.startswith('ENST'):
+                # like for like with the reference, which designs the impulse response inside EVERY get_controls
+                # (fdn_reverb.py:383-392): the FDN node with cache_ir=False
+                pgx.processors[-1].cache_ir = False
+                ts = event_times(lambda: call(pgx, fx), 10, warmup=2)
+                shipped[cfg + ' (FDN designed per call)'] = {
+                    'workload': shipped[cfg]['workload'].split(' (FDN node')[0] + ' (FDN impulse response designed inside every '
+                                'call, as fdn_reverb.py:383-392 does: ddspp_fdn_transfer + irfft + early reflections per step)',
+                    'ms_per_step': ms_summary(ts), 'rtf': b_ * T * u_ / (float(np.median(ts)) * 1e-3) / sr_}
             del fx, bx, pgx
             torch.cuda.empty_cache()
         extra['shipped_configs'] = shipped
+        phase_done('extras_shipped_shapes')
         # what synthesize_midi_file.py does: the whole file as ONE segment (here 136 s, poly 16)
         Tw = 34000
         fw, _ = make_features(1, P, Tw, H, K, S, int(2.0 * sr), device, seed=11)
@@ -842,27 +1062,32 @@ def main():
                                'ms_per_file': dw / 5 * 1e3, 'rtf': (Tw * U * 5 / dw) / sr}
         del fw, pgw
         torch.cuda.empty_cache()
-        # ... and a piece of typical MAESTRO length: 20 minutes = 300 000 frames, past the 131 072 frames up to which the
-        # reference's bilinear resize takes rows (t, t + 1) for every sample of frame t (core.walk_weights: the samples that
-        # take row t + 1 itself are marked and the fused kernels keep the file; before round 4 it fell to per-voice
-        # materialised envelopes)
-        Tl = 300000
-        fl, _ = make_features(1, P, Tl, H, K, S, int(2.0 * sr), device, seed=12)
-        pgl = build_group(dp, P, sr)
-        dl = min(time_steps(lambda: call(pgl, fl), 3, 1) for _ in range(2))
-        extra['whole_file_20min'] = {'workload': f'B=1 x {Tl / 250:g} s in one segment, poly={P}, 2 s IR',
-                                     'ms_per_file': dl / 3 * 1e3, 'rtf': (Tl * U * 3 / dl) / sr}
-        del fl, pgl, f1, pg1
+        if extras_level == 'full':
+            # ... and a piece of typical MAESTRO length: 20 minutes = 300 000 frames, past the 131 072 frames up to which the
+            # reference's bilinear resize takes rows (t, t + 1) for every sample of frame t (core.walk_weights: the samples that
+            # take row t + 1 itself are marked and the fused kernels keep the file; before round 4 it fell to per-voice
+            # materialised envelopes)
+            Tl = 300000
+            fl, _ = make_features(1, P, Tl, H, K, S, int(2.0 * sr), device, seed=12)
+            pgl = build_group(dp, P, sr)
+            dl = min(time_steps(lambda: call(pgl, fl), 3, 1) for _ in range(2))
+            extra['whole_file_20min'] = {'workload': f'B=1 x {Tl / 250:g} s in one segment, poly={P}, 2 s IR',
+                                         'ms_per_file': dl / 3 * 1e3, 'rtf': (Tl * U * 3 / dl) / sr}
+            del fl, pgl
+        del f1, pg1
         torch.cuda.empty_cache()
+        phase_done('extras_whole_file')
     roof_step = roof_noise = None
     if rank == 0 and not args.no_roofline:
         del feats
         torch.cuda.empty_cache()
         roof_step = measure_roofline_step(dp, base, args, T, U, device)
         roof_noise = measure_roofline_noise(dp, base, args, T, U, device)
+        phase_done('roofline_step_and_noise')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = measure_cpu_baseline(args, T, U)
+        cpu = measure_cpu_baseline(args, T, U, full=(extras_level == 'full'))
+        phase_done('cpu_baseline')
     if dist is not None:
         dist.barrier()
 
@@ -886,6 +1111,7 @@ def main():
                                                                                        + (' + one gather of the audio per step (inside the timed step; overlapped with the next step in `pipelined`)' if world > 1 else '')},
             'roofline': roof, 'roofline_step': roof_step, 'roofline_noise': roof_noise, 'cpu_baseline': cpu,
             'counters_stale': (any(bool(x) for x in stale) if stale else None),
+            'extras': extras_level, 'phase_seconds': {k: round(v, 2) for k, v in phase_s.items()},
         }
         line.update(extra)
     if dist is not None:

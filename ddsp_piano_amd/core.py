@@ -285,9 +285,21 @@ def _walk_weights_np(n_frames, n_timesteps, rule='legacy', first_sample=0, n=Non
     return w, True
 
 
+@functools.lru_cache(maxsize=8)
+def _walk_full_np(n_frames, n_timesteps, rule):
+    """(w, walkable) of a whole signal, computed ONCE per shape: fused_synthesis_supported() and walk_weights() both ask
+    (a 20-minute file is 28.8 M samples -- seconds of host work and ~1 GB of temporaries per evaluation)."""
+    return _walk_weights_np(n_frames, n_timesteps, rule)
+
+
 @functools.lru_cache(maxsize=64)
 def _walkable_np(n_frames, n_timesteps, rule):
-    return _walk_weights_np(n_frames, n_timesteps, rule)[1]
+    if rule == 'legacy' and n_timesteps % n_frames == 0 and n_timesteps < (1 << 24):
+        # below 2^24 samples float32(T) / float32(N) is RN(1 / U) exactly, and linear_exact_frames(U) is the first frame at
+        # which float32(n) * RN(1 / U) leaves frame n // U: shorter signals are frame aligned, nothing to build
+        if n_frames < linear_exact_frames(n_timesteps // n_frames):
+            return True
+    return _walk_full_np(n_frames, n_timesteps, rule)[1]
 
 
 _table_cache = {}
@@ -319,7 +331,7 @@ def walk_weights(n_frames, n_timesteps, device, sample_offset=0):
     the next-row mark.  sample_offset > 0: a streamed piece, built on the device and not cached."""
     if not sample_offset:
         def build():
-            return torch.from_numpy(_walk_weights_np(int(n_frames), int(n_timesteps), RECALLED['resize'])[0]).to(device)
+            return torch.from_numpy(_walk_full_np(int(n_frames), int(n_timesteps), RECALLED['resize'])[0]).to(device)
         return _cached(('walk', int(n_frames), int(n_timesteps), str(device), RECALLED['resize']), build)
     global _last_weights
     on_gpu = torch.device(device).type == 'cuda'
@@ -375,10 +387,23 @@ def _linear_weights_at(n_frames, n_timesteps, device, sample_offset, walk=False)
         pos = n * scale
     fl = torch.floor(pos)
     w = pos - fl
-    if walk and int(n_timesteps) % int(n_frames) == 0:
-        # the next-row mark of _walk_weights_np (whether the piece is walkable at all is the caller's question: walkable())
+    if walk:
+        # the next-row mark of _walk_weights_np, with its restrictions: a marked sample takes row t + 1 with weight 0 and lies
+        # in the last block of its frame (the kernels look for marks there only).  A piece with any OTHER off-row sample --
+        # hours into a signal, or under the half-pixel rule -- cannot be rendered by the frame walk: refuse it here instead
+        # of rendering wrong frequencies (StreamingSynthesizer.push asks walkable() first and never gets here)
+        if int(n_timesteps) % int(n_frames) != 0:
+            raise ValueError(f'walk_weights: {n_timesteps} samples are not a whole number of hops of {n_frames} frames')
         u = int(n_timesteps) // int(n_frames)
-        nxt = (fl.to(torch.int64) == idx // u + 1) & (w == 0)
+        t = idx // u
+        lo = fl.to(torch.int64).clamp_(min=0)
+        off = lo != t
+        nxt = off & (lo == t + 1) & (w == 0) & (idx % u >= u - WALK_BLOCK)
+        if bool((off & ~nxt).any().item()):
+            raise ValueError(f'walk_weights: samples {int(sample_offset)} .. {int(sample_offset) + int(n_timesteps)} of a signal '
+                             f'with {u} samples per frame are not walkable under resize={RECALLED["resize"]!r} (the bilinear '
+                             'resize leaves frames n // U and n // U + 1 there); render the piece through resample + '
+                             'cos_oscillator_bank, or ask core.walkable() first')
         w = torch.where(nxt, torch.ones_like(w), w)
     return w.contiguous()
 

@@ -306,7 +306,7 @@ inharmonic_controls_kernel(const InharmParams p) {
 // The same conditioning for the flags every model of the reference ships with (cut above Nyquist FIRST, then
 // normalise: normalize_below_nyquist and normalize_after_nyquist_cut both set) and a whole number of 16-harmonic groups,
 // with the scale function a template argument (round 4).  Same arithmetic per element and the same order of additions as
-// inharmonic_controls_body -- the two agree bit for bit (tests/test_gpu_controls.py) -- but a third of the instructions:
+// inharmonic_controls_body -- the two agree bit for bit (tests/test_gpu_osc.py::test_lean_get_controls_*) -- but a third of the instructions:
 //   * the body above re-decided the scale function with scalar branches at every element, kept hd[] / shift[] in
 //     register tuples the compiler shuffled with ~25 v_mov_b64 per element, and wrapped every element in an EXEC branch;
 //     here an element is straight-line code under one wave-uniform "is any of the four frames' groups alive" test;

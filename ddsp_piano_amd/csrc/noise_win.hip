@@ -24,6 +24,8 @@
 // (stride U / 4 + 1 blocks, odd).  A window computes W = D - 2 frames (the first and the last designed frame only
 // feed their neighbours).
 #include "ddspp_common.h"
+#include <stdio.h>
+
 #include "noise_win.h"
 
 namespace ddspp {
@@ -1026,6 +1028,14 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     if (tpw < 1) tpw = 1;
     while (tpw > 1 && tasks / tpw < 768) tpw >>= 1;          // few tasks (a single segment): one unit per workgroup
     const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk, 16 = untrimmed walk
+    if (dbg & (1 | 2 | 8)) {                                // (these three leave work out: the audio is WRONG by design)
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "libddspp: DDSPP_WIN_DEBUG=%d is a TIMING ABLATION -- FilteredNoise output is deliberately wrong; "
+                            "unset it for anything but a timing experiment\n", dbg);
+        }
+    }
     const dim3 grid((unsigned)((tasks + tpw - 1) / tpw)), block(256);
 #define DDSPP_WIN_LAUNCH(KH, JT, OPL, BPF)                                                                        \
     hipLaunchKernelGGL((noise_win_fused_kernel<KH, JT, OPL, BPF>), grid, block, lds, stream, audio, magnitudes, CE, \

@@ -148,15 +148,18 @@ class FeedbackDelayNetwork(Processor):
     never trains them: they are initialised with the reference's initialisers (seeded) or set from a checkpoint with
     load_parameters().  That makes the layer usable as the LAST node of the polyphonic DAG with reverb_controls = []
     (configs/ENSTDkCl-8kHz.gin:85-86,100-104, ENSTDkCl-32kHz.gin).  The impulse response of fixed parameters is
-    computed once and kept until load_parameters() is called again."""
+    computed once and kept until load_parameters() is called again (cache_ir=True, the default: weights do not move at
+    inference); cache_ir=False designs it inside every get_controls, as the reference does (fdn_reverb.py:383-392) --
+    the like-for-like cost of a call (bench.py reports both)."""
 
     PARAMETER_NAMES = ('early_ir', 'input_gain', 'output_gain', 'time_rev_0_sec', 'alpha_tone', 'delay_values',
                        'delays_allpass', 'gain_allpass')
 
     def __init__(self, trainable=False, name='DelayNetwork', sampling_rate=16000.0, delay_lines=8,
                  delay_values=None, delays_allpass=None, early_ir_length=200, early_reflections=6,
-                 time_control_bands=6, delay_trainable=False, seed=0):
+                 time_control_bands=6, delay_trainable=False, seed=0, cache_ir=True):
         super().__init__(name=name, trainable=trainable)
+        self.cache_ir = bool(cache_ir)
         self.sampling_rate = float(sampling_rate)
         self.freq_points = int(2 * self.sampling_rate)                  # :81
         self.early_ir_length = early_ir_length
@@ -164,6 +167,7 @@ class FeedbackDelayNetwork(Processor):
         self.time_control_bands = time_control_bands
         self.delay_trainable = delay_trainable
         self._ir_cache = None
+        self._dev_params = None
         if trainable:
             d = int(delay_lines)
             g = torch.Generator().manual_seed(int(seed))
@@ -227,6 +231,7 @@ class FeedbackDelayNetwork(Processor):
         self.delay_values = tuple(float(v) for v in new['delay_values'])
         self.delay_lines = d
         self._ir_cache = None
+        self._dev_params = None
 
     def get_ir(self, input_gain, output_gain, gain_allpass, delays_allpass, time_rev_0_sec, alpha_tone, early_ir):
         """fdn_reverb.py:336-360 (one instrument; returns [2 * sampling_rate])."""
@@ -244,8 +249,10 @@ class FeedbackDelayNetwork(Processor):
         """fdn_reverb.py:362-405."""
         if self.trainable:                                                         # :383-392
             dev = core.tf_float32(audio_dry).device if audio_dry is not None else core.default_device()
-            if self._ir_cache is None or self._ir_cache.device != dev:
-                p = {k: v.to(dev) for k, v in self._params.items()}
+            if self._ir_cache is None or self._ir_cache.device != dev or not self.cache_ir:
+                if self._dev_params is None or self._dev_params[0] != dev:
+                    self._dev_params = (dev, {k: v.to(dev) for k, v in self._params.items()})
+                p = self._dev_params[1]
                 self._ir_cache = self.get_ir(p['input_gain'], p['output_gain'], p['gain_allpass'], p['delays_allpass'],
                                              p['time_rev_0_sec'], torch.sigmoid(p['alpha_tone']), p['early_ir'])
             return {'audio': audio_dry, 'ir': self._ir_cache}
