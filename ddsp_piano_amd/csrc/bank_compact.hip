@@ -39,11 +39,20 @@ struct SlotCtx {
 // DECAY (SurrogateAdditive, surrogate_synth.py:76-95): the amplitude of oscillator k in frame t is multiplied by
 // |decays[t, k]| ** (decay_time[t] U + r); as in osc_kernel<..., DECAY> the power is evaluated by powf once per frame and
 // lane and advances by d ** 8 per block and d per sample.  The next frame's factors are requested one frame ahead.
-template <int VPL, bool DECAY = false>
+//
+// PAIR (round 5; S = 2, VPL = 2, no decay): the two entries of a lane are the two SUB-STRINGS of one (voice, harmonic)
+// instead of two unrelated oscillators.  MultiInharmonic shares amplitudes, harmonic_distribution and harmonic_shifts
+// between the sub-strings (inharm_synth.py:279-292: only f0_hz[..., s] differs), so a lane loads them once, forms
+// shift_from_inharm once per frame, and -- while both sub-strings sit on the same side of Nyquist, which they do except
+// for a partial in the 0.3-cent gap between them -- evaluates ONE Hann cross-fade per sample: a (cos0 + cos1).  The packed
+// list then has one entry per (voice, harmonic): a slot carries 64 pairs.
+template <int VPL, bool DECAY = false, bool PAIR = false>
 __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const SlotCtx& c) {
+    static_assert(!PAIR || (VPL == 2 && !DECAY), "PAIR: two sub-strings per lane, no decay term");
     const int lane = c.lane, row = c.row, span = c.span, cw_all = c.cw_all;
     const int n_begin = c.n_begin, n_end = c.n_end, qlo = c.qlo, qhi = c.qhi, total = c.total;
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S;
+    const int SUB = PAIR ? 1 : S;                            // sub-rows of a voice in the packed list
     typedef const __attribute__((address_space(4))) float* cfloat_p;     // wave-uniform tables -> scalar loads
     const cfloat_p wlin_c = (cfloat_p)(uintptr_t)p.wlin;
     const cfloat_p whann_c = (cfloat_p)(uintptr_t)p.whann;
@@ -67,15 +76,15 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     float kmul[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        const int g = c.first + lane + 64 * j;
+        const int g = c.first + lane + (PAIR ? 0 : 64 * j);
         const int gc = min(g, total - 1);
         int q = qlo;                                         // last sub-row of the region whose offset is <= gc
 #pragma unroll
         for (int step = 32; step > 0; step >>= 1)
             if (q + step < qhi && offs[q + step] <= gc) q += step;
         const int k = gc - offs[q];
-        lrow[j] = p.vmajor ? (q / S) * p.R + row : row * p.P + q / S;
-        vs[j] = q - (q / S) * S;
+        lrow[j] = p.vmajor ? (q / SUB) * p.R + row : row * p.P + q / SUB;
+        vs[j] = PAIR ? j : q - (q / SUB) * SUB;
         vk[j] = k;
         vidx[j] = vs[j] * H + k;
         valid[j] = g < total;
@@ -136,21 +145,31 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const size_t fr = (size_t)lrow[j] * T + tt;
-            q_amp[j] = p.amp[fr];
             q_f0[j] = p.f0[fr * S + vs[j]];
+            if (PAIR && j > 0) {                   // the sub-strings share everything but f0_hz
+                q_amp[j] = q_amp[0];
+                q_sh[j] = q_sh[0];
+                q_hd[j] = q_hd[0];
+                continue;
+            }
+            q_amp[j] = p.amp[fr];
             q_sh[j] = has_shifts ? p.shifts[fr * H + vk[j]] : (from_inh ? p.inh[fr] : 0.0f);
             q_hd[j] = p.hd[fr * H + vk[j]];
         }
     };
     float r_f0[VPL], r_sh[VPL];                    // the raw values x1 was formed from (held-note test at a frame boundary)
     auto frame_finish = [&](float* xf, float* xa) {
+        float one_plus_shift = 1.0f;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             r_f0[j] = q_f0[j];
             r_sh[j] = q_sh[j];
             float f = q_f0[j] * kmul[j];
             if (has_shifts) f = f * (1.0f + q_sh[j]);
-            else if (from_inh) f = f * (1.0f + shift_from_inharm(q_sh[j], kmul[j]));     // get_inharmonic_freq, per lane and frame
+            else if (from_inh) {                                                         // get_inharmonic_freq, per lane and frame
+                if (!(PAIR && j > 0)) one_plus_shift = 1.0f + shift_from_inharm(q_sh[j], kmul[j]);
+                f = f * one_plus_shift;
+            }
             const float a = q_amp[j] * q_hd[j];
             xf[j] = valid[j] ? f : 0.0f;
             xa[j] = valid[j] ? a : 0.0f;
@@ -167,6 +186,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     const float f_big = 3900.0f * sr;              // 1008 samples of omega(f_big) stay below 2.6e7 rad
     auto classify_frame = [&]() {
         bool ok = true, msk = false, cst = true;
+        bool gone_j[VPL];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
@@ -174,15 +194,20 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
             // above Nyquist for the whole frame pair: masked once, here (a0 / a1 themselves stay as they are: the
             // next pair starts from the unmasked a1)
             const bool gone = lo >= nyq;
+            gone_j[j] = gone;
             am0[j] = gone ? 0.0f : a0[j];
             da[j] = gone ? 0.0f : a1[j] - a0[j];
             msk = msk || (lo < nyq && hi >= nyq);
             cst = cst && (x0[j] == x1[j]);
             om_c[j] = omega_of<false>(x0[j], sr, rsr);
         }
+        // PAIR: the shared cross-fade needs both sub-strings of every lane on the same side of Nyquist for the whole frame
+        // pair; a frame where they are not (a partial inside the detune gap) takes the masked moving path, which keeps
+        // the amplitudes apart (x0 + 0 * w = x0: the same phases, whatever the frame's frequencies do)
+        if (PAIR) msk = msk || (gone_j[0] != gone_j[VPL - 1]);
         fast = __all(ok) && p.fastdiv;
         need_mask = __any(msk);
-        const_freq = __all(cst);
+        const_freq = __all(cst) && !(PAIR && need_mask);
     };
 
     int t = n_begin / U, r = n_begin - t * U;
@@ -271,6 +296,14 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
             for (int j = 0; j < VPL; ++j) er[j] = e_blk[j];
         }
+        if constexpr (PAIR && !MASK) {
+            // the two sub-strings of a (voice, harmonic) under ONE cross-fade (classify_frame: same side of Nyquist)
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) {
+                const float a = __builtin_fmaf(da[0], w1[i], am0[0]);
+                acc[i] = a * (pv[i][0] + pv[i][1]);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) {
             float a = __builtin_fmaf(da[0], w1[i], am0[0]);
@@ -293,6 +326,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
                 acc[i] = __builtin_fmaf(a, pv[i][j], acc[i]);
             }
+        }
         if constexpr (DECAY) {
 #pragma unroll
             for (int j = 0; j < VPL; ++j) e_blk[j] = e_blk[j] * d0_8[j];
@@ -480,7 +514,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 }
 
 // One wavefront per workgroup: slots past the audible set exit at once and give their place to the next workgroup.
-template <int VPL, bool DECAY = false>
+template <int VPL, bool DECAY = false, bool PAIR = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bank_compact_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
@@ -497,7 +531,8 @@ bank_compact_kernel(const OscParams p) {
     const int c0 = c.span * p.cps, c1 = min(c0 + p.cps, p.nchunks);
     c.n_begin = c0 * DDSPP_CHUNK;
     c.n_end = min(c1 * DDSPP_CHUNK, p.N);
-    const int lane = c.lane, S = p.S;
+    const int lane = c.lane, S = PAIR ? 1 : p.S;             // (PAIR: one packed entry per (voice, harmonic), both sub-strings)
+    constexpr int CAP = PAIR ? 64 : 64 * VPL;                // packed entries a slot carries
 
     // ---- which oscillators this slot carries ------------------------------------------------------------------
     // The audible oscillators of the segment's (voice, sub-string) rows are packed back to back: sub-row q
@@ -516,11 +551,11 @@ bank_compact_kernel(const OscParams p) {
     const int total_b = __shfl(incl, 63) - total_a;
     if (c.cw_all == 0 && lane == 0) {
         int* wc = p.wcount + ((size_t)c.row * p.spans + c.span) * 2;
-        wc[0] = (total_a + 64 * VPL - 1) / (64 * VPL);
-        wc[1] = (total_b + 64 * VPL - 1) / (64 * VPL);
+        wc[0] = (total_a + CAP - 1) / CAP;
+        wc[1] = (total_b + CAP - 1) / CAP;
     }
     c.total = in_b ? total_b : total_a;
-    c.first = 64 * VPL * cw;
+    c.first = CAP * cw;
     if (c.first >= c.total) return;                          // nothing audible left for this slot
     c.qlo = in_b ? Qa : 0;
     c.qhi = in_b ? Q : Qa;
@@ -534,7 +569,9 @@ bank_compact_kernel(const OscParams p) {
         const int q = i >> 2;
         (q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE))[i & 3] = p.whann[i];
     }
-    if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
+    if constexpr (PAIR)
+        bank_slot<2, false, true>(p, tile, c);
+    else if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
         bank_slot<2, DECAY>(p, tile, c);
     else
         bank_slot<1, DECAY>(p, tile, c);
@@ -569,6 +606,175 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Compacted scan of the chunks whose frequencies move (round 5; OscParams::scan_tasks).  The span starts of the bank are
+// running sums of chunk END PHASES e[c] = (sum of the chunk's 1000 omegas, sequentially in float32) % 2 pi of every chunk
+// before the span (ddsp.core.angular_cumsum).  osc_prepass_fused_kernel memoises the chunks of held notes; a chunk in
+// which some frequency of the segment moves is listed by osc_count_frames_kernel and scanned HERE, sample by sample, with
+// the bank's packing: the oscillators of a segment that are audible anywhere in their row, voices back to back, 64 VPL to
+// a wavefront -- instead of one wavefront per (row, 64 harmonics), which at a piano's note mix has 1.7 lanes per audible
+// partial.  A persistent grid walks the task list (its length is only known on the device: no tasks -- held notes -- and
+// the wavefronts leave at once).  Same arithmetic, same order, same bits as the pre-pass's own moving branch
+// (scan_block_staged); rows that are constant in a listed chunk are written by both kernels with the same values.
+template <int VPL>
+__global__ void __launch_bounds__(64) bank_scan_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
+    int* offs = reinterpret_cast<int*>(lds_dyn);             // [64] exclusive offsets of the sub-rows of the segment
+    float* wlds = lds_dyn + 64;                              // [PRE_W] interpolation weights of the frame being scanned
+    const int lane = threadIdx.x & 63;
+    const int ntasks = wave_uniform(*p.scan_ntasks);
+    const int S = p.S, H = p.H, T = p.T, U = p.U, N = p.N, Q = p.P * S;
+    const bool has_shifts = p.shifts != nullptr, from_inh = !has_shifts && p.inh != nullptr;
+    const float srv = in_vgpr(p.sr), rsrv = in_vgpr(p.rsr);
+    // tasks are handed out dynamically (one atomic per task): a listed (segment, chunk) brings ALL its slots, those past the
+    // segment's audible set are empty, and a fixed stride would give some wavefronts only empty tasks and others only full ones
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = atomicAdd(p.scan_ntasks + 1, 1);
+        task = wave_uniform(task);
+        if (task >= ntasks) break;
+        const int code = wave_uniform(p.scan_tasks[task]);
+        const int slot = code % p.scan_slots, bc = code / p.scan_slots;
+        const int c = bc % p.npre, seg = bc / p.npre;
+        // ---- the packed list of the segment: sub-row q (voice, sub-string) contributes its first rowmax harmonics ----
+        int len = 0;
+        if (lane < Q) {
+            const int v = lane / S;
+            len = p.rowmax[p.vmajor ? v * p.R + seg : seg * p.P + v];
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int total = __shfl(incl, 63);
+        const int first = 64 * VPL * slot;
+        if (first >= total) continue;                        // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        offs[lane] = incl - len;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int vk[VPL], vs[VPL], lrow[VPL], vidx[VPL];
+        bool valid[VPL];
+        float kmul[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int g = first + lane + 64 * j;
+            const int gc = min(g, total - 1);
+            int q = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (q + step < Q && offs[q + step] <= gc) q += step;
+            const int k = gc - offs[q];
+            lrow[j] = p.vmajor ? (q / S) * p.R + seg : seg * p.P + q / S;
+            vs[j] = q - (q / S) * S;
+            vk[j] = k;
+            vidx[j] = vs[j] * H + k;
+            valid[j] = g < total;
+            kmul[j] = (float)(k + 1);
+        }
+        auto hf_raw = [&](int tt, float* rf, float* rs) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const size_t fr = (size_t)lrow[j] * T + tt;
+                rf[j] = p.f0[fr * S + vs[j]];
+                rs[j] = has_shifts ? p.shifts[fr * H + vk[j]] : (from_inh ? p.inh[fr] : 0.0f);
+            }
+        };
+        auto hf_calc = [&](const float* rf, const float* rs, float* xf) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                float f = rf[j] * kmul[j];
+                if (has_shifts) f = f * (1.0f + rs[j]);
+                else if (from_inh) f = f * (1.0f + shift_from_inharm(rs[j], kmul[j]));
+                xf[j] = valid[j] ? f : 0.0f;
+            }
+        };
+        // ---- the chunk, frame by frame (osc_prepass_fused_kernel's moving branch) ----------------------------------
+        const int n_lo = c * DDSPP_CHUNK, n_hi = min(n_lo + DDSPP_CHUNK, N);
+        int tt = n_lo / U, r = n_lo - tt * U;
+        float ph[VPL], x0[VPL], x1[VPL], qf[VPL], qs[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) ph[j] = 0.0f;
+        {
+            float rf[VPL], rs[VPL];
+            hf_raw(tt, rf, rs);
+            hf_calc(rf, rs, x0);
+            hf_raw(min(tt + 1, T - 1), rf, rs);
+            hf_calc(rf, rs, x1);
+        }
+        hf_raw(min(tt + 2, T - 1), qf, qs);
+        auto pair_ok = [&]() {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const float lo = fminf(x0[j], x1[j]), hi = fmaxf(x0[j], x1[j]);
+                ok = ok && (lo > 1e-28f || (lo == 0.0f && (hi == 0.0f || hi > 1e-24f))) && (hi < 3.0e38f);
+            }
+            return p.fastdiv && __all(ok);
+        };
+        bool fast = pair_ok();
+        auto stage_weights = [&](int n_first) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int idx = lane * 4;
+            if (n_first + idx < n_hi)
+                *reinterpret_cast<float4*>(wlds + idx) = *reinterpret_cast<const float4*>(p.wlin + n_first + idx);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        float wl[BLK], wn[BLK];
+        auto weights_at = [&](int off, float* w) {
+            const float4 wa = *reinterpret_cast<const float4*>(wlds + off);
+            const float4 wb = *reinterpret_cast<const float4*>(wlds + off + 4);
+            w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w;
+            w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+        };
+        for (int n = n_lo; n < n_hi;) {
+            const int nf = min(n + min(U - r, PRE_W), n_hi);
+            stage_weights(n);
+            weights_at(0, wl);
+            auto blocks = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                int woff = 0;
+                for (; n + BLK < nf; n += BLK) {
+                    weights_at(woff + BLK, wn);
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<FAST>(ph[j], x0[j], x1[j], wl, srv, rsrv, false);
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i) wl[i] = wn[i];
+                    woff += BLK;
+                    r += BLK;
+                }
+                const bool nxt = r + BLK == U &&
+                                 __builtin_amdgcn_readfirstlane(__float_as_int(wl[BLK - 1])) == __float_as_int(WALK_NEXT_ROW);
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) ph[j] = scan_block_staged<FAST>(ph[j], x0[j], x1[j], wl, srv, rsrv, nxt);
+                n += BLK;
+                r += BLK;
+            };
+            if (fast) blocks(std::true_type{});
+            else blocks(std::false_type{});
+            if (r == U) {
+                r = 0;
+                ++tt;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) x0[j] = x1[j];
+                hf_calc(qf, qs, x1);
+                hf_raw(min(tt + 2, T - 1), qf, qs);
+                fast = pair_ok();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            if (valid[j]) p.echunk[((size_t)lrow[j] * p.npre + c) * p.VP + vidx[j]] = mod_2pi(ph[j]);
+    }
+}
+
 }  // namespace
 
 void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
@@ -580,7 +786,16 @@ void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
         return;
     }
     if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1>), grid, blk, lds, stream, p);
+    else if (p.pair) hipLaunchKernelGGL((bank_compact_kernel<2, false, true>), grid, blk, lds, stream, p);
     else hipLaunchKernelGGL((bank_compact_kernel<2>), grid, blk, lds, stream, p);
+}
+
+void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream) {
+    // persistent grid: as many one-wavefront workgroups as the chip holds a few times over; the task count lives on the device
+    const size_t lds = (size_t)(64 + PRE_W) * sizeof(float);
+    const unsigned grid = (unsigned)ddspp_option("DDSPP_OSC_SCAN_WAVES", 4096);
+    if (vpl == 1) hipLaunchKernelGGL((bank_scan_kernel<1>), dim3(grid), dim3(64), lds, stream, p);
+    else hipLaunchKernelGGL((bank_scan_kernel<2>), dim3(grid), dim3(64), lds, stream, p);
 }
 
 void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, hipStream_t stream) {

@@ -44,6 +44,7 @@ struct OscParams {
     // compacted bank (bank_compact.hip): slots [0, wmax_a) carry the audible oscillators of voices [0, P - split_last),
     // slots [wmax_a, wmax) those of the last voice (split_last = 1: the caller wants that voice's stem on its own)
     int split_last, wmax_a;
+    int pair;                          // S = 2 and two oscillators per lane: a lane carries both sub-strings of a (voice, harmonic) (bank_slot<2, false, PAIR>; DDSPP_OSC_PAIR)
     int half_slots;                    // a 128-oscillator slot with <= 64 oscillators left runs the 64-oscillator body (DDSPP_OSC_HALF_SLOTS)
     int held_skip;                     // frame boundaries of held notes skip the frequency / classification work (DDSPP_OSC_HELD_SKIP)
     float* __restrict__ out_last;      // [B, N] the last voice's stem (split_last = 1), `out` then holds the other voices' sum
@@ -53,6 +54,16 @@ struct OscParams {
     // the span-start walk normally leaves out 64-oscillator groups that are silent in every frame of the call (nothing
     // reads their start phases); need_all = 1 walks them too: a carried phase state must cover every oscillator
     int need_all;
+    // Compacted scan of moving chunks (round 5).  The span starts need the end phase of EVERY chunk before them.  Chunks of
+    // held notes are memoised by the pre-pass (osc_prepass_fused_kernel); chunks in which some frequency moves have to be
+    // scanned sample by sample, and the pre-pass does that with one wavefront per (row, 64 harmonics) -- 1.7 x the lanes a
+    // piano's audible partials fill.  With skip_moving the pre-pass leaves those chunks alone and bank_scan_kernel scans
+    // them with the bank's packing (lanes only for harmonics below the row's audible maximum, voices back to back):
+    // scan_tasks [<= B * npre * scan_slots] = (segment * npre + chunk) * scan_slots + slot, appended by the count kernel
+    // for every (segment, chunk) in which a voice's frequencies move; scan_ntasks: their number (device).
+    int* __restrict__ scan_tasks;
+    int* __restrict__ scan_ntasks;
+    int scan_slots, skip_moving;
     // SurrogateAdditive (surrogate_synth.py:76-95): per-harmonic exponential decay of the amplitude envelopes,
     // |decays[t, k]| ** (decay_time[t] * U + n % U) with t = n / U (the frame's values repeated, not interpolated); null = none
     const float* __restrict__ decays;      // [R, T, H]
@@ -97,8 +108,58 @@ __device__ __forceinline__ float omega_of(float fe, float sr, float rsr) {
 }
 
 
+constexpr int PRE_W = 256;              // floats of LDS per wavefront: the interpolation weights of the next PRE_W samples (scans)
+
+// BLK samples of the phase scan `ph += omega(x0 + (x1 - x0) * w[i])` for one oscillator per lane, in stages that keep
+// BLK independent chains in flight: interpolate all BLK frequencies, scale them all, divide them all, and only then
+// the BLK dependent adds.  Written sample after sample the compiler funnels every omega through the same two
+// temporaries -- one dependent chain of forty instructions per step, and a dependent wave64 instruction issues every
+// 4.4 cycles instead of 2.3 whatever the other wavefronts of the SIMD do (tools/ubench/valu_latency): the
+// moving-frequency pre-pass ran at a third of the issue rate.  srv / rsrv: sample rate and its reciprocal in VECTOR
+// registers (an SGPR operand in a VOP3 fma costs 4.2 cycles).  Arithmetic and order are those of omega_of.
+template <bool FAST>
+__device__ __forceinline__ float scan_block_staged(float ph, float x0, float x1, const float* w, float srv, float rsrv,
+                                                   bool next_row = false) {
+    float om[BLK], q[BLK];
+    const float dx = x1 - x0;
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = dx * w[i];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = x0 + om[i];
+    if (next_row) {                       // wave-uniform: the frame's last block holds marked samples (osc_common.h)
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = (w[i] == WALK_NEXT_ROW) ? x1 : om[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) om[i] = om[i] * DDSPP_TWO_PI_F32;          // inharm_synth.py:69
+    if (FAST) {                                                              // :70, div_const (ddspp_common.h)
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) q[i] = om[i] * rsrv;
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(-q[i], srv, om[i]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(om[i], rsrv, q[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) om[i] = om[i] / srv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) ph = ph + om[i];
+    __builtin_amdgcn_sched_barrier(0);
+    return ph;
+}
+
+__device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value copied into a vector register
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
 // compacted polyphonic bank: launches of bank_compact.hip (p.out = partial rows, see ddspp_polyphonic_additive)
 void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream);
 void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, hipStream_t stream);
+// compacted scan of the chunks whose frequencies move (bank_scan_kernel; p as for launch_bank_compact + the scan_* fields)
+void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream);
 
 }  // namespace ddspp

@@ -552,52 +552,6 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
 // business: with one workgroup per (row, group) (round 2) all 2048 workgroups were resident at once, a CU that drew seven
 // moving ones worked 1.8x the average and the chip waited for it (VALU issue fraction 0.43).  Five sections are 10240
 // workgroups of a sixth of the length, handed out as earlier ones finish.
-// BLK samples of the phase scan `ph += omega(x0 + (x1 - x0) * w[i])` for one oscillator per lane, in stages that keep
-// BLK independent chains in flight: interpolate all BLK frequencies, scale them all, divide them all, and only then
-// the BLK dependent adds.  Written sample after sample the compiler funnels every omega through the same two
-// temporaries -- one dependent chain of forty instructions per step, and a dependent wave64 instruction issues every
-// 4.4 cycles instead of 2.3 whatever the other wavefronts of the SIMD do (tools/ubench/valu_latency): the
-// moving-frequency pre-pass ran at a third of the issue rate.  srv / rsrv: sample rate and its reciprocal in VECTOR
-// registers (an SGPR operand in a VOP3 fma costs 4.2 cycles).  Arithmetic and order are those of omega_of.
-template <bool FAST>
-__device__ __forceinline__ float scan_block_staged(float ph, float x0, float x1, const float* w, float srv, float rsrv,
-                                                   bool next_row = false) {
-    float om[BLK], q[BLK];
-    const float dx = x1 - x0;
-#pragma unroll
-    for (int i = 0; i < BLK; ++i) om[i] = dx * w[i];
-#pragma unroll
-    for (int i = 0; i < BLK; ++i) om[i] = x0 + om[i];
-    if (next_row) {                       // wave-uniform: the frame's last block holds marked samples (osc_common.h)
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) om[i] = (w[i] == WALK_NEXT_ROW) ? x1 : om[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BLK; ++i) om[i] = om[i] * DDSPP_TWO_PI_F32;          // inharm_synth.py:69
-    if (FAST) {                                                              // :70, div_const (ddspp_common.h)
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) q[i] = om[i] * rsrv;
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(-q[i], srv, om[i]);
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) om[i] = __builtin_fmaf(om[i], rsrv, q[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < BLK; ++i) om[i] = om[i] / srv;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < BLK; ++i) ph = ph + om[i];
-    __builtin_amdgcn_sched_barrier(0);
-    return ph;
-}
-
-__device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value copied into a vector register
-    float v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
-    return v;
-}
-
 // max over the frames of a row of the per-frame audible-harmonic counts (low 16 bits of `audible`), twelve loads in
 // flight per lane: a wavefront that starts with this pays one memory latency for a 3 s row, not twelve
 __device__ __forceinline__ int row_audible_max(const int* __restrict__ aud, int T, int lane) {
@@ -617,7 +571,6 @@ __device__ __forceinline__ int row_audible_max(const int* __restrict__ aud, int 
     return amax;
 }
 
-constexpr int PRE_W = 256;              // floats of LDS per wavefront: the interpolation weights of the next PRE_W samples
 template <int VPL, int PARTS>
 __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
@@ -793,6 +746,7 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
         // no change in (t_lo, t_hi] <=> every frame the chunk touches carries the same frequencies
         const bool chunk_const = (t_checked >= t_hi) && (last_change <= t_lo);
         float e[VPL];
+        if (PARTS > 1 && !chunk_const && p.skip_moving) continue;     // bank_scan_kernel writes this chunk's end phases
         if (chunk_const && memo_t >= 0 && last_change <= memo_t) {
 #pragma unroll
             for (int j = 0; j < VPL; ++j) e[j] = e_memo[j];
@@ -1269,7 +1223,9 @@ __global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict_
 // (row, span), a dozen ints instead of a [frames, H] scan.
 __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __restrict__ audible, int* __restrict__ nk,
                                                              int R, int P, int T, int U, int N, int spans, int cps,
-                                                             int vmajor) {
+                                                             int vmajor, int* __restrict__ rowmax_out,
+                                                             int* __restrict__ chunk_flag, int* __restrict__ tasks,
+                                                             int* __restrict__ ntasks, int npre, int nslots) {
     const int task = blockIdx.x * 256 + threadIdx.x;
     if (task >= R * spans) return;
     const int row = task / spans, span = task - row * spans;
@@ -1280,6 +1236,22 @@ __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __rest
     const int B = R / P;
     const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
     nk[((size_t)b * spans + span) * P + v] = best;
+    if (!rowmax_out) return;
+    // (round 5) the row's maximum over all its spans, and the chunks of this span in which the row's frequencies move
+    // (bit 16 of a frame's count: its frequencies differ from the frame before): the first row of a segment to find one
+    // appends the (segment, chunk)'s slots to the task list of bank_scan_kernel.  The test is osc_prepass_fused_kernel's
+    // `chunk_const`: no change in frames (t_lo, t_hi] of the chunk.
+    if (best > rowmax_out[row]) atomicMax(&rowmax_out[row], best);     // (a stale read only costs an atomic: the maximum is monotonic)
+    for (int c = span * cps; c < min((span + 1) * cps, npre); ++c) {
+        const int cn_lo = c * DDSPP_CHUNK, cn_hi = min(cn_lo + DDSPP_CHUNK, N);
+        const int ct_lo = cn_lo / U, ct_hi = min((cn_hi - 1) / U + 1, T - 1);
+        int moved = 0;
+        for (int t = ct_lo + 1; t <= ct_hi; ++t) moved |= audible[(size_t)row * T + t] >> 16;
+        if ((moved & 1) && atomicOr(&chunk_flag[(size_t)b * npre + c], 1) == 0) {
+            const int base = atomicAdd(ntasks, nslots);
+            for (int sl = 0; sl < nslots; ++sl) tasks[base + sl] = (b * npre + c) * nslots + sl;
+        }
+    }
 }
 
 static bool sample_rate_is_checked(float sr) {
@@ -1376,6 +1348,7 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
 static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* echunk, hipStream_t stream) {
     const size_t ldsw = (size_t)4 * PRE_W * sizeof(float);              // weight buffers of the four wavefronts
     const bool parts4 = vpl <= 2 && echunk && q0.npre >= 8 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
+    // (skip_moving is only set where this holds: polyphonic_additive_impl tests the same conditions)
     if (parts4) {
         OscParams q = q0;
         // runs of about six chunks per wavefront: short enough to balance, long enough that the held-note case (one
@@ -1386,6 +1359,11 @@ static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* 
         q.echunk = echunk;
         if (vpl == 1) hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
         else hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 4>), dim3(tasks * q.nsec), dim3(256), ldsw, stream, q);
+        if (q.skip_moving) {               // the chunks the pre-pass left alone (frequencies moving), packed like the bank
+            OscParams b = q;
+            b.R = q.R / q.P;               // segments
+            launch_bank_scan(b, env_int("DDSPP_OSC_SCAN_VPL", 2), stream);
+        }
         if (q.npre > SCAN_CT)              // long rows: tiles through LDS, four wavefronts per (row, 64 oscillators)
             hipLaunchKernelGGL(osc_offset_scan_kernel, dim3(q.R * (q.VP / 64)), dim3(256), 0, stream, echunk, q.ework, q);
         else
@@ -1648,6 +1626,7 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
     return (2 * (size_t)B * P * nchunks * VP      /* astart + chunk end phases (worst case: one span per chunk) */
             + (size_t)B * nchunks * (P + 2)       /* nk + wcount */
             + (size_t)B * P                       /* per-row max of the audible counts */
+            + (size_t)B * nchunks * (wmax + 1) + 64   /* compacted scan: chunk flags, task list, counter */
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
@@ -1690,7 +1669,16 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     int* nk = (int*)(ework + (size_t)R * nchunks * VP);
     int* wcount = nk + (size_t)B * sp * P;
     int* rowmax = wcount + (size_t)B * sp * 2;
-    float* partial = (float*)(rowmax + R);
+    // compacted scan (osc_common.h: scan_tasks): [rowmax R | counter 1 (+ pad) | chunk flags B * npre | tasks B * npre * slots]:
+    // the first three are zeroed by ONE memset per call
+    const int npre_c = sp > 1 ? (sp - 1) * cps : 0;
+    const int scan_vpl = vpl_pre <= 2 ? 2 : 0;            // (the pre-pass takes sections of four wavefronts up to 128 oscillators per row)
+    const int scan_lanes = 64 * (env_int("DDSPP_OSC_SCAN_VPL", 2) == 1 ? 1 : 2);      // oscillators per scan task
+    const int scan_slots = scan_vpl ? (P * V + scan_lanes - 1) / scan_lanes : 0;
+    int* scan_ntasks = rowmax + R;
+    int* chunk_flag = scan_ntasks + 16;
+    int* scan_tasks = chunk_flag + (size_t)B * npre_c;
+    float* partial = (float*)(scan_tasks + (size_t)B * npre_c * scan_slots);
     partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
 
     OscParams p{};
@@ -1708,19 +1696,35 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     p.off_plain = env_int("DDSPP_ANGULAR_OFFSETS_PLAIN", 0) ? 1 : 0;
     p.astart = astart;
 
-    // 1. span start offsets for every (row, oscillator) over rows = B * P
+    // The chunks in which some frequency moves are scanned by bank_scan_kernel, packed like the bank (round 5): when the
+    // per-frame counts and flags of get_controls are there, the sectioned memo pre-pass is the one that runs (same test as
+    // launch_memo_prepass), nothing asks for every oscillator's state, and there are chunks to pre-pass at all
+    const bool compact_scan = audible && !p.dbg_noflags && scan_vpl && npre_c >= 8 && sp > 1 && !p.state_in && S * H == V &&
+                              V % 64 == 0 && env_int("DDSPP_OSC_COMPACT_SCAN", 1) && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0) &&
+                              !env_int("DDSPP_OSC_PLAIN_PREPASS", 0) && R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256);
+    // 1. audible-harmonic counts per (segment, span, voice) (+ with the compacted scan: row maxima and the scan's task list)
+    if (compact_scan) {
+        DDSPP_HIP_CHECK(hipMemsetAsync(rowmax, 0, ((size_t)R + 16 + (size_t)B * npre_c) * sizeof(int), stream));
+        hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
+                           P, T, U, N, sp, cps, voice_major, rowmax, chunk_flag, scan_tasks, scan_ntasks, npre_c, scan_slots);
+        p.rowmax = rowmax;
+        p.scan_tasks = scan_tasks; p.scan_ntasks = scan_ntasks; p.scan_slots = scan_slots; p.skip_moving = 1;
+        p.P = P; p.vmajor = voice_major ? 1 : 0;          // (the scan kernel packs the voices of a segment: it reads both)
+    }
+    // 2. span start offsets for every (row, oscillator) over rows = B * P
     if (sp > 1 || p.state_in) {
-        if (audible && T > 1536) {         // which 64-oscillator groups are never heard: asked by every wavefront below --
+        if (audible && T > 1536 && !compact_scan) {   // which 64-oscillator groups are never heard: asked by every wavefront below --
             // of a long row in a kernel of its own (a 3 s row is twelve loads in flight per wavefront: cheaper than a launch)
             hipLaunchKernelGGL(osc_row_max_kernel, dim3(R), dim3(256), 0, stream, audible, rowmax, T);
             p.rowmax = rowmax;
         }
         span_starts(p, R, V, vpl_pre, astart, ework, stream);
     }
-    // 2. audible-harmonic counts per (segment, span, voice)
-    if (audible)
+    p.skip_moving = 0;
+    if (compact_scan) {
+    } else if (audible)
         hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
-                           P, T, U, N, sp, cps, voice_major);
+                           P, T, U, N, sp, cps, voice_major, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0);
     else
         hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
                            harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
@@ -1730,6 +1734,7 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     p.R = B; p.groups = 1; p.vgrp = 64; p.P = P; p.wmax = wmax; p.nslots = wmax; p.vmajor = voice_major ? 1 : 0;
     p.split_last = split_last; p.wmax_a = wmax_a;
     p.half_slots = env_int("DDSPP_OSC_HALF_SLOTS", 1);
+    p.pair = (S == 2 && vpl_c == 2 && !decays && env_int("DDSPP_OSC_PAIR", 1)) ? 1 : 0;
     p.held_skip = env_int("DDSPP_OSC_HELD_SKIP", 1);
     p.nk = nk; p.wcount = wcount; p.out = partial;
     launch_bank_compact(p, vpl_c, stream);

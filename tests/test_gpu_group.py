@@ -452,6 +452,77 @@ def test_compacted_additive_equals_voice_stems():
     assert out.shape == (2, 1920) and (out == 0).all()
 
 
+def test_paired_substrings_in_the_compacted_bank(monkeypatch):
+    """Round 5: with two sub-strings (dafx22 configs, default_model.py) a lane of the compacted bank carries BOTH sub-strings of
+    one (voice, harmonic) and evaluates one Hann cross-fade for the pair, a (cos0 + cos1) -- MultiInharmonic shares amplitudes,
+    distribution and shifts between them (inharm_synth.py:279-292).  Against the unpaired kernel (DDSPP_OSC_PAIR=0), the
+    per-voice stems and the oracle; held notes, moving notes, and a partial that lies in the detune gap around Nyquist (one
+    sub-string audible, the other masked by remove_above_nyquist: the pair falls back to separate amplitudes)."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(52)
+    set_option(monkeypatch, 'DDSPP_OSC_COMPACT_VPL1_BELOW', '0')          # two oscillators per lane even for these few rows
+    keys = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    for (B, P, T, H, sr, moving) in [(2, 5, 40, 96, 16000, False), (3, 16, 30, 128, 24000, True), (1, 32, 30, 64, 16000, False)]:
+        U, S = sr // 250, 2
+        N, R = T * U, B * P
+        raw = synth_controls(rng, R, T, H, S=S, silent_frac=0.2, midi_lo=40 if moving else 21, midi_hi=100)
+        if moving:      # vibrato + a glide: partials cross Nyquist inside frames, the two sub-strings at different samples
+            tt = np.arange(T, dtype=np.float32)[None, :, None]
+            raw['f0_hz'] = (raw['f0_hz'] * (1 + 0.004 * np.sin(0.13 * tt + rng.uniform(0, 6, [R, 1, 1])) - 0.0015 * tt)).astype(np.float32)
+        syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+        dev = [torch.as_tensor(raw[k], device='cuda') for k in keys]
+        ctl = syn._controls(*dev, want_counts=True)
+        amp = ctl['amplitudes'].reshape(R, T).contiguous()
+        args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr)
+        stems = core.harmonic_synthesis_fused(*args[:4], N, sr, True).reshape(B, P, N)
+        for spans in (0, 1, 5):
+            set_option(monkeypatch, 'DDSPP_OSC_PAIR', '0')
+            plain = core.polyphonic_additive(*args, spans=spans, audible=ctl['_audible'])
+            set_option(monkeypatch, 'DDSPP_OSC_PAIR')
+            mix = core.polyphonic_additive(*args, spans=spans, audible=ctl['_audible'])
+            scale = max(1.0, float(plain.abs().max()))
+            assert (mix - plain).abs().max().item() < 2e-6 * scale, (B, P, H, spans)       # a c0 + a c1 against a (c0 + c1)
+            assert (mix - stems.sum(dim=1)).abs().max().item() < 4e-6 * scale, (B, P, H, spans)
+            rest, last_v = core.polyphonic_additive(*args, spans=spans, audible=ctl['_audible'], split_last=True)
+            assert (last_v - stems[:, P - 1]).abs().max().item() < 3e-6 * scale
+            assert (rest - stems[:, :P - 1].sum(dim=1)).abs().max().item() < 4e-6 * scale
+            vm = [x.reshape((B, P) + x.shape[1:]).transpose(0, 1).reshape(x.shape).contiguous() for x in args[:4]]
+            cnt_vm = ctl['_audible'].reshape(B, P, T).transpose(0, 1).reshape(R, T).contiguous()
+            assert torch.equal(core.polyphonic_additive(*vm, B, N, sr, spans=spans, voice_major=True, audible=cnt_vm), mix)
+            inh_raw = dev[2].reshape(R, T).contiguous()                                       # shifts formed in the kernel
+            mix_inh = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], None, B, N, sr, spans=spans,
+                                               audible=ctl['_audible'], inharm_coef=inh_raw)
+            assert torch.equal(mix_inh, mix), (B, P, H, spans)
+        osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
+        ref = osyn(*[raw[k][:P] for k in keys]).sum(0)                                         # segment 0 against the oracle
+        assert rms_err(mix[0].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), (B, P, H)
+    # the detune gap: harmonic 12 of sub-string 0 at 11 999.88 Hz (audible), of sub-string 1 at 12 000 Hz = Nyquist (masked
+    # by cos_oscillator_bank, inharm_synth.py:65-67; get_controls cuts by sub-string 0 only, :185-187)
+    B, P, T, H, sr = 4, 2, 25, 16, 24000
+    R, N = B * P, T * 96
+    raw = synth_controls(rng, R, T, H, S=2, silent_frac=0.0)
+    raw['f0_hz'][..., 0], raw['f0_hz'][..., 1] = np.float32(999.99), np.float32(1000.0)
+    raw['f0_hz'][1::2] *= np.float32(0.5)                                                      # every other voice: far from the gap
+    raw['inharm_coef'][:] = 0.0
+    syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+    dev = [torch.as_tensor(raw[k], device='cuda') for k in keys]
+    ctl = syn._controls(*dev, want_counts=True)
+    assert int((ctl['_audible'][0] & 0xffff).max()) == 12                                      # harmonic 12 is the last one kept
+    amp = ctl['amplitudes'].reshape(R, T).contiguous()
+    mix = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr,
+                                   audible=ctl['_audible'])
+    osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
+    for b in range(B):
+        ref = osyn(*[raw[k][b * P:(b + 1) * P] for k in keys]).sum(0)
+        assert rms_err(mix[b].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), b
+    # ... and it matters: with sub-string 1's harmonic 12 left in, the audio is another one
+    set_option(monkeypatch, 'DDSPP_OSC_PAIR', '0')
+    plain = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr,
+                                     audible=ctl['_audible'])
+    assert (mix - plain).abs().max().item() < 2e-6 * max(1.0, float(plain.abs().max()))
+
+
 def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
     """Every frame's frequencies move (vibrato + glide, some partials gliding through Nyquist): the memoised pre-pass
     scans every chunk sample by sample, sections of four wavefronts per (row, 64 oscillators) sharing the chunks.  Same start
@@ -494,6 +565,50 @@ def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):
         one_seg = core.polyphonic_additive(*[a[:P].contiguous() for a in args[:4]], 1, N, sr)     # compact kernel, 1 segment
         ref_seg = osyn(*[raw[k][:P] for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]).sum(0)
         assert rms_err(one_seg.cpu().numpy()[0], ref_seg) < TOL, nbn
+
+
+def test_compacted_scan_of_moving_chunks(monkeypatch):
+    """Round 5: the chunks in which a segment's frequencies move are scanned by bank_scan_kernel with the bank's packing
+    (lanes for the harmonics below each row's audible maximum, voices back to back) instead of one wavefront per (row, 64
+    harmonics); held chunks stay with the memoised pre-pass.  Same span starts, bit for bit, as the pre-pass alone
+    (DDSPP_OSC_COMPACT_SCAN=0): batches that mix held, moving and silent voices, notes that move only for a part of the
+    segment, two sub-strings, voice-major rows, the last voice kept apart."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(77)
+    keys = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
+    for (B, P, T, H, S, sr) in [(64, 4, 120, 128, 1, 24000), (32, 8, 150, 96, 2, 16000), (16, 16, 125, 64, 1, 24000)]:
+        U = sr // 250
+        N, R = T * U, B * P
+        raw = synth_controls(rng, R, T, H, S=S, silent_frac=0.15, midi_lo=30, midi_hi=100)
+        tt = np.arange(T, dtype=np.float32)[None, :, None]
+        kind = rng.integers(0, 3, size=[R, 1, 1])                 # 0: held, 1: vibrato all along, 2: a glide in the middle third only
+        vib = 1 + 0.004 * np.sin(0.13 * tt + rng.uniform(0, 6, [R, 1, 1]))
+        glide = 1 + 0.02 * np.clip((tt - T / 3) / (T / 3), 0, 1)
+        raw['f0_hz'] = (raw['f0_hz'] * np.where(kind == 1, vib, np.where(kind == 2, glide, 1.0))).astype(np.float32)
+        syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+        dev = [torch.as_tensor(raw[k], device='cuda') for k in keys]
+        ctl = syn._controls(*dev, want_counts=True, want_shifts=False)
+        amp = ctl['amplitudes'].reshape(R, T).contiguous()
+        inh = ctl['_inharm_coef'].reshape(R, T)
+        kw = dict(audible=ctl['_audible'], inharm_coef=inh)
+        args = (ctl['f0_hz'], amp, ctl['harmonic_distribution'], None, B, N, sr)
+        set_option(monkeypatch, 'DDSPP_OSC_COMPACT_SCAN', '0')
+        want = core.polyphonic_additive(*args, **kw)
+        want_rest, want_last = core.polyphonic_additive(*args, split_last=True, **kw)
+        set_option(monkeypatch, 'DDSPP_OSC_COMPACT_SCAN')
+        got = core.polyphonic_additive(*args, **kw)
+        assert torch.equal(got, want), (B, P, T, H, S)
+        rest, last_v = core.polyphonic_additive(*args, split_last=True, **kw)
+        assert torch.equal(rest, want_rest) and torch.equal(last_v, want_last), (B, P, T, H, S)
+        vm = [x.reshape((B, P) + x.shape[1:]).transpose(0, 1).reshape(x.shape).contiguous()
+              for x in (ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['_audible'], inh)]
+        got_vm = core.polyphonic_additive(vm[0], vm[1], vm[2], None, B, N, sr, voice_major=True, audible=vm[3], inharm_coef=vm[4])
+        assert torch.equal(got_vm, got), (B, P, T, H, S)
+        # and against the oracle on one segment
+        osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
+        ref = osyn(*[raw[k][:P] for k in keys]).sum(0)
+        assert rms_err(got[0].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), (B, P, T, H, S)
 
 
 def test_parallelizer_views_feed_the_group_without_copies():
