@@ -613,35 +613,37 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
 // which some frequency of the segment moves is listed by osc_count_frames_kernel and scanned HERE, sample by sample, with
 // the bank's packing: the oscillators of a segment that are audible anywhere in their row, voices back to back, 64 VPL to
 // a wavefront -- instead of one wavefront per (row, 64 harmonics), which at a piano's note mix has 1.7 lanes per audible
-// partial.  A persistent grid walks the task list (its length is only known on the device: no tasks -- held notes -- and
-// the wavefronts leave at once).  Same arithmetic, same order, same bits as the pre-pass's own moving branch
+// partial.  A persistent grid walks (slot, segment, chunk); which chunks are flagged is only known on the device: none --
+// held notes -- and the wavefronts leave at once.  Same arithmetic, same order, same bits as the pre-pass's own moving branch
 // (scan_block_staged); rows that are constant in a listed chunk are written by both kernels with the same values.
+constexpr int SCAN_WQ = (DDSPP_CHUNK + 255) / 256;          // float4 loads per lane that cover a chunk's weights
 template <int VPL>
-__global__ void __launch_bounds__(64) bank_scan_kernel(const OscParams p) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
+bank_scan_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
     int* offs = reinterpret_cast<int*>(lds_dyn);             // [64] exclusive offsets of the sub-rows of the segment
-    float* wlds = lds_dyn + 64;                              // [PRE_W] interpolation weights of the frame being scanned
+    float* wlds = lds_dyn + 64;                              // [256 SCAN_WQ + 8] interpolation weights of the chunk being scanned
     const int lane = threadIdx.x & 63;
-    const int ntasks = wave_uniform(*p.scan_ntasks);
+    if (wave_uniform(*p.scan_ntasks) != p.scan_call) return;      // held notes: no row moves anywhere, nothing to scan
     const int S = p.S, H = p.H, T = p.T, U = p.U, N = p.N, Q = p.P * S;
     const bool has_shifts = p.shifts != nullptr, from_inh = !has_shifts && p.inh != nullptr;
     const float srv = in_vgpr(p.sr), rsrv = in_vgpr(p.rsr);
-    // tasks are handed out dynamically (one atomic per task): a listed (segment, chunk) brings ALL its slots, those past the
-    // segment's audible set are empty, and a fixed stride would give some wavefronts only empty tasks and others only full ones
-    for (;;) {
-        int task = 0;
-        if (lane == 0) task = atomicAdd(p.scan_ntasks + 1, 1);
-        task = wave_uniform(task);
-        if (task >= ntasks) break;
-        const int code = wave_uniform(p.scan_tasks[task]);
-        const int slot = code % p.scan_slots, bc = code / p.scan_slots;
-        const int c = bc % p.npre, seg = bc / p.npre;
+    // No atomics anywhere (a first version appended tasks to a list and handed them out with one counter: 70 000 atomics on
+    // one address cost more than the scan).  A task is (slot, segment, chunk), slot-major: a wavefront's tasks t = w, w + G,
+    // ... run through the slots, so every wavefront gets its share of the full low slots and of the empty high ones.
+    const int nentries = p.R * p.npre;
+    for (int task = blockIdx.x; task < nentries * p.scan_slots; task += gridDim.x) {
+        const int slot = task / nentries, bc = task - slot * nentries;
+        const int seg = bc / p.npre, c = bc - seg * p.npre;
         // ---- the packed list of the segment: sub-row q (voice, sub-string) contributes its first rowmax harmonics ----
-        int len = 0;
+        int len = 0, mv = 0;
         if (lane < Q) {
             const int v = lane / S;
-            len = p.rowmax[p.vmajor ? v * p.R + seg : seg * p.P + v];
+            const int vrow = p.vmajor ? v * p.R + seg : seg * p.P + v;
+            len = p.rowmax[vrow];
+            mv = p.scan_tasks[(size_t)vrow * p.npre + c];
         }
+        if (!__any(mv != 0)) continue;                       // no frequency of this segment moves in this chunk: the pre-pass has it
         int incl = len;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -717,16 +719,24 @@ __global__ void __launch_bounds__(64) bank_scan_kernel(const OscParams p) {
             return p.fastdiv && __all(ok);
         };
         bool fast = pair_ok();
-        auto stage_weights = [&](int n_first) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int idx = lane * 4;
-            if (n_first + idx < n_hi)
-                *reinterpret_cast<float4*>(wlds + idx) = *reinterpret_cast<const float4*>(p.wlin + n_first + idx);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
+        // the interpolation weights of the WHOLE chunk go through LDS at once (1000 floats: sixteen per lane, all loads in
+        // flight together): one memory latency per task -- staged frame by frame, as the pre-pass does with twice the
+        // wavefronts per SIMD, the scan waited for eleven of them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            float4 wq[SCAN_WQ];
+#pragma unroll
+            for (int u = 0; u < SCAN_WQ; ++u) {
+                const int idx = 4 * (lane + 64 * u);
+                wq[u] = (n_lo + idx < n_hi) ? *reinterpret_cast<const float4*>(p.wlin + n_lo + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_WQ; ++u) *reinterpret_cast<float4*>(wlds + 4 * (lane + 64 * u)) = wq[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float wl[BLK], wn[BLK];
         auto weights_at = [&](int off, float* w) {
             const float4 wa = *reinterpret_cast<const float4*>(wlds + off);
@@ -735,12 +745,11 @@ __global__ void __launch_bounds__(64) bank_scan_kernel(const OscParams p) {
             w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
         };
         for (int n = n_lo; n < n_hi;) {
-            const int nf = min(n + min(U - r, PRE_W), n_hi);
-            stage_weights(n);
-            weights_at(0, wl);
+            const int nf = min(n + (U - r), n_hi);
+            weights_at(n - n_lo, wl);
             auto blocks = [&](auto fast_tag) {
                 constexpr bool FAST = decltype(fast_tag)::value;
-                int woff = 0;
+                int woff = n - n_lo;
                 for (; n + BLK < nf; n += BLK) {
                     weights_at(woff + BLK, wn);
 #pragma unroll
@@ -792,8 +801,8 @@ void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
 
 void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream) {
     // persistent grid: as many one-wavefront workgroups as the chip holds a few times over; the task count lives on the device
-    const size_t lds = (size_t)(64 + PRE_W) * sizeof(float);
-    const unsigned grid = (unsigned)ddspp_option("DDSPP_OSC_SCAN_WAVES", 4096);
+    const size_t lds = (size_t)(64 + 256 * SCAN_WQ + 8) * sizeof(float);
+    const unsigned grid = (unsigned)ddspp_option("DDSPP_OSC_SCAN_WAVES", 8192);
     if (vpl == 1) hipLaunchKernelGGL((bank_scan_kernel<1>), dim3(grid), dim3(64), lds, stream, p);
     else hipLaunchKernelGGL((bank_scan_kernel<2>), dim3(grid), dim3(64), lds, stream, p);
 }

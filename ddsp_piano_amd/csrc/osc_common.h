@@ -59,11 +59,11 @@ struct OscParams {
     // scanned sample by sample, and the pre-pass does that with one wavefront per (row, 64 harmonics) -- 1.7 x the lanes a
     // piano's audible partials fill.  With skip_moving the pre-pass leaves those chunks alone and bank_scan_kernel scans
     // them with the bank's packing (lanes only for harmonics below the row's audible maximum, voices back to back):
-    // scan_tasks [<= B * npre * scan_slots] = (segment * npre + chunk) * scan_slots + slot, appended by the count kernel
-    // for every (segment, chunk) in which a voice's frequencies move; scan_ntasks: their number (device).
+    // scan_tasks [R rows, npre]: 1 where the row's frequencies move in the chunk, scan_ntasks[0] == scan_call when any row moves
+    // anywhere (both written by osc_count_rows_kernel, nothing to zero); scan_slots: slots of 64 VPL oscillators a segment may need.
     int* __restrict__ scan_tasks;
     int* __restrict__ scan_ntasks;
-    int scan_slots, skip_moving;
+    int scan_slots, skip_moving, scan_call;
     // SurrogateAdditive (surrogate_synth.py:76-95): per-harmonic exponential decay of the amplitude envelopes,
     // |decays[t, k]| ** (decay_time[t] * U + n % U) with t = n / U (the frame's values repeated, not interpolated); null = none
     const float* __restrict__ decays;      // [R, T, H]

@@ -24,6 +24,8 @@
 //   read exactly once) is the HBM-roofline configuration.
 #include <type_traits>
 
+#include <atomic>
+
 #include "osc_common.h"
 
 namespace ddspp {
@@ -1223,9 +1225,7 @@ __global__ void __launch_bounds__(256) osc_count_kernel(const float* __restrict_
 // (row, span), a dozen ints instead of a [frames, H] scan.
 __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __restrict__ audible, int* __restrict__ nk,
                                                              int R, int P, int T, int U, int N, int spans, int cps,
-                                                             int vmajor, int* __restrict__ rowmax_out,
-                                                             int* __restrict__ chunk_flag, int* __restrict__ tasks,
-                                                             int* __restrict__ ntasks, int npre, int nslots) {
+                                                             int vmajor) {
     const int task = blockIdx.x * 256 + threadIdx.x;
     if (task >= R * spans) return;
     const int row = task / spans, span = task - row * spans;
@@ -1236,22 +1236,44 @@ __global__ void __launch_bounds__(256) osc_count_frames_kernel(const int* __rest
     const int B = R / P;
     const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
     nk[((size_t)b * spans + span) * P + v] = best;
-    if (!rowmax_out) return;
-    // (round 5) the row's maximum over all its spans, and the chunks of this span in which the row's frequencies move
-    // (bit 16 of a frame's count: its frequencies differ from the frame before): the first row of a segment to find one
-    // appends the (segment, chunk)'s slots to the task list of bank_scan_kernel.  The test is osc_prepass_fused_kernel's
-    // `chunk_const`: no change in frames (t_lo, t_hi] of the chunk.
-    if (best > rowmax_out[row]) atomicMax(&rowmax_out[row], best);     // (a stale read only costs an atomic: the maximum is monotonic)
-    for (int c = span * cps; c < min((span + 1) * cps, npre); ++c) {
-        const int cn_lo = c * DDSPP_CHUNK, cn_hi = min(cn_lo + DDSPP_CHUNK, N);
-        const int ct_lo = cn_lo / U, ct_hi = min((cn_hi - 1) / U + 1, T - 1);
-        int moved = 0;
-        for (int t = ct_lo + 1; t <= ct_hi; ++t) moved |= audible[(size_t)row * T + t] >> 16;
-        if ((moved & 1) && atomicOr(&chunk_flag[(size_t)b * npre + c], 1) == 0) {
-            const int base = atomicAdd(ntasks, nslots);
-            for (int sl = 0; sl < nslots; ++sl) tasks[base + sl] = (b * npre + c) * nslots + sl;
+}
+
+// The same with the compacted scan of moving chunks in view (round 5): ONE WAVEFRONT PER ROW, lane = span (+ 64, + 128, ...),
+// so that what the scan needs comes out of wave reductions with no atomics and no buffer to zero first:
+//   rowmax[row]        the row's audible maximum over all its spans (what the pre-pass and the scans ask of a 64-group)
+//   moved[row, c]      1 when the row's frequencies move in chunk c < npre (bit 16 of a frame's count: its frequencies differ
+//                      from the frame before; the test is osc_prepass_fused_kernel's `chunk_const`: no change in frames
+//                      (t_lo, t_hi] of the chunk) -- written for every (row, chunk), 0 or 1
+//   *any = call_id     when some row moves somewhere: bank_scan_kernel leaves at once unless it finds this call's id there
+//                      (a stale or garbage value that happens to match only costs a walk over flags that are all current)
+__global__ void __launch_bounds__(64) osc_count_rows_kernel(const int* __restrict__ audible, int* __restrict__ nk, int R, int P,
+                                                          int T, int U, int N, int spans, int cps, int vmajor,
+                                                          int* __restrict__ rowmax_out, int* __restrict__ moved_out,
+                                                          int* __restrict__ any, int call_id, int npre) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int B = R / P;
+    const int b = vmajor ? row % B : row / P, v = vmajor ? row / B : row - b * P;
+    int rmax = 0, any_moved = 0;
+    for (int span = lane; span < spans; span += 64) {
+        const int n_lo = span * cps * DDSPP_CHUNK, n_hi = min((span + 1) * cps * DDSPP_CHUNK, N);
+        const int t_lo = n_lo / U, t_hi = min((n_hi - 1) / U + 1, T - 1);
+        int best = 0;
+        for (int t = t_lo; t <= t_hi; ++t) best = max(best, audible[(size_t)row * T + t] & 0xffff);
+        nk[((size_t)b * spans + span) * P + v] = best;
+        rmax = max(rmax, best);
+        for (int c = span * cps; c < min((span + 1) * cps, npre); ++c) {
+            const int cn_lo = c * DDSPP_CHUNK, cn_hi = min(cn_lo + DDSPP_CHUNK, N);
+            const int ct_lo = cn_lo / U, ct_hi = min((cn_hi - 1) / U + 1, T - 1);
+            int moved = 0;
+            for (int t = ct_lo + 1; t <= ct_hi; ++t) moved |= audible[(size_t)row * T + t] >> 16;
+            moved_out[(size_t)row * npre + c] = moved & 1;
+            any_moved |= moved & 1;
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, __shfl_xor(rmax, o));
+    if (lane == 0) rowmax_out[row] = rmax;
+    if (__any(any_moved) && lane == 0) *any = call_id;
 }
 
 static bool sample_rate_is_checked(float sr) {
@@ -1626,7 +1648,7 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
     return (2 * (size_t)B * P * nchunks * VP      /* astart + chunk end phases (worst case: one span per chunk) */
             + (size_t)B * nchunks * (P + 2)       /* nk + wcount */
             + (size_t)B * P                       /* per-row max of the audible counts */
-            + (size_t)B * nchunks * (wmax + 1) + 64   /* compacted scan: chunk flags, task list, counter */
+            + (size_t)B * P * nchunks + 64        /* compacted scan: moved flags per (row, chunk), "any" flag */
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
@@ -1669,16 +1691,15 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     int* nk = (int*)(ework + (size_t)R * nchunks * VP);
     int* wcount = nk + (size_t)B * sp * P;
     int* rowmax = wcount + (size_t)B * sp * 2;
-    // compacted scan (osc_common.h: scan_tasks): [rowmax R | counter 1 (+ pad) | chunk flags B * npre | tasks B * npre * slots]:
-    // the first three are zeroed by ONE memset per call
+    // compacted scan (osc_common.h: scan_tasks): [rowmax R | "some row moves" 1 (+ pad) | moved flags R * npre], all written by
+    // osc_count_rows_kernel: nothing to zero
     const int npre_c = sp > 1 ? (sp - 1) * cps : 0;
     const int scan_vpl = vpl_pre <= 2 ? 2 : 0;            // (the pre-pass takes sections of four wavefronts up to 128 oscillators per row)
     const int scan_lanes = 64 * (env_int("DDSPP_OSC_SCAN_VPL", 2) == 1 ? 1 : 2);      // oscillators per scan task
     const int scan_slots = scan_vpl ? (P * V + scan_lanes - 1) / scan_lanes : 0;
     int* scan_ntasks = rowmax + R;
     int* chunk_flag = scan_ntasks + 16;
-    int* scan_tasks = chunk_flag + (size_t)B * npre_c;
-    float* partial = (float*)(scan_tasks + (size_t)B * npre_c * scan_slots);
+    float* partial = (float*)(chunk_flag + (size_t)R * npre_c);
     partial = (float*)(((uintptr_t)partial + 255) & ~(uintptr_t)255);
 
     OscParams p{};
@@ -1704,11 +1725,13 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
                               !env_int("DDSPP_OSC_PLAIN_PREPASS", 0) && R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256);
     // 1. audible-harmonic counts per (segment, span, voice) (+ with the compacted scan: row maxima and the scan's task list)
     if (compact_scan) {
-        DDSPP_HIP_CHECK(hipMemsetAsync(rowmax, 0, ((size_t)R + 16 + (size_t)B * npre_c) * sizeof(int), stream));
-        hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
-                           P, T, U, N, sp, cps, voice_major, rowmax, chunk_flag, scan_tasks, scan_ntasks, npre_c, scan_slots);
+        static std::atomic<int> call_counter{1};
+        const int call_id = call_counter.fetch_add(1) | 0x40000000;
+        hipLaunchKernelGGL(osc_count_rows_kernel, dim3(R), dim3(64), 0, stream, audible, nk, R, P, T, U, N, sp, cps, voice_major,
+                           rowmax, chunk_flag, scan_ntasks, call_id, npre_c);
         p.rowmax = rowmax;
-        p.scan_tasks = scan_tasks; p.scan_ntasks = scan_ntasks; p.scan_slots = scan_slots; p.skip_moving = 1;
+        p.scan_tasks = chunk_flag; p.scan_ntasks = scan_ntasks; p.scan_slots = scan_slots; p.skip_moving = 1;
+        p.scan_call = call_id;
         p.P = P; p.vmajor = voice_major ? 1 : 0;          // (the scan kernel packs the voices of a segment: it reads both)
     }
     // 2. span start offsets for every (row, oscillator) over rows = B * P
@@ -1724,7 +1747,7 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     if (compact_scan) {
     } else if (audible)
         hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
-                           P, T, U, N, sp, cps, voice_major, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0);
+                           P, T, U, N, sp, cps, voice_major);
     else
         hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
                            harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
