@@ -104,11 +104,15 @@ def test_bench_distributed_branch_runs():
     env = _env(_free_port())
     env['DDSPP_BENCH_DIST'] = '1'
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
-                        '--batch', '4', '--no-roofline', '--no-cpu-baseline', '--no-single-stream'],
+                        '--batch', '4', '--no-roofline', '--no-cpu-baseline', '--no-single-stream', '--sustain-seconds', '0.3'],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])        # the JSON line must be the LAST line
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['steps'] == 2
+    # round 5: what the first multi-GPU run reads out by itself -- every rank's step, the collective alone, is it hidden?
+    assert len(line['per_rank']['ms_step_with_sync_gather']) == 1 and line['per_rank']['ms_step_compute_only'][0] > 0
+    assert set(line['gather_hidden']) >= {'compute_only_ms', 'with_synchronous_gather_ms', 'pipelined_ms', 'hidden'}
+    assert line['sustained']['n'] >= 200 and line['sustained']['ms_per_step'] > 0 and 'gpu' in line['sustained']
 
 
 _WORKER2 = r"""
@@ -195,7 +199,7 @@ def test_bench_two_rank_launcher_flow_on_one_gpu():
         env.pop(k, None)
     env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'DDSPP_BENCH_SHARE_GPU': '1', 'DDSPP_BENCH_BACKEND': 'gloo'})
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                        '--batch', '4', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                        '--batch', '4', '--no-roofline', '--no-cpu-baseline', '--no-extras', '--sustain-seconds', '0.2'],
                        env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
@@ -205,6 +209,8 @@ def test_bench_two_rank_launcher_flow_on_one_gpu():
     assert line['config']['global_batch'] == 8 and line['value'] > 0 and line['steps'] == 3
     assert line['allgather']['bytes_received'] == 4 * 72000 * 4 and line['gather_to_rank0']['ms'] > 0
     assert line['gather'].startswith('to rank 0')
+    assert len(line['per_rank']['ms_step_pipelined']) == 2 and isinstance(line['gather_hidden']['hidden'], bool)
+    assert line['sustained']['ms_per_step'] > 0                  # (the sustained loop runs the pipelined step, gathers included)
 
 
 _WORKER8 = r"""
@@ -278,7 +284,7 @@ def test_bench_eight_rank_launcher_flow_on_one_gpu():
         env.pop(k, None)
     env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'DDSPP_BENCH_SHARE_GPU': '1', 'DDSPP_BENCH_BACKEND': 'gloo'})
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
-                        '--batch', '2', '--seconds', '1', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                        '--batch', '2', '--seconds', '1', '--no-roofline', '--no-cpu-baseline', '--no-extras', '--sustain-seconds', '0'],
                        env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
@@ -289,3 +295,4 @@ def test_bench_eight_rank_launcher_flow_on_one_gpu():
     assert g['bytes_received'] == 7 * 2 * 24000 * 4 and g['gb_per_s'] > 0
     assert g['xgmi']['links_used'] == 7 and abs(g['xgmi']['ceiling_gb_per_s'] - 7 * 153) < 1
     assert line['allgather']['xgmi']['frac_of_ceiling'] > 0
+    assert len(line['per_rank']['ms_step_compute_only']) == 8 and 'sustained' not in line

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_r05
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py --steps 10 --warmup 2 > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py --steps 10 --warmup 2 --sustain-seconds 1 > $OUT/bench_under_rocprof.log 2>&1
 grep "^{\"metric" $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python $R/tools/bench_kernels.py --which osc --spans 1 --reps 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python $R/tools/bench_kernels.py --which osc --spans 1 --reps 2 > $OUT/pmc_write.log 2>&1
