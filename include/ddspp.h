@@ -44,7 +44,12 @@ const char* ddspp_target_arch(void);
 const char* ddspp_last_error(void);
 /* Tuning options (launch geometry, A/B route switches): named like their DDSPP_* environment
  * variable.  The environment is consulted ONCE per option (first use) and cached -- no getenv on the call path;
- * ddspp_set_option overrides a value, ddspp_reload_options forgets the cache (next use reads the environment again). */
+ * ddspp_set_option overrides a value, ddspp_reload_options forgets the cache (next use reads the environment again).
+ * One option is not tuning but a RECALLED DETAIL of ddsp.core.angular_cumsum (`angular_offsets`): the
+ * running sum of chunk end phases is added to a chunk wrapped, `tf.cumsum(offsets, axis=1) % (2 pi)` (the default, 0), or as it
+ * is (DDSPP_ANGULAR_OFFSETS_PLAIN = 1).  Every entry point that runs the angular cumsum reads it at launch
+ * (ddspp_cos_oscillator_bank, ddspp_harmonic_synthesis, ddspp_surrogate_harmonic_synthesis, ddspp_polyphonic_additive,
+ * ddspp_polyphonic_surrogate_additive, ddspp_group_run); a caller that resets the options sets it again. */
 int ddspp_option(const char* name, int default_value);      /* the value in effect */
 int ddspp_set_option(const char* name, int value);
 void ddspp_reload_options(void);

@@ -42,6 +42,17 @@ while time.time() - t0 < budget:
     T = int(rng.integers(8, 200)) if B * P > 64 else int(rng.integers(8, 600))
     seed = int(rng.integers(1, 1 << 30))
     kind = int(rng.integers(0, 4))
+    # round 5: half of the draws lower the thresholds behind which the memoised pre-pass + the compacted scan of moving chunks
+    # and the two-oscillators-per-lane slots (paired sub-strings at S = 2) run, so that small random shapes take those
+    # kernels too (by default they need 256 rows / 2048 wavefronts)
+    forced = rng.random() < 0.5
+    for k_, v_ in (('DDSPP_OSC_MEMO_MIN_WAVES', '4'), ('DDSPP_OSC_COMPACT_VPL1_BELOW', '0')):
+        if forced:
+            os.environ[k_] = v_
+        else:
+            os.environ.pop(k_, None)
+    from ddsp_piano_amd import _lib as _L
+    _L.options.reload()
     try:
         if kind == 0:
             args = (seed, B, P, T, H, S, U, FLAGS[int(rng.integers(0, len(FLAGS)))])
@@ -69,4 +80,5 @@ while time.time() - t0 < budget:
         bad += 1
         print('FAILED', kind, args, flush=True)
         traceback.print_exc(limit=3)
-print(f'fuzz soak: {n} draws passed, {bad} failed, {time.time() - t0:.0f} s')
+print(f'fuzz soak: {n} draws passed, {bad} failed, {time.time() - t0:.0f} s (half of the draws with DDSPP_OSC_MEMO_MIN_WAVES=4, '
+      'DDSPP_OSC_COMPACT_VPL1_BELOW=0: the compacted scan and the paired sub-strings on small shapes)')
