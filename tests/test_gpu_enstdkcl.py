@@ -72,6 +72,13 @@ def test_enstdkcl_config_full_chain(sr, H, K, lines):
         # the layer keeps the impulse response of its fixed parameters; new parameters replace it
         again = fdn.get_controls(out['controls']['add']['signal'])['ir']
         assert again.data_ptr() == out['controls']['fdn']['controls']['ir'].data_ptr()
+        # cache_ir=False (round 5): the impulse response designed inside EVERY get_controls, as fdn_reverb.py:383-392 does --
+        # a new tensor per call, the same values, the same audio
+        fdn.cache_ir = False
+        fresh = fdn.get_controls(out['controls']['add']['signal'])['ir']
+        assert fresh.data_ptr() != again.data_ptr() and torch.equal(fresh, again)
+        assert torch.equal(pg(gfeats, return_outputs_dict=True, noise=gnoise)['signal'], out['signal'])
+        fdn.cache_ir = True
         fdn.load_parameters({'time_rev_0_sec': 0.3})
         assert fdn.get_controls(out['controls']['add']['signal'])['ir'].data_ptr() != again.data_ptr()
         with pytest.raises(KeyError):
