@@ -294,6 +294,31 @@ def test_bench_launcher_logic(monkeypatch):
     assert cmd is not None and '--nproc-per-node=2' in cmd
 
 
+def test_bench_extras_levels_and_gpu_sampler_without_a_gpu():
+    """Round 5: `--extras default | full | none` (and the old `--no-extras`), `--sustain-seconds`; the clock / power sampler of the
+    `sustained` measurement must never take the timing down with it: on a box without readable amdgpu hwmon files (this one) it
+    falls back to rocm-smi, reads nothing, and reports an empty summary."""
+    import importlib
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    a = bench.parse([])
+    assert a.extras == 'default' and not a.no_extras and a.sustain_seconds == 5.0 and a.gpus == 1
+    assert bench.parse(['--extras', 'full']).extras == 'full' and bench.parse(['--no-extras']).no_extras
+    with pytest.raises(SystemExit):
+        bench.parse(['--extras', 'everything'])
+    with bench.GpuSampler(0, period=0.01) as smp:
+        time.sleep(0.05)
+    out = smp.summary()
+    assert out['source'] in ('rocm-smi',) or out['source'].startswith('sysfs hwmon')
+    assert out['n'] == len(smp.samples) and ('sclk_mhz' in out) == any(r[1] == r[1] for r in smp.samples)
+    assert smp.summary(t_from=time.perf_counter() + 1.0)['n'] == 0
+    assert bench.ms_summary([1.0, 3.0, 2.0]) == {'median': 2.0, 'min': 1.0, 'max': 3.0, 'n': 3}
+
+
 def test_plan_cache_is_bounded_and_respects_pins(monkeypatch):
     """rocFFT plans are library-owned handles: the cache destroys the least recently used ones when it is full, never a
     plan pinned by an unfinished two-phase convolution, and clear() (atexit) tolerates a library that is gone."""
