@@ -616,9 +616,12 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
 // partial.  A persistent grid walks (slot, segment, chunk); which chunks are flagged is only known on the device: none --
 // held notes -- and the wavefronts leave at once.  Same arithmetic, same order, same bits as the pre-pass's own moving branch
 // (scan_block_staged); rows that are constant in a listed chunk are written by both kernels with the same values.
+#ifndef SCAN_WPE
+#define SCAN_WPE 4      // wavefronts per SIMD of bank_scan_kernel (an even count: a SIMD issues for two wavefronts at a time)
+#endif
 constexpr int SCAN_WQ = (DDSPP_CHUNK + 255) / 256;          // float4 loads per lane that cover a chunk's weights
 template <int VPL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCAN_WPE, SCAN_WPE)))
 bank_scan_kernel(const OscParams p) {
     extern __shared__ float lds_dyn[];
     int* offs = reinterpret_cast<int*>(lds_dyn);             // [64] exclusive offsets of the sub-rows of the segment

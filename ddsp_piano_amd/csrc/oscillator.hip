@@ -1694,7 +1694,11 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     // compacted scan (osc_common.h: scan_tasks): [rowmax R | "some row moves" 1 (+ pad) | moved flags R * npre], all written by
     // osc_count_rows_kernel: nothing to zero
     const int npre_c = sp > 1 ? (sp - 1) * cps : 0;
-    const int scan_vpl = vpl_pre <= 2 ? 2 : 0;            // (the pre-pass takes sections of four wavefronts up to 128 oscillators per row)
+    // (the sectioned pre-pass -- the one that can leave moving chunks to the scan -- runs on 64-oscillator groups of a row
+    // when the row splits into them, span_starts' `split`, or on whole rows of up to 128 oscillators)
+    const bool sectioned = (V % 64 == 0 && (long long)R * (V / 64) <= 8192 && !env_int("DDSPP_OSC_PREPASS_WHOLE_ROWS", 0)) ||
+                           vpl_pre <= 2;
+    const int scan_vpl = sectioned ? 2 : 0;
     const int scan_lanes = 64 * (env_int("DDSPP_OSC_SCAN_VPL", 2) == 1 ? 1 : 2);      // oscillators per scan task
     const int scan_slots = scan_vpl ? (P * V + scan_lanes - 1) / scan_lanes : 0;
     int* scan_ntasks = rowmax + R;
