@@ -1724,8 +1724,8 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     // The chunks in which some frequency moves are scanned by bank_scan_kernel, packed like the bank (round 5): when the
     // per-frame counts and flags of get_controls are there, the sectioned memo pre-pass is the one that runs (same test as
     // launch_memo_prepass), nothing asks for every oscillator's state, and there are chunks to pre-pass at all
-    const bool compact_scan = audible && !p.dbg_noflags && scan_vpl && npre_c >= 8 && sp > 1 && !p.state_in && S * H == V &&
-                              V % 64 == 0 && env_int("DDSPP_OSC_COMPACT_SCAN", 1) && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0) &&
+    const bool compact_scan = audible && !p.dbg_noflags && scan_vpl && npre_c >= 8 && sp > 1 && !p.state_in &&
+                              env_int("DDSPP_OSC_COMPACT_SCAN", 1) && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0) &&
                               !env_int("DDSPP_OSC_PLAIN_PREPASS", 0) && R >= env_int("DDSPP_OSC_MEMO_MIN_WAVES", 256);
     // 1. audible-harmonic counts per (segment, span, voice) (+ with the compacted scan: row maxima and the scan's task list)
     if (compact_scan) {
@@ -1748,11 +1748,10 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
         span_starts(p, R, V, vpl_pre, astart, ework, stream);
     }
     p.skip_moving = 0;
-    if (compact_scan) {
-    } else if (audible)
+    if (audible && !compact_scan)
         hipLaunchKernelGGL(osc_count_frames_kernel, dim3((R * sp + 255) / 256), dim3(256), 0, stream, audible, nk, R,
                            P, T, U, N, sp, cps, voice_major);
-    else
+    else if (!audible)
         hipLaunchKernelGGL(osc_count_kernel, dim3((R * sp + 3) / 4), dim3(256), 0, stream, amplitudes,
                            harmonic_distribution, nk, R, P, T, H, U, N, sp, cps, voice_major);
     // 3. the compacted oscillator bank (bank_compact.hip): one wavefront per (segment, span, slot of 64 * vpl audible

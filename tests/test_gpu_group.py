@@ -577,7 +577,9 @@ def test_compacted_scan_of_moving_chunks(monkeypatch):
     from ddsp_piano_amd import core
     rng = np.random.default_rng(77)
     keys = ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')
-    for (B, P, T, H, S, sr) in [(64, 4, 120, 128, 1, 24000), (32, 8, 150, 96, 2, 16000), (16, 16, 125, 64, 1, 24000)]:
+    # (oscillators per row: 128, 192 = three 64-groups, 64, and 96 -- not a multiple of 64: whole rows of two per lane)
+    for (B, P, T, H, S, sr) in [(64, 4, 120, 128, 1, 24000), (32, 8, 150, 96, 2, 16000), (16, 16, 125, 64, 1, 24000),
+                                (32, 8, 140, 96, 1, 16000)]:
         U = sr // 250
         N, R = T * U, B * P
         raw = synth_controls(rng, R, T, H, S=S, silent_frac=0.15, midi_lo=30, midi_hi=100)

@@ -22,7 +22,7 @@ elif case == 'dafx22':      # configs/dafx22.gin dims (bench.py: dafx22_dims)
     B, P, H, K, S, sr, L = 64, 16, 96, 64, 2, 16000, 24000
 elif case in ('dafx24', 'dafx24moving'):      # configs/dafx22-24kHz.gin dims: two sub-strings at 24 kHz
     B, P, H, K, S, sr, L = 64, 16, 128, 96, 2, 24000, 36000
-elif case == 'multi':       # configs/multi_instruments.gin dims
+elif case in ('multi', 'multimoving'):       # configs/multi_instruments.gin dims
     B, P, H, K, S, sr, L = 64, 16, 96, 64, 1, 16000, 24000
 elif case == 'surrogate':   # configs/surrogate.gin dims and flags (bench.py: shipped_configs)
     B, P, H, K, S, sr, L = 64, 16, 96, 64, 1, 16000, 16000
@@ -34,7 +34,7 @@ elif case == 'enst8k':      # configs/ENSTDkCl-8kHz.gin dims (here with ddsp.eff
     B, P, H, K, S, sr, L = 64, 16, 48, 32, 1, 8000, 16000
 elif case in ('enst32k', 'enst32kmoving'):     # configs/ENSTDkCl-32kHz.gin dims
     B, P, H, K, S, sr, L = 64, 16, 192, 128, 1, 32000, 64000
-kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'dafx24moving': dict(vibrato=0.002), 'enst32kmoving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'surrogate': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
+kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'dafx24moving': dict(vibrato=0.002), 'multimoving': dict(vibrato=0.002), 'enst32kmoving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'surrogate': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
       'dense': dict(silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)}[case]
 feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
 pg = bench.build_group(dp, P, sr)
