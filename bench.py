@@ -15,7 +15,9 @@ Workload at N GPUs (weak scaling): BASELINE.json config 3 per GPU = 64 segments 
                      oscillator-sample + 4 B written per sample) timed with HIP events on materialised
                      [rows, N, H] envelopes of the same workload, against 8 TB/s;
   * roofline_step  : the timed step's own dominant call (the compacted oscillator bank, VALU bound): live
-                     HIP-event time against the VALU issue ceiling, instruction counts from profiles/;
+                     HIP-event time against the VALU issue ceiling, instruction counts from profiles/; since round 5 also
+                     against the MEASURED ceiling of this run (measured_ceiling: ddspp_fma_probe, a pure multiply-add
+                     stream for 20 ms -- what the chip sustains at its power limit, not the nominal 2 cycles at 2.4 GHz);
   * roofline_noise : the step's second large call, FilteredNoise: live time against the issue time of its useful
                      multiply-adds (samples x taps) and of all its VALU instructions (counts from profiles/);
   * cpu_baseline   : the float32-faithful numpy restatement (oracle/, the only runnable stand-in for the
@@ -496,7 +498,31 @@ def measure_roofline(dp, base, args, T, U, device):
             'ms_per_launch': t * 1e3, 'ms_min': float(np.min(times)) * 1e3}
 
 
-def measure_roofline_step(dp, base, args, T, U, device):
+def measure_valu_ceiling(device, waves_per_simd=4, target_ms=20.0):
+    """What the chip SUSTAINS in wave64 multiply-adds, in this run: ddspp_fma_probe (a pure stream of independent v_fmac_f32,
+    `waves_per_simd` wavefronts on every SIMD) timed with HIP events over ~20 ms -- the power management needs milliseconds
+    to settle, and under such a stream the clock falls well below 2.4 GHz.  Returns instructions per second over the chip."""
+    import ctypes
+    from ddsp_piano_amd import core
+    lib = core._lib_()
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    per_simd = ctypes.c_double(0.0)
+
+    def run(iters):
+        rc = lib.ddspp_fma_probe(core._ptr(sink), waves_per_simd, int(iters), ctypes.byref(per_simd), core._stream())
+        assert rc == 0, core._lib.last_error()
+
+    iters = 4000
+    t = float(np.median(event_times(lambda: run(iters), 2, warmup=1)))                 # sizes the real run
+    iters = max(1000, int(iters * target_ms / max(t, 1e-3)))
+    t = float(np.min(event_times(lambda: run(iters), 2, warmup=0))) * 1e-3
+    ns = t * 1e9 / per_simd.value
+    return {'wave_instructions_per_s': N_SIMDS / (ns * 1e-9), 'ns_per_instruction_per_simd': ns, 'waves_per_simd': waves_per_simd,
+            'ms': t * 1e3, 'note': 'ddspp_fma_probe: independent wave64 v_fmac_f32 (three VGPR operands) on every SIMD, '
+                                   'HIP events; the power-limited rate the VALU-bound kernels are read against'}
+
+
+def measure_roofline_step(dp, base, args, T, U, device, ceiling=None):
     """The timed step's dominant call, the compacted oscillator bank (ddspp_polyphonic_additive: VALU bound, it
     moves ~0.7 GB): HIP-event time of the call on the bench inputs against the VALU issue ceiling.  The wave-
     instruction count of its kernels comes from the committed counter pass (profiles/step_valu.json, written by
@@ -534,6 +560,11 @@ def measure_roofline_step(dp, base, args, T, U, device):
             out.update({'valu_wave_instructions': insts, 'achieved': insts / t,
                         'frac': insts / t / out['peak'], 'counters': prof.get('source')})
             trans = float(prof.get('valu_trans_wave_instructions_per_call', 0.0))
+            if trans and ceiling:
+                # ... and against what the chip sustains (measure_valu_ceiling, this run): the kernels' instructions with a
+                # quarter-rate transcendental counted as four plain ones
+                out['measured_ceiling'] = ceiling
+                out['frac_of_measured_ceiling'] = ((insts - trans) + 4.0 * trans) / t / ceiling['wave_instructions_per_s']
             if trans:
                 # a v_cos_f32 / v_sqrt_f32 / v_rcp_f32 occupies the SIMD for 8 cycles, not 2: the share of the call's
                 # time its instruction mix accounts for at full issue rate (1.0 = nothing but issue cycles)
@@ -545,7 +576,7 @@ def measure_roofline_step(dp, base, args, T, U, device):
     return out
 
 
-def measure_roofline_noise(dp, base, args, T, U, device):
+def measure_roofline_noise(dp, base, args, T, U, device, ceiling=None):
     """The step's second large kernel, FilteredNoise (the fused design + time-varying FIR kernel: VALU bound).  Live HIP-
     event time of the call as the batched group makes it (voice sums of 8, the last voice kept apart, scale_fn inside),
     against the issue time of (a) its USEFUL multiply-adds -- samples x taps of the windowed impulse response, what any
@@ -581,6 +612,10 @@ def measure_roofline_noise(dp, base, args, T, U, device):
             prof = json.load(open(pf))
             out['counters_stale'] = prof.get('csrc_hash') != dp._lib.source_hash()
             nz = prof.get('noise')
+            if nz and not out['counters_stale'] and ceiling:
+                out['measured_ceiling'] = ceiling
+                out['frac_of_measured_ceiling'] = nz['valu'] / t / ceiling['wave_instructions_per_s']
+                out['frac_useful_of_measured_ceiling'] = useful / t / ceiling['wave_instructions_per_s']
             if nz and not out['counters_stale']:
                 out.update({'valu_wave_instructions': nz['valu'], 'fma_wave_instructions': nz['fma'],
                             'mfma_mops': nz.get('mfma_mops'), 'lds_instructions': nz.get('lds'),
@@ -1081,8 +1116,9 @@ def main():
     if rank == 0 and not args.no_roofline:
         del feats
         torch.cuda.empty_cache()
-        roof_step = measure_roofline_step(dp, base, args, T, U, device)
-        roof_noise = measure_roofline_noise(dp, base, args, T, U, device)
+        ceiling = measure_valu_ceiling(device)
+        roof_step = measure_roofline_step(dp, base, args, T, U, device, ceiling)
+        roof_noise = measure_roofline_noise(dp, base, args, T, U, device, ceiling)
         phase_done('roofline_step_and_noise')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -25,9 +25,50 @@ __global__ void __launch_bounds__(256) hbm_read_streams_kernel(const float* __re
     if (acc == 1.2345e30f) sink[0] = acc;        // never true for finite audio-rate data: keeps the loads alive
 }
 
+// The other ceiling (round 5; bench.py's `roofline_step.measured_ceiling`): what the chip SUSTAINS in wave64 multiply-adds.
+// The step's two large kernels are bound by VALU issue, and "one instruction per 2 cycles at 2.4 GHz" is not what a SIMD
+// delivers for long: under a pure stream of independent v_fmac_f32 (three VGPR operands, twelve accumulators per lane -- the
+// operand mix of the FilteredNoise walk) the socket reaches its power limit and the clock falls (tools/ubench/fma_ceiling:
+// 1.04 ns per instruction and SIMD at 2 or 4 wavefronts per SIMD).  iters x 192 multiply-adds per lane.
+__global__ void __launch_bounds__(256) fma_stream_kernel(float* __restrict__ sink, int iters, float sa, float sb) {
+    float acc[12], tap[16], x[4];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = threadIdx.x * 1e-6f + i;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tap[i] = 1e-4f * (float)((threadIdx.x + i) & 31) + sb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = 1e-3f * (float)((threadIdx.x * 3 + i) & 15) + sa;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) acc[e] = __builtin_fmaf(x[d], tap[e - d + 3], acc[e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += acc[i];
+    if (s == 1.2345e30f) sink[0] = s;            // keeps the chains alive
+}
+
 }  // namespace ddspp
 
 extern "C" {
+
+// Runs `iters` x 192 independent multiply-adds per lane on 256 x waves_per_simd workgroups of four wavefronts (waves_per_simd
+// wavefronts on every SIMD of the chip); *wave_fmas_per_simd: wave64 multiply-adds each SIMD executed.  Time it with events:
+// ns per instruction and SIMD = elapsed / *wave_fmas_per_simd.  Give it ~20 ms (iters ~ 100 000 at 4 per SIMD): the power
+// controller needs milliseconds to settle.
+int ddspp_fma_probe(float* sink, int waves_per_simd, int iters, double* wave_fmas_per_simd, hipStream_t stream) {
+    DDSPP_REQUIRE(sink && waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0, "fma_probe: bad arguments");
+    hipLaunchKernelGGL(ddspp::fma_stream_kernel, dim3(256 * waves_per_simd), dim3(256), 0, stream, sink, iters, 1.0001f, 0.25f);
+    DDSPP_LAUNCH_CHECK();
+    if (wave_fmas_per_simd) *wave_fmas_per_simd = (double)iters * 192.0 * waves_per_simd;
+    return DDSPP_OK;
+}
 
 // Reads the first `n_floats` (rounded down to a whole number of 16 KB wavefront steps) of x with `n_waves` concurrent
 // streams (a multiple of 4; 2048 = two per SIMD is what the graded kernel runs); *bytes_read: what was read.
