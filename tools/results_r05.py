@@ -51,7 +51,7 @@ rows = [
     ('every shipped gin file (batch 64 × 3 s, poly 16)', ', '.join(f"{k} {v['ms_per_step']['median']:.2f}" for k, v in d['shipped_configs'].items()) + ' ms'),
     ('graded kernel (`roofline`)', f"{ro['ms_per_launch']:.2f} ms = {ro['achieved'] / 1e3:.2f} TB/s = **{ro['frac']:.3f} of 8 TB/s** = {ro['frac_of_measured_peak']:.3f} of the pure read of the same buffers = {ro['frac_of_guide_achievable']:.3f} of the guide's 6.29 TB/s; PMC traffic / algorithmic = {traffic['traffic_over_algorithmic']:.6f}"
      + (f"; kernel trace {trace_ms:.2f} ms against {under['roofline']['ms_per_launch']:.2f} ms by HIP events inside that run" if trace_ms and under.get('roofline') else '')),
-    ('`roofline_step` (compacted bank call) / `roofline_noise` (FilteredNoise call)', f"{rs['ms_per_call']:.3f} ms" + (f" (issue fraction {rs['frac']:.2f}, {rs['frac_mix']:.2f} with the cosines at 8 cycles)" if 'frac_mix' in rs else '') + f" / {rn['ms_per_call']:.3f} ms (useful multiply-adds {rn['frac_useful']:.2f} of the issue ceiling)"),
+    ('`roofline_step` (compacted bank call) / `roofline_noise` (FilteredNoise call)', f"{rs['ms_per_call']:.3f} ms" + (f" (issue fraction {rs['frac']:.2f} of the nominal ceiling, {rs['frac_mix']:.2f} with the cosines at 8 cycles" + (f"; **{rs['frac_of_measured_ceiling']:.2f} of the multiply-add rate measured in this run**, {rs['measured_ceiling']['ns_per_instruction_per_simd']:.2f} ns per wave64 instruction and SIMD" if 'frac_of_measured_ceiling' in rs else '') + ")" if 'frac_mix' in rs else '') + f" / {rn['ms_per_call']:.3f} ms (useful multiply-adds {rn['frac_useful']:.2f} of the nominal ceiling" + (f", {rn['frac_useful_of_measured_ceiling']:.2f} of the measured one; all its VALU instructions {rn['frac_of_measured_ceiling']:.2f}" if 'frac_of_measured_ceiling' in rn else '') + ")"),
     ('`cpu_baseline` (numpy oracle, `kind: port`)', f"{d['cpu_baseline']['value'] / 1e4:.1f}e4 samples/s on {d['cpu_baseline']['cores']} threads = {d['cpu_baseline']['rtf']:.1f} × real time"),
     ('bench.py wall clock after `import torch`', f"{sum(d['phase_seconds'].values()):.0f} s (" + ', '.join(f"{k} {v:.1f}" for k, v in d['phase_seconds'].items()) + ')'),
 ]
