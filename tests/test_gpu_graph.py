@@ -105,3 +105,32 @@ def test_replay_with_the_large_lds_noise_instances():
         want = group(feats, noise=noise)
         got = fast(feats, noise=noise)
         assert torch.equal(got, want), sr
+
+
+def test_replay_when_the_frequencies_start_and_stop_moving():
+    """Which kernels a call launches may depend on shapes and options only, never on the data: a graph captured on held
+    notes has to render a vibrato on replay (the compacted scan of moving chunks is decided by a word the count kernel
+    writes, inside the captured launches), and held notes again after that (the word of the previous replay is still in the
+    workspace).  A batch large enough for the memoised pre-pass + bank_scan_kernel (256 rows)."""
+    import ddsp_piano_amd as dp
+    sr, B, P, T, H, K, S, L = 24000, 64, 4, 120, 128, 96, 1, 3000
+    N = T * (sr // 250)
+    group = dp.ProcessorGroup(dp.polyphonic_dag(
+        dp.MultiInharmonic(name='additive', frame_rate=250, sample_rate=sr, inference=True),
+        dp.DynamicSizeFilteredNoise(name='noise', frame_rate=250, sample_rate=sr), dp.Reverb(name='reverb'),
+        n_synths=P, **KEYS))
+    held = _features(11, B, P, T, H, K, S, L)
+    fast = dp.CapturedGroup(group, held)
+    tt = torch.arange(T, device='cuda', dtype=torch.float32)[None, :, None]
+    noise = torch.as_tensor(np.random.default_rng(12).uniform(-1, 1, [B, P, N]).astype(np.float32), device='cuda')
+    outs = {}
+    for step, moving in enumerate((True, False, True, False)):
+        feats = dict(_features(20 + step, B, P, T, H, K, S, L))
+        if moving:
+            for i in range(P):
+                feats[f'f0_hz_{i}'] = feats[f'f0_hz_{i}'] * (1 + 0.004 * torch.sin(0.13 * tt + i))
+        want = group(feats, noise=noise)
+        got = fast(feats, noise=noise)
+        assert torch.equal(got, want), (step, moving)
+        outs[step] = want.clone()
+    assert not torch.equal(outs[0], outs[1])
