@@ -253,6 +253,7 @@ class Options:
         self.side_stream_min = int(env.get('DDSPP_SIDE_STREAM_MIN', 1 << 24))
         self.no_side_stream = env.get('DDSPP_NO_SIDE_STREAM') == '1' or not self.side_stream
         self.no_early_ir = env.get('DDSPP_NO_EARLY_IR') == '1'
+        self.no_stems_compact = env.get('DDSPP_NO_STEMS_COMPACT') == '1'    # every voice's stems through the per-voice fused kernel (A/B)
         self.surrogate_materialised = env.get('DDSPP_SURROGATE_MATERIALISED') == '1'   # SurrogateAdditive: the three-operator route (A/B)
         if _library and _lib is not None:
             _lib.ddspp_reload_options()

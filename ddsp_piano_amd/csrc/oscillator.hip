@@ -1680,7 +1680,11 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     const int VP = vpl_pre * 64;
     // A wavefront slot carries 128 audible oscillators (2 per lane); when that leaves the chip short of wavefronts
     // (single segments: B * spans * slots < ~2 per SIMD) it carries 64, twice the wavefronts at half the length.
-    const int vpl_c = ((long long)B * sp * ((P * V + 127) / 128) < env_int("DDSPP_OSC_COMPACT_VPL1_BELOW", 2048)) ? 1 : 2;
+    // Segments of ONE voice (every voice's stem asked for: the rows of a batch as segments of their own) take 64 as well: a
+    // piano row has 40 audible partials on average, a slot of 128 would run half empty (same box, 1024 rows of config 3:
+    // 1.90 -> 1.82 ms, two sub-strings 2.79 -> 2.47, every f0 moving 3.80 -> 3.44).
+    const int vpl_c = (P == 1 && env_int("DDSPP_OSC_COMPACT_VPL1_SINGLE", 1)) ? 1 :
+        ((long long)B * sp * ((P * V + 127) / 128) < env_int("DDSPP_OSC_COMPACT_VPL1_BELOW", 2048)) ? 1 : 2;
     // partial rows (wavefront slots) per segment: with audio_last the last voice's oscillators get slots of their own
     const int split_last = (audio_last && P > 1) ? 1 : 0;
     const int wmax_a = ((P - split_last) * V + 64 * vpl_c - 1) / (64 * vpl_c);

@@ -292,10 +292,16 @@ def run(plan, inputs, noise=None, need_stems=True):
     want_all = need_stems is True or need_stems == 'all'
     want_last = need_stems == 'last'
     compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
+    # every voice's stems (round 5, late): the same compacted bank with every voice as a segment of its own -- lanes only
+    # below each row's audible maximum, silent rows cost nothing, the memoised pre-pass and the compacted scan as on the
+    # group route.  Same box, 1024 rows of config 3: 2.05 -> 1.82 ms; two sub-strings 4.65 -> 2.47; every f0 moving 3.79 -> 3.44.
+    stems_compact = (want_all and additive.inference and S <= 64 and S * H <= 512 and N % 4 == 0 and
+                     not _lib.options.no_stems_compact)
     if surrogate:                  # (the compacted bank takes the decay term when get_controls runs as kernels)
         compact = compact and core.scale_kind(additive.scale_fn) is not None and H <= 512
+        stems_compact = False
     # --- noise branch ---------------------------------------------------------------------------
-    fuse_scale = compact and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
+    fuse_scale = (compact or stems_compact) and noise_p.scale_fn is not None and noise_p.raw_scale() is not None
     # audio only: the noise kernel adds the filtered noise of up to 8 voices of a segment in registers
     # (batch 64, same box: 2.12 ms per step with per-voice rows, 2.08 / 2.05 / 2.03 / 2.04 with 2 / 4 / 8 / 16)
     opt = _lib.options
@@ -353,8 +359,9 @@ def run(plan, inputs, noise=None, need_stems=True):
         if compact and '_audible' not in ctl:          # get_controls did not run as kernels: the caller walks the DAG
             return None
     else:
-        ctl = additive._controls(amp, hd, inh, f0, want_counts=compact, want_shifts=not compact,
-                                 last_voice_of=(P, vm) if want_last else None)
+        lean = compact or stems_compact
+        ctl = additive._controls(amp, hd, inh, f0, want_counts=lean, want_shifts=not lean,
+                                 last_voice_of=(P, vm) if (want_last or stems_compact) else None)
     additive_last = None
     if surrogate and compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
@@ -376,6 +383,10 @@ def run(plan, inputs, noise=None, need_stems=True):
         if want_last:               # (voices 0 .. P-2 summed, the last voice's stem): one launch, no oscillator twice
             additive_mix, additive_last = additive_mix
         additive_sig = None
+    elif stems_compact:
+        additive_sig = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],
+                                                None, R, N, additive.sample_rate, audible=ctl['_audible'],
+                                                inharm_coef=ctl['_inharm_coef'].reshape(R, T))
     else:
         additive_sig = core.harmonic_synthesis_fused(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),
                                                      ctl['harmonic_distribution'], ctl['harmonic_shifts'], N,
@@ -504,13 +515,14 @@ def run(plan, inputs, noise=None, need_stems=True):
         'signal': additive_sig[:, last],
         'controls': {'amplitudes': voice(ctl['amplitudes'], (T, 1)),
                      'harmonic_distribution': voice(ctl['harmonic_distribution'], (T, H)),
-                     'harmonic_shifts': voice(ctl['harmonic_shifts'], (T, H)),
+                     'harmonic_shifts': ctl['_shifts_last'] if stems_compact else voice(ctl['harmonic_shifts'], (T, H)),
                      'f0_hz': voice(ctl['f0_hz'], (T, S))}}
     if surrogate:
         outputs[additive.name]['controls'].update(decays=voice(ctl['decays'], (T, H)),
                                                   decay_time=voice(ctl['decay_time'], (T, 1)))
-    outputs[noise_p.name] = {'signal': noise_sig[:, last],
-                             'controls': {'magnitudes': voice(nctl['magnitudes'], (T, K))}}
+    mags_last = voice(nctl['magnitudes'], (T, K)) if nctl is not None else \
+        noise_p.get_controls(voice(mags, (T, K)).contiguous())['magnitudes']
+    outputs[noise_p.name] = {'signal': noise_sig[:, last], 'controls': {'magnitudes': mags_last}}
     if not default_shape:
         add_controls = {'signal_0': prev, 'signal_1': noise_sig[:, last], 'signal_2': additive_sig[:, last]} if P > 1 else \
             {'signal_0': noise_sig[:, last], 'signal_1': additive_sig[:, last]}

@@ -613,6 +613,54 @@ def test_compacted_scan_of_moving_chunks(monkeypatch):
         assert rms_err(got[0].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), (B, P, T, H, S)
 
 
+def test_every_voice_stem_through_the_compacted_bank(monkeypatch):
+    """Round 5: need_stems=True renders the additive stems with the compacted bank, every voice a segment of its own
+    (ddspp_polyphonic_additive with B' = B P, P' = 1: lanes below each row's audible maximum only, silent rows cost
+    nothing), instead of the per-voice fused kernel (DDSPP_NO_STEMS_COMPACT=1).  Same dictionary, same stems to float32
+    rounding of the harmonic sum, one and two sub-strings, rows voice major and segment major, against the oracle."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import _lib
+    rng = np.random.default_rng(91)
+    for (B, P, T, H, K, S, sr, L, vm) in [(3, 5, 60, 128, 96, 1, 24000, 3000, False), (2, 4, 50, 96, 64, 2, 16000, 2000, True),
+                                          (64, 4, 125, 128, 96, 1, 24000, 3000, False)]:
+        N = T * (sr // 250)
+        feats = _features(rng, B, P, T, H, K, S, L)
+        if B >= 64:                          # a vibrato on every other voice: the compacted scan of moving chunks on single-voice segments
+            tt = np.arange(T, dtype=np.float32)[None, :, None]
+            for i in range(0, P, 2):
+                feats[f'f0_hz_{i}'] = (feats[f'f0_hz_{i}'] * (1 + 0.004 * np.sin(0.13 * tt + i))).astype(np.float32)
+        noises = [rng.uniform(-1, 1, [B, N]).astype(np.float32) for _ in range(P)]
+        dev = {}
+        for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz', 'magnitudes'):
+            whole = torch.as_tensor(np.stack([feats[f'{k}_{i}'] for i in range(P)], axis=0 if vm else 1), device='cuda')
+            for i in range(P):
+                dev[f'{k}_{i}'] = whole[i] if vm else whole[:, i]
+        dev['reverb_ir'] = torch.as_tensor(feats['reverb_ir'], device='cuda')
+        gdag, _ = _build(dp, P, sr)
+        pg = dp.ProcessorGroup(gdag)
+        nz = [torch.as_tensor(z, device='cuda') for z in noises]
+        monkeypatch.setattr(_lib.options, 'no_stems_compact', True)
+        want = pg(dev, return_outputs_dict=True, need_stems=True, noise=nz)
+        monkeypatch.setattr(_lib.options, 'no_stems_compact', False)
+        got = pg(dev, return_outputs_dict=True, need_stems=True, noise=nz)
+        gv, wv = got['controls']['voices'], want['controls']['voices']
+        assert gv['additive'].shape == wv['additive'].shape == (B, P, N)
+        scale = max(1.0, float(wv['additive'].abs().max()))
+        assert float((gv['additive'] - wv['additive']).abs().max()) < 4e-6 * scale, (B, P, S)
+        assert torch.equal(gv['noise'], wv['noise'])
+        assert float((got['signal'] - want['signal']).abs().max()) < 2e-5 * max(1.0, float(want['signal'].abs().max()))
+        for name in ('additive', 'noise', 'add', 'reverb'):
+            assert set(got['controls'][name]['controls']) == set(want['controls'][name]['controls']), name
+        for k, v in want['controls']['additive']['controls'].items():
+            assert torch.equal(got['controls']['additive']['controls'][k], v), k
+        assert torch.equal(got['controls']['noise']['controls']['magnitudes'], want['controls']['noise']['controls']['magnitudes'])
+        if B < 64:
+            osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
+            for i in (0, P - 1):
+                ref = osyn(*[feats[f'{k}_{i}'] for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')])
+                assert rms_err(gv['additive'][:, i].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), (B, P, S, i)
+
+
 def test_parallelizer_views_feed_the_group_without_copies():
     """The reference hands the group `features[k + '_i'] = features[k][i]` of the merged [P * B, T, C] control
     tensors (sub_modules.py:584-592): those views are consumed in place and give the same audio as separately

@@ -1,9 +1,9 @@
 # per-kernel breakdown of one bench input case without the side stream (clean kernel durations): trace1.sh <case> <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-c=${1:-moving}; TAG=${2:-t1}
+c=${1:-moving}; TAG=${2:-t1}; FORM=${3:-dict}
 mkdir -p $R/gpurun_out/$TAG
-DDSPP_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$c -o $c -- python $R/tools/trace_case.py $c dict 10 > $R/gpurun_out/$TAG/$c.log 2>&1
+DDSPP_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$c -o $c -- python $R/tools/trace_case.py $c $FORM 10 > $R/gpurun_out/$TAG/$c.log 2>&1
 grep "ms per step" $R/gpurun_out/$TAG/$c.log
 f=$(find $R/gpurun_out/$TAG/$c -name "*kernel_stats.csv" | head -1)
 python - "$f" <<PY

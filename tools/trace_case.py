@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one bench input case a few times (for rocprofv3 --kernel-trace --stats).
-usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22|dafx24|multi|surrogate|enst8k|enst32k|file|one] [audio|dict] [reps]"""
+usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22|dafx24|multi|surrogate|enst8k|enst32k|file|one] [audio|dict|stems] [reps]"""
 import os
 import sys
 
@@ -46,6 +46,7 @@ if case == 'surrogate':
     for i in range(P):
         feats[f'decays_{i}'], feats[f'decay_time_{i}'] = dec[:, i], dt[:, i]
     pg = bench.build_shipped_group(dp, 'surrogate', P, sr)
-fn = (lambda: pg(feats, return_outputs_dict=True)) if form == 'dict' else (lambda: pg(feats))
+fn = {'dict': lambda: pg(feats, return_outputs_dict=True), 'audio': lambda: pg(feats),
+      'stems': lambda: pg(feats, return_outputs_dict=True, need_stems=True)}[form]
 ts = bench.event_times(fn, reps, warmup=2)
 print(case, form, 'ms per step:', bench.ms_summary(ts))
