@@ -133,6 +133,8 @@ SIGNATURES = {
     'ddspp_surrogate_decays': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
     'ddspp_polyphonic_additive_workspace_bytes': (c_size_t, [c_int] * 6),
     'ddspp_polyphonic_additive': (c_int, [c_void_p] * 11 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ddspp_polyphonic_stems_workspace_bytes': (c_size_t, [c_int] * 6),
+    'ddspp_polyphonic_stems': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_surrogate_additive': (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_float, c_int, c_int, c_void_p, c_size_t,
                                                     c_void_p]),
     'ddspp_oscillator_phase_state_workspace_bytes': (c_size_t, [c_int] * 4),
@@ -253,6 +255,7 @@ class Options:
         self.side_stream_min = int(env.get('DDSPP_SIDE_STREAM_MIN', 1 << 24))
         self.no_side_stream = env.get('DDSPP_NO_SIDE_STREAM') == '1' or not self.side_stream
         self.no_early_ir = env.get('DDSPP_NO_EARLY_IR') == '1'
+        self.stems_single = env.get('DDSPP_STEMS_SINGLE') == '1'            # every voice's stems: every voice a segment of its own (A/B)
         self.no_stems_compact = env.get('DDSPP_NO_STEMS_COMPACT') == '1'    # every voice's stems through the per-voice fused kernel (A/B)
         self.surrogate_materialised = env.get('DDSPP_SURROGATE_MATERIALISED') == '1'   # SurrogateAdditive: the three-operator route (A/B)
         if _library and _lib is not None:

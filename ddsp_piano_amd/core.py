@@ -740,6 +740,35 @@ def polyphonic_additive(f0_hz, amplitudes, harmonic_distribution, harmonic_shift
     return (out, last) if split_last else out
 
 
+def polyphonic_stems(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, n_segments, n_samples, sample_rate,
+                     spans=0, voice_major=False, audible=None, inharm_coef=None):
+    """MultiInharmonic.get_signal of EVERY voice: rows [B * P, T, .] -> stems [B * P, N], rows in the order of the controls
+    (ddspp_polyphonic_stems: the compacted bank of polyphonic_additive with the harmonic sum stopped at voice
+    boundaries).  Inference (angular cumsum) path only; arguments as polyphonic_additive."""
+    r, t, s = f0_hz.shape
+    h = harmonic_distribution.shape[-1]
+    b = int(n_segments)
+    p = r // b
+    u = n_samples // t
+    dev = f0_hz.device
+    wlin = walk_weights(t, n_samples, dev, 0)
+    whann = hann_window(2 * u, dev)
+    lib = _lib_()
+    nbytes = int(lib.ddspp_polyphonic_stems_workspace_bytes(b, p, t, s, h, u))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((r, n_samples), dtype=torch.float32, device=dev)
+    null = ctypes.c_void_p(0)
+    if audible is not None and (audible.dtype != torch.int32 or audible.numel() != r * t or not audible.is_contiguous()):
+        raise ValueError('audible must be a contiguous int32 tensor of R * T frame counts')
+    _lib.check(lib.ddspp_polyphonic_stems(
+        _ptr(f0_hz), _ptr(amplitudes), _ptr(harmonic_distribution),
+        _ptr(harmonic_shifts) if harmonic_shifts is not None else null,
+        _ptr(inharm_coef) if (inharm_coef is not None and harmonic_shifts is None) else null,
+        ctypes.c_void_p(audible.data_ptr()) if audible is not None else null, _ptr(wlin), _ptr(whann), _ptr(out),
+        b, p, t, s, h, u, float(sample_rate), int(spans), int(bool(voice_major)), _ptr(ws), nbytes, _stream()))
+    return out
+
+
 def oscillator_phase_state(f0_hz, n_chunks, upsampling, sample_rate, harmonic_shifts=None, inharm_coef=None,
                            n_harmonics=None, phase_state=None, audible=None, sample_offset=0):
     """The state an oscillator bank carries across calls: phase_state [R, S * H] after the first n_chunks 1000-sample

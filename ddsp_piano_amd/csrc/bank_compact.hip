@@ -46,9 +46,17 @@ struct SlotCtx {
 // shift_from_inharm once per frame, and -- while both sub-strings sit on the same side of Nyquist, which they do except
 // for a partial in the 0.3-cent gap between them -- evaluates ONE Hann cross-fade per sample: a (cos0 + cos1).  The packed
 // list then has one entry per (voice, harmonic): a slot carries 64 pairs.
-template <int VPL, bool DECAY = false, bool PAIR = false>
+//
+// STEMS (round 5; every voice's stem asked for): the same walk, but the harmonic sum stops at voice boundaries.  The packed
+// list gives every (voice, sub-string) a whole number of 32-entry blocks (entries past the sub-row's audible count are
+// silent lanes), so each half of a wavefront -- and with two oscillators per lane each of the two entries -- belongs to
+// ONE voice: the tile keeps the entries apart (rows [0, 16) entry 0, rows [16, 32) entry 1, flushed every 16 samples) and
+// a flush writes one row of `out` per 32-entry block instead of one per slot; bank_stems_sum_kernel adds a voice's blocks.
+template <int VPL, bool DECAY = false, bool PAIR = false, bool STEMS = false>
 __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const SlotCtx& c) {
     static_assert(!PAIR || (VPL == 2 && !DECAY), "PAIR: two sub-strings per lane, no decay term");
+    static_assert(!STEMS || (!PAIR && !DECAY), "STEMS: plain oscillators only");
+    constexpr int TILE_S = (STEMS && VPL == 2) ? TILE / 2 : TILE;        // samples between two flushes
     const int lane = c.lane, row = c.row, span = c.span, cw_all = c.cw_all;
     const int n_begin = c.n_begin, n_end = c.n_end, qlo = c.qlo, qhi = c.qhi, total = c.total;
     const int N = p.N, U = p.U, H = p.H, T = p.T, S = p.S;
@@ -82,12 +90,17 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
         for (int step = 32; step > 0; step >>= 1)
             if (q + step < qhi && offs[q + step] <= gc) q += step;
-        const int k = gc - offs[q];
+        int k = gc - offs[q];
+        valid[j] = g < total;
+        if constexpr (STEMS) {                               // the sub-row's block padding: entries past its audible count
+            const int cnt = offs[TSTRIDE + q];
+            valid[j] = valid[j] && k < cnt;
+            k = min(k, max(cnt - 1, 0));
+        }
         lrow[j] = p.vmajor ? (q / SUB) * p.R + row : row * p.P + q / SUB;
         vs[j] = PAIR ? j : q - (q / SUB) * SUB;
         vk[j] = k;
         vidx[j] = vs[j] * H + k;
-        valid[j] = g < total;
         kmul[j] = (float)(k + 1);                            // linspace(1, H, H)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -221,13 +234,39 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     decay_start(r);
     decay_request(min(t + 1, T - 1));
 
-    float* out_row = p.out + ((size_t)row * p.wmax + cw_all) * N;
+    float* out_row = STEMS ? p.out + ((size_t)row * p.stem_blocks + (c.first >> 5)) * N
+                           : p.out + ((size_t)row * p.wmax + cw_all) * N;
     int cpos = 0, tpos = 0, tile_n0 = n_begin;
 
     auto flush_tile = [&](int nt0, int count) {
 #if defined(DDSPP_BANK_ABLATE) && (DDSPP_BANK_ABLATE & 1)
         return;
 #endif
+        if constexpr (STEMS) {
+            // lane (col, entry, half) adds the 32 lane partials of sample `col` that belong to block 2 entry + half of the slot
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int col = lane & (TILE_S - 1), ent = VPL == 2 ? (lane >> 4) & 1 : 0, half = lane >> 5;
+            const float4* src = reinterpret_cast<const float4*>(tile + (ent * TILE_S + col) * TSTRIDE + half * 32);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v tv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tv[i] = *reinterpret_cast<const f4v*>(src + i);
+            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+            float4 s4 = make_float4(tv[0].x, tv[0].y, tv[0].z, tv[0].w);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) {
+                s4.x += tv[i].x; s4.y += tv[i].y; s4.z += tv[i].z; s4.w += tv[i].w;
+            }
+            const float s = (s4.x + s4.y) + (s4.z + s4.w);
+            const int blk = 2 * ent + half;
+            if (col < count && c.first + 32 * blk < total) out_row[(size_t)blk * N + nt0 + col] = s;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            return;
+        }
         // column sums: lane (col, half) adds 32 of the 64 lane partials of sample `col`
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -296,6 +335,18 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
 #pragma unroll
             for (int j = 0; j < VPL; ++j) er[j] = e_blk[j];
         }
+        if constexpr (STEMS && VPL == 2) {
+            // the two entries of a lane may belong to two voices: kept apart in the tile
+#pragma unroll
+            for (int j = 0; j < VPL; ++j)
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) {
+                    float a = __builtin_fmaf(da[j], w1[i], am0[j]);
+                    if (MASK) a = (fe[i][j] >= nyq) ? 0.0f : a;
+                    tile[(j * TILE_S + tpos + i) * TSTRIDE + lane] = a * pv[i][j];
+                }
+            return;
+        }
         if constexpr (PAIR && !MASK) {
             // the two sub-strings of a (voice, harmonic) under ONE cross-fade (classify_frame: same side of Nyquist)
 #pragma unroll
@@ -354,7 +405,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     auto block_tail = [&](int n0) {
         // ---- tile bookkeeping ---------------------------------------------------------------------------------
         tpos += BLK;
-        if (tpos == TILE || n0 + BLK >= n_end) {
+        if (tpos == TILE_S || n0 + BLK >= n_end) {
             flush_tile(tile_n0, tpos);
             tile_n0 += tpos;
             tpos = 0;
@@ -469,9 +520,13 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                         e_blk[j] = e_blk[j] * d0[j];
                     }
                     a = (f >= nyq) ? 0.0f : a;
+                    if constexpr (STEMS && VPL == 2) {
+                        tile[(j * TILE_S + tpos + i) * TSTRIDE + lane] = a * cos_reduced(mod_2pi(ph[j] + off[j]));
+                        continue;
+                    }
                     acc = __builtin_fmaf(a, cos_reduced(mod_2pi(ph[j] + off[j])), acc);
                 }
-                tile[(tpos + i) * TSTRIDE + lane] = acc;
+                if constexpr (!(STEMS && VPL == 2)) tile[(tpos + i) * TSTRIDE + lane] = acc;
             }
             block_tail(n0);
         }
@@ -603,6 +658,80 @@ __global__ void __launch_bounds__(256) bank_slot_sum_kernel(const float* __restr
             acc.x += accb.x; acc.y += accb.y; acc.z += accb.z; acc.w += accb.w;
         }
         reinterpret_cast<float4*>(out + (size_t)b * N)[i] = acc;
+    }
+}
+
+// Every voice's stem (bank_slot<.., STEMS>): the packed list of a segment with every (voice, sub-string) sub-row rounded up
+// to whole 32-entry blocks; a slot writes one row of p.out per block it carries: p.out [B, stem_blocks, N].
+template <int VPL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bank_stems_kernel(const OscParams p) {
+    extern __shared__ float lds_dyn[];
+    float* tile = lds_dyn;
+    SlotCtx c;
+    c.lane = threadIdx.x & 63;
+    const int nbs = p.R * p.spans;
+    c.cw_all = blockIdx.x / nbs;
+    const int bs = blockIdx.x - c.cw_all * nbs;
+    c.row = bs / p.spans;
+    c.span = bs - c.row * p.spans;
+    const int c0 = c.span * p.cps, c1 = min(c0 + p.cps, p.nchunks);
+    c.n_begin = c0 * DDSPP_CHUNK;
+    c.n_end = min(c1 * DDSPP_CHUNK, p.N);
+    const int lane = c.lane, S = p.S, Q = p.P * S;
+    constexpr int CAP = 64 * VPL;
+    const int cnt = lane < Q ? p.nk[((size_t)c.row * p.spans + c.span) * p.P + lane / S] : 0;
+    const int len = (cnt + 31) & ~31;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    c.total = __shfl(incl, 63);
+    c.first = CAP * c.cw_all;
+    if (c.first >= c.total) return;
+    c.qlo = 0;
+    c.qhi = Q;
+    int* offs = reinterpret_cast<int*>(tile);
+    offs[lane] = incl - len;                                 // exclusive block-aligned offsets of the sub-rows
+    offs[TSTRIDE + lane] = cnt;                              // ... and their audible counts (bank_slot: silent padding lanes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < p.U; i += 64) {
+        const int q = i >> 2;
+        (q < TILE ? tile + q * TSTRIDE + 64 : tile + TILE * TSTRIDE + 4 * (q - TILE))[i & 3] = p.whann[i];
+    }
+    if (VPL == 2 && (c.total - c.first > 64 || !p.half_slots))
+        bank_slot<2, false, false, true>(p, tile, c);
+    else
+        bank_slot<1, false, false, true>(p, tile, c);
+}
+
+// stems[row of (b, v), n] = the blocks of voice v in the packed list of (b, span of n), in block order (deterministic);
+// a voice that is silent in the span gets zeros.  One workgroup per (segment, span, voice).
+__global__ void __launch_bounds__(256) bank_stems_sum_kernel(const float* __restrict__ blocks, const int* __restrict__ nk,
+                                                           float* __restrict__ stems, int B, int P, int S, int N,
+                                                           int stem_blocks, int spans, int cps, int vmajor) {
+    int id = blockIdx.x;
+    const int v = id % P; id /= P;
+    const int span = id % spans;
+    const int b = id / spans;
+    const int* cnt = nk + ((size_t)b * spans + span) * P;
+    int first = 0;
+    for (int u = 0; u < v; ++u) first += S * ((cnt[u] + 31) >> 5);
+    const int nblk = S * ((cnt[v] + 31) >> 5);
+    const int n0 = span * cps * DDSPP_CHUNK, n1 = min(n0 + cps * DDSPP_CHUNK, N);
+    const float* src = blocks + ((size_t)b * stem_blocks + first) * N;
+    float* dst = stems + (size_t)(vmajor ? v * B + b : b * P + v) * N;
+    for (int i = n0 / 4 + threadIdx.x; i < n1 / 4; i += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < nblk; ++w) {
+            const float4 x = reinterpret_cast<const float4*>(src + (size_t)w * N)[i];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = acc;
     }
 }
 
@@ -800,6 +929,15 @@ void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream) {
     if (vpl == 1) hipLaunchKernelGGL((bank_compact_kernel<1>), grid, blk, lds, stream, p);
     else if (p.pair) hipLaunchKernelGGL((bank_compact_kernel<2, false, true>), grid, blk, lds, stream, p);
     else hipLaunchKernelGGL((bank_compact_kernel<2>), grid, blk, lds, stream, p);
+}
+
+void launch_bank_stems(const OscParams& p, int vpl, float* stems, hipStream_t stream) {
+    const size_t lds = (size_t)(TILE * TSTRIDE + (p.U > 4 * TILE ? p.U - 4 * TILE : 0)) * sizeof(float);
+    const dim3 grid((unsigned)((size_t)p.R * p.spans * p.wmax)), blk(64);
+    if (vpl == 1) hipLaunchKernelGGL((bank_stems_kernel<1>), grid, blk, lds, stream, p);
+    else hipLaunchKernelGGL((bank_stems_kernel<2>), grid, blk, lds, stream, p);
+    hipLaunchKernelGGL(bank_stems_sum_kernel, dim3((unsigned)((size_t)p.R * p.spans * p.P)), dim3(256), 0, stream, p.out, p.nk,
+                       stems, p.R, p.P, p.S, p.N, p.stem_blocks, p.spans, p.cps, p.vmajor);
 }
 
 void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream) {

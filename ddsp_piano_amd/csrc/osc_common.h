@@ -48,6 +48,7 @@ struct OscParams {
     int half_slots;                    // a 128-oscillator slot with <= 64 oscillators left runs the 64-oscillator body (DDSPP_OSC_HALF_SLOTS)
     int held_skip;                     // frame boundaries of held notes skip the frequency / classification work (DDSPP_OSC_HELD_SKIP)
     float* __restrict__ out_last;      // [B, N] the last voice's stem (split_last = 1), `out` then holds the other voices' sum
+    int stem_blocks;                   // every voice's stem (bank_stems_kernel): `out` is [B, stem_blocks, N], a row per 32-entry block of the packed list
     // streaming: the float32 running sum of chunk end phases (ddsp.core.angular_cumsum's cumsum over chunks) each
     // oscillator starts from, [rows, V]; null = 0 (a signal that starts here)
     const float* __restrict__ state_in;
@@ -159,6 +160,8 @@ __device__ __forceinline__ float in_vgpr(float x) {      // a wave-uniform value
 // compacted polyphonic bank: launches of bank_compact.hip (p.out = partial rows, see ddspp_polyphonic_additive)
 void launch_bank_compact(const OscParams& p, int vpl, hipStream_t stream);
 void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, hipStream_t stream);
+// every voice's stem: the bank with the harmonic sum stopped at voice boundaries + the sum of a voice's blocks -> stems [B * P, N]
+void launch_bank_stems(const OscParams& p, int vpl, float* stems, hipStream_t stream);
 // compacted scan of the chunks whose frequencies move (bank_scan_kernel; p as for launch_bank_compact + the scan_* fields)
 void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream);
 

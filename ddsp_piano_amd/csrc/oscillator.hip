@@ -1652,21 +1652,36 @@ size_t ddspp_polyphonic_additive_workspace_bytes(int B, int P, int T, int S, int
             + (size_t)B * wmax * N) * 4 + 4096;   /* partial rows */
 }
 
+// ... and for every voice's stem (ddspp_polyphonic_stems): the partial rows are one per 32-entry block of the packed list
+static size_t stem_blocks_of(int P, int S, int H) { return ((size_t)P * S * ((H + 31) / 32) + 3) & ~(size_t)3; }
+
+size_t ddspp_polyphonic_stems_workspace_bytes(int B, int P, int T, int S, int H, int U) {
+    if (B <= 0 || P <= 0 || T <= 0 || S <= 0 || H <= 0 || U <= 0) return 0;
+    const size_t N = (size_t)T * U;
+    const size_t V = (size_t)S * H, wmax = (P * V + 63) / 64 + 1;
+    return ddspp_polyphonic_additive_workspace_bytes(B, P, T, S, H, U) - (size_t)B * wmax * N * 4
+           + (size_t)B * stem_blocks_of(P, S, H) * N * 4;
+}
+
 static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                                     const float* harmonic_shifts, const float* inharm_coef, const int* audible,
                                     const float* decays, const float* decay_time,
                                     const float* wlin, const float* whann, const float* phase_state_in, float* audio,
                                     float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
-                                    int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && audio && workspace,
+                                    int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                                    float* stems = nullptr) {
+    DDSPP_REQUIRE(f0_hz && amplitudes && harmonic_distribution && wlin && whann && (audio || stems) && workspace,
                   "polyphonic_additive: null buffer");
+    DDSPP_REQUIRE(!stems || (!audio && !audio_last && !decays && !phase_state_in),
+                  "polyphonic_stems: stems come without a mix, a decay term or a carried phase state");
     DDSPP_REQUIRE(B > 0 && P > 0 && T > 0 && S > 0 && H > 0 && U > 0, "polyphonic_additive: bad dims");
     DDSPP_REQUIRE(U % BLK == 0, "polyphonic_additive: upsampling=%d must be a multiple of %d", U, BLK);
     DDSPP_REQUIRE(P * S <= 64, "polyphonic_additive: n_synths * n_substrings = %d exceeds 64", P * S);
     DDSPP_REQUIRE((long long)T * U < (1ll << 31) && (T * U) % 4 == 0, "polyphonic_additive: bad sample count");
     const int V = S * H, R = B * P, N = T * U;
     DDSPP_REQUIRE(pick_vpl(V) != 0, "polyphonic_additive: n_substrings*n_harmonics=%d exceeds 512", V);
-    DDSPP_REQUIRE(workspace_bytes >= ddspp_polyphonic_additive_workspace_bytes(B, P, T, S, H, U),
+    DDSPP_REQUIRE(workspace_bytes >= (stems ? ddspp_polyphonic_stems_workspace_bytes(B, P, T, S, H, U)
+                                            : ddspp_polyphonic_additive_workspace_bytes(B, P, T, S, H, U)),
                   "polyphonic_additive: workspace too small");
     const int nchunks = (N + DDSPP_CHUNK - 1) / DDSPP_CHUNK;
     // spans: enough (segment, span, slot) tasks to balance 256 CUs
@@ -1687,7 +1702,9 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
         ((long long)B * sp * ((P * V + 127) / 128) < env_int("DDSPP_OSC_COMPACT_VPL1_BELOW", 2048)) ? 1 : 2;
     // partial rows (wavefront slots) per segment: with audio_last the last voice's oscillators get slots of their own
     const int split_last = (audio_last && P > 1) ? 1 : 0;
-    const int wmax_a = ((P - split_last) * V + 64 * vpl_c - 1) / (64 * vpl_c);
+    const int stem_blocks = stems ? (int)stem_blocks_of(P, S, H) : 0;
+    const int wmax_a = stems ? (stem_blocks * 32 + 64 * vpl_c - 1) / (64 * vpl_c)
+                             : ((P - split_last) * V + 64 * vpl_c - 1) / (64 * vpl_c);
     const int wmax = wmax_a + (split_last ? (V + 64 * vpl_c - 1) / (64 * vpl_c) : 0);
 
     float* astart = (float*)workspace;
@@ -1767,6 +1784,13 @@ static int polyphonic_additive_impl(const float* f0_hz, const float* amplitudes,
     p.pair = (S == 2 && vpl_c == 2 && !decays && env_int("DDSPP_OSC_PAIR", 1)) ? 1 : 0;
     p.held_skip = env_int("DDSPP_OSC_HELD_SKIP", 1);
     p.nk = nk; p.wcount = wcount; p.out = partial;
+    if (stems) {                               // every voice's stem: the harmonic sum stops at voice boundaries
+        p.pair = 0;
+        p.stem_blocks = stem_blocks;
+        launch_bank_stems(p, vpl_c, stems, stream);
+        DDSPP_LAUNCH_CHECK();
+        return DDSPP_OK;
+    }
     launch_bank_compact(p, vpl_c, stream);
     // 4. slots -> audio (with audio_last: voices [0, P - 1) -> audio, the last voice -> audio_last)
     if (audio_last && !split_last) {           // P == 1: the only voice is the last one
@@ -1787,6 +1811,21 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
     return polyphonic_additive_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, inharm_coef, audible, nullptr,
                                     nullptr, wlin, whann, phase_state_in, audio, audio_last, B, P, T, S, H, U, sample_rate,
                                     spans, voice_major, workspace, workspace_bytes, stream);
+}
+
+// Every voice's stem of the same call -- stems [B * P, T * U], rows in the order of the controls: what
+// synthesize_from_csv.py:99-120 obtains by calling the additive processor once per voice, and what the outputs dictionary of
+// default_model.py's node list holds (every `sub_add_i` names a voice's signal).  The compacted bank with the harmonic sum
+// stopped at voice boundaries (bank_compact.hip, STEMS): lanes only for audible oscillators, voices packed back to back in
+// whole blocks of 32.
+int ddspp_polyphonic_stems(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                           const float* harmonic_shifts, const float* inharm_coef, const int* audible, const float* wlin,
+                           const float* whann, float* stems, int B, int P, int T, int S, int H, int U, float sample_rate,
+                           int spans, int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    DDSPP_REQUIRE(stems, "polyphonic_stems: null buffer");
+    return polyphonic_additive_impl(f0_hz, amplitudes, harmonic_distribution, harmonic_shifts, inharm_coef, audible, nullptr,
+                                    nullptr, wlin, whann, nullptr, nullptr, nullptr, B, P, T, S, H, U, sample_rate, spans,
+                                    voice_major, workspace, workspace_bytes, stream, stems);
 }
 
 // The same for SurrogateAdditive voices (surrogate_synth.py:11-104, configs/surrogate.gin): every partial's amplitude

@@ -383,7 +383,13 @@ def run(plan, inputs, noise=None, need_stems=True):
         if want_last:               # (voices 0 .. P-2 summed, the last voice's stem): one launch, no oscillator twice
             additive_mix, additive_last = additive_mix
         additive_sig = None
+    elif stems_compact and P * S <= 64 and not _lib.options.stems_single:
+        # the voices of a segment packed into the same wavefronts, the harmonic sum stopped at voice boundaries
+        additive_sig = core.polyphonic_stems(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],
+                                             None, B, N, additive.sample_rate, voice_major=vm, audible=ctl['_audible'],
+                                             inharm_coef=ctl['_inharm_coef'].reshape(R, T))
     elif stems_compact:
+        # every voice a segment of its own (more than 64 (voice, sub-string) rows per segment; DDSPP_STEMS_SINGLE=1)
         additive_sig = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T), ctl['harmonic_distribution'],
                                                 None, R, N, additive.sample_rate, audible=ctl['_audible'],
                                                 inharm_coef=ctl['_inharm_coef'].reshape(R, T))

@@ -170,6 +170,18 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
                               float* audio_last, int B, int P, int T, int S, int H, int U, float sample_rate, int spans,
                               int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* Every voice's stem of the same call: stems[B * P, T*U] = MultiInharmonic.get_signal of every voice, rows in the order of
+ * the controls -- what synthesize_from_csv.py:99-120 obtains by calling the additive processor once per voice
+ * (--decompose), and what the outputs dictionary of default_model.py:56-74's node list holds (every `sub_add_i` names a
+ * voice's signal).  The same compacted bank with the harmonic sum stopped at voice boundaries: lanes only for audible
+ * oscillators, the voices of a segment packed back to back in whole blocks of 32.  Arguments as
+ * ddspp_polyphonic_additive (no streaming state); workspace: ddspp_polyphonic_stems_workspace_bytes. */
+size_t ddspp_polyphonic_stems_workspace_bytes(int B, int P, int T, int S, int H, int U);
+int ddspp_polyphonic_stems(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
+                           const float* harmonic_shifts, const float* inharm_coef, const int* audible, const float* wlin,
+                           const float* whann, float* stems, int B, int P, int T, int S, int H, int U, float sample_rate,
+                           int spans, int voice_major, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* The same for SurrogateAdditive voices (surrogate_synth.py:11-104, configs/surrogate.gin through polyphonic_dag.py): every
  * partial's amplitude multiplied by |decays[t,k]| ** (decay_time[t] * U + n % U) inside the compacted bank.  decays[B*P,T,H]
  * as ddspp_surrogate_decays leaves them, decay_time[B*P,T]; one sub-string; workspace as ddspp_polyphonic_additive (S = 1). */

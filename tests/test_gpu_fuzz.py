@@ -90,8 +90,18 @@ def test_compacted_bank_equals_the_stems(seed, B, P, T, H, S, U, flags):
                                           audible=ctl['_audible'], inharm_coef=inh, split_last=True)
     assert (last - stems[:, P - 1]).abs().max().item() < 6e-6 * scale
     assert ((rest + last) - want).abs().max().item() < 6e-6 * scale
+    # every voice's stem from the same packing with the harmonic sum stopped at voice boundaries (ddspp_polyphonic_stems)
+    flat = stems.reshape(R, N)
+    sscale = max(1.0, float(flat.abs().max()))
+    for name, kw in (('counts', dict(audible=ctl['_audible'])), ('no counts', {}), ('spans=1', dict(audible=ctl['_audible'], spans=1)),
+                     ('spans=3, shifts given', dict(audible=ctl['_audible'], spans=3, shifts=ctl['harmonic_shifts']))):
+        shifts = kw.pop('shifts', None)
+        got = core.polyphonic_stems(ctl['f0_hz'], amp, ctl['harmonic_distribution'], shifts, B, N, sr,
+                                    inharm_coef=None if shifts is not None else inh, **kw)
+        assert (got - flat).abs().max().item() < 4e-6 * sscale, ('stems', name)
     if R * N * H <= 16 * 36000 * 128:                      # small enough for the numpy oracle: a few seconds
         ref = O.MultiInharmonic(sample_rate=sr, inference=True, scale_fn=getattr(O, scale_name), **flags)(**raw)
+        assert rms_err(got.cpu().numpy(), ref) < 2e-6
         ref = ref.reshape(B, P, N).sum(1)
         assert rms_err(outs['counts'].cpu().numpy(), ref) < 2e-6
 

@@ -614,18 +614,21 @@ def test_compacted_scan_of_moving_chunks(monkeypatch):
 
 
 def test_every_voice_stem_through_the_compacted_bank(monkeypatch):
-    """Round 5: need_stems=True renders the additive stems with the compacted bank, every voice a segment of its own
-    (ddspp_polyphonic_additive with B' = B P, P' = 1: lanes below each row's audible maximum only, silent rows cost
-    nothing), instead of the per-voice fused kernel (DDSPP_NO_STEMS_COMPACT=1).  Same dictionary, same stems to float32
-    rounding of the harmonic sum, one and two sub-strings, rows voice major and segment major, against the oracle."""
+    """Round 5: need_stems=True renders the additive stems with the compacted bank -- ddspp_polyphonic_stems: the voices of
+    a segment packed into the same wavefronts in whole blocks of 32 oscillators, the harmonic sum stopped at voice
+    boundaries (or, DDSPP_STEMS_SINGLE=1, ddspp_polyphonic_additive with every voice a segment of its own) -- instead of
+    the per-voice fused kernel (DDSPP_NO_STEMS_COMPACT=1).  Same dictionary, same stems to float32 rounding of the harmonic
+    sum, one and two sub-strings, rows voice major and segment major, harmonic counts that are no multiple of 32, against
+    the oracle."""
     import ddsp_piano_amd as dp
     from ddsp_piano_amd import _lib
     rng = np.random.default_rng(91)
     for (B, P, T, H, K, S, sr, L, vm) in [(3, 5, 60, 128, 96, 1, 24000, 3000, False), (2, 4, 50, 96, 64, 2, 16000, 2000, True),
-                                          (64, 4, 125, 128, 96, 1, 24000, 3000, False)]:
+                                          (2, 3, 40, 48, 32, 1, 8000, 1000, False), (3, 7, 50, 100, 64, 1, 16000, 1000, True),
+                                          (64, 4, 125, 128, 96, 1, 24000, 3000, False), (40, 16, 130, 128, 96, 1, 24000, 3000, True)]:
         N = T * (sr // 250)
         feats = _features(rng, B, P, T, H, K, S, L)
-        if B >= 64:                          # a vibrato on every other voice: the compacted scan of moving chunks on single-voice segments
+        if B >= 40:                          # a vibrato on every other voice: the compacted scan of moving chunks
             tt = np.arange(T, dtype=np.float32)[None, :, None]
             for i in range(0, P, 2):
                 feats[f'f0_hz_{i}'] = (feats[f'f0_hz_{i}'] * (1 + 0.004 * np.sin(0.13 * tt + i))).astype(np.float32)
@@ -642,8 +645,12 @@ def test_every_voice_stem_through_the_compacted_bank(monkeypatch):
         monkeypatch.setattr(_lib.options, 'no_stems_compact', True)
         want = pg(dev, return_outputs_dict=True, need_stems=True, noise=nz)
         monkeypatch.setattr(_lib.options, 'no_stems_compact', False)
+        monkeypatch.setattr(_lib.options, 'stems_single', True)      # every voice a segment of its own (ddspp_polyphonic_additive, P' = 1)
+        single = pg(dev, return_outputs_dict=True, need_stems=True, noise=nz)['controls']['voices']['additive']
+        monkeypatch.setattr(_lib.options, 'stems_single', False)     # the default: ddspp_polyphonic_stems
         got = pg(dev, return_outputs_dict=True, need_stems=True, noise=nz)
         gv, wv = got['controls']['voices'], want['controls']['voices']
+        assert float((single - wv['additive']).abs().max()) < 4e-6 * max(1.0, float(wv['additive'].abs().max())), (B, P, S)
         assert gv['additive'].shape == wv['additive'].shape == (B, P, N)
         scale = max(1.0, float(wv['additive'].abs().max()))
         assert float((gv['additive'] - wv['additive']).abs().max()) < 4e-6 * scale, (B, P, S)
@@ -654,7 +661,7 @@ def test_every_voice_stem_through_the_compacted_bank(monkeypatch):
         for k, v in want['controls']['additive']['controls'].items():
             assert torch.equal(got['controls']['additive']['controls'][k], v), k
         assert torch.equal(got['controls']['noise']['controls']['magnitudes'], want['controls']['noise']['controls']['magnitudes'])
-        if B < 64:
+        if B < 40:
             osyn = O.MultiInharmonic(sample_rate=sr, inference=True)
             for i in (0, P - 1):
                 ref = osyn(*[feats[f'{k}_{i}'] for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Every voice's additive stem, two ways, on the headline inputs: the per-voice fused kernel (ddspp_harmonic_synthesis, what
 need_stems=True runs) against the compacted bank with every voice as its own segment (ddspp_polyphonic_additive, B' = B P,
-P' = 1).  usage: python tools/ab_stems.py [case]"""
+P' = 1).  and against ddspp_polyphonic_stems (the voices of a segment packed, the harmonic sum stopped at voice boundaries).
+usage: python tools/ab_stems.py [case]"""
 import os
 import sys
 
@@ -40,13 +41,19 @@ def bank():
                                     audible=ctl_b['_audible'], inharm_coef=ctl_b['_inharm_coef'].reshape(R, T))
 
 
-a, b = fused(), bank()
-print(case, 'max |fused - bank| =', (a - b).abs().max().item(), 'rms', a.pow(2).mean().sqrt().item())
-for name, fn, opts in (('fused rows', fused, {}), ('bank P=1 (64-oscillator slots)', bank, {}),
+def packed():
+    return core.polyphonic_stems(ctl_b['f0_hz'], ctl_b['amplitudes'].reshape(R, T), ctl_b['harmonic_distribution'], None, B, N, sr,
+                                 audible=ctl_b['_audible'], inharm_coef=ctl_b['_inharm_coef'].reshape(R, T))
+
+
+a, b, c = fused(), bank(), packed()
+print(case, 'max |fused - bank| =', (a - b).abs().max().item(), 'max |fused - packed| =', (a - c).abs().max().item(),
+      'rms', a.pow(2).mean().sqrt().item())
+for name, fn, opts in (('fused rows', fused, {}), ('packed stems (ddspp_polyphonic_stems)', packed, {}), ('bank P=1 (64-oscillator slots)', bank, {}),
                        ('bank P=1, 128-oscillator slots', bank, {'DDSPP_OSC_COMPACT_VPL1_SINGLE': 0})):
     for k, v in opts.items():
         _lib.set_option(k, v)
     ts = bench.event_times(fn, 10, warmup=3)
-    print(f'{name:34s}', bench.ms_summary(ts))
+    print(f'{name:40s}', bench.ms_summary(ts))
     for k in opts:
         _lib.set_option(k, 1)
