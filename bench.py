@@ -951,7 +951,8 @@ def main():
                                                                       'group(features, return_outputs_dict=True)'),
                         'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
         # every voice's stems (what synthesize_from_csv.py:99-120 gets by re-running processors one by one): the compacted
-        # bank with every voice a segment of its own, per-voice noise rows, the mixer in the DAG's order
+        # bank with the harmonic sum stopped at voice boundaries (ddspp_polyphonic_stems), per-voice noise rows, the mixer in
+        # the DAG's order
         ts = event_times(lambda: pg(feats, return_outputs_dict=True, need_stems=True), 10, warmup=2)
         extra['all_stems_call'] = {'workload': 'the headline batch through group(features, return_outputs_dict=True, '
                                                'need_stems=True): the additive and noise stems of all 16 voices',
