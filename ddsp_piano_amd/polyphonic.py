@@ -292,9 +292,11 @@ def run(plan, inputs, noise=None, need_stems=True):
     want_all = need_stems is True or need_stems == 'all'
     want_last = need_stems == 'last'
     compact = (not want_all) and additive.inference and P * S <= 64 and N % 4 == 0
-    # every voice's stems (round 5, late): the same compacted bank with every voice as a segment of its own -- lanes only
-    # below each row's audible maximum, silent rows cost nothing, the memoised pre-pass and the compacted scan as on the
-    # group route.  Same box, 1024 rows of config 3: 2.05 -> 1.82 ms; two sub-strings 4.65 -> 2.47; every f0 moving 3.79 -> 3.44.
+    # every voice's stems (round 5, late): the compacted bank as well -- core.polyphonic_stems, the group route's packing with
+    # the harmonic sum stopped at voice boundaries (lanes only for audible partials, silent rows cost nothing, the memoised
+    # pre-pass and the compacted scan as on the group route); more than 64 (voice, sub-string) rows per segment: every voice
+    # as a segment of its own.  Same box, 1024 rows of config 3, per-voice fused kernel -> one-voice segments -> packed:
+    # 2.03 -> 1.84 -> 1.19 ms; two sub-strings 4.66 -> 2.49 -> 2.14; every f0 moving 3.81 -> 3.45 -> 2.15.
     stems_compact = (want_all and additive.inference and S <= 64 and S * H <= 512 and N % 4 == 0 and
                      not _lib.options.no_stems_compact)
     if surrogate:                  # (the compacted bank takes the decay term when get_controls runs as kernels)
