@@ -148,6 +148,7 @@ SIGNATURES = {
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'ddspp_polyphonic_mix': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ddspp_add_chain_paired': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_mix_voices': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ddspp_mix_last_voice': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),

@@ -514,6 +514,30 @@ __global__ void __launch_bounds__(256) polyphonic_mix_kernel(const float* __rest
     }
 }
 
+// Every node of the add chain of default_model.py:56-74, with all its intermediate signals: sub[b, v] = noise[b, v] +
+// additive[b, v] (`sub_add_v`; for v = 0 this is `add_0` itself), run[b, 0] = sub[b, 0], run[b, v] = run[b, v - 1] + sub[b, v]
+// (`add_v`).  One pass over the stems instead of 2 P - 1 launches.
+__global__ void __launch_bounds__(256) add_chain_paired_kernel(const float* __restrict__ additive,
+                                                             const float* __restrict__ noise, float* __restrict__ sub,
+                                                             float* __restrict__ run, int B, int P, int N, int voice_major) {
+    const int n4 = N / 4;
+    const size_t total = (size_t)B * n4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int b = (int)(g / n4), i = (int)(g - (size_t)b * n4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < P; ++v) {
+            const size_t off = (voice_major ? (size_t)v * B + b : (size_t)b * P + v) * n4 + i;
+            const float4 z = reinterpret_cast<const float4*>(noise)[off], a = reinterpret_cast<const float4*>(additive)[off];
+            const float4 s = make_float4(z.x + a.x, z.y + a.y, z.z + a.z, z.w + a.w);
+            if (v == 0) acc = s;
+            else { acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w; }
+            const size_t o = ((size_t)b * P + v) * n4 + i;
+            reinterpret_cast<float4*>(sub)[o] = s;
+            reinterpret_cast<float4*>(run)[o] = acc;
+        }
+    }
+}
+
 // out[b, n] = sum_v a[b, v, n] (PA rows) + sum_v z[b, v, n] (PZ rows): the add chain when one operand is
 // already a per-segment mix
 // tail_z / tail_a / out_prev (all or none): out_prev = the sum above, out = (out_prev + tail_z) + tail_a -- the last step
@@ -734,6 +758,18 @@ int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, 
                   "polyphonic_mix: bad dims");
     hipLaunchKernelGGL(polyphonic_mix_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream,
                        additive, noise, out, B, P, N, out_stride, voice_major, out_prev);
+    DDSPP_LAUNCH_CHECK();
+    return DDSPP_OK;
+}
+
+// The whole add chain of default_model.py:56-74 with every node's signal: additive / noise [B,P,N] (or [P,B,N]) ->
+// sub [B,P,N] (`sub_add_v`; sub[:, 0] = `add_0`), run [B,P,N] (`add_v`), both segment major.
+int ddspp_add_chain_paired(const float* additive, const float* noise, float* sub, float* run, int B, int P, int N,
+                           int voice_major, hipStream_t stream) {
+    DDSPP_REQUIRE(additive && noise && sub && run, "add_chain_paired: null buffer");
+    DDSPP_REQUIRE(B > 0 && P > 0 && N > 0 && N % 4 == 0, "add_chain_paired: bad dims");
+    hipLaunchKernelGGL(add_chain_paired_kernel, dim3(stream_grid((size_t)B * (N / 4))), dim3(256), 0, stream, additive, noise,
+                       sub, run, B, P, N, voice_major);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

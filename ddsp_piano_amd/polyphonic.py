@@ -500,19 +500,22 @@ def run(plan, inputs, noise=None, need_stems=True):
     if default_shape:
         # every `sub_add_i` and `add_i` of default_model.py:56-74, in the DAG's order: add_0 = noise_0 + additive_0,
         # sub_add_i = noise_i + additive_i, add_i = add_{i-1} + sub_add_i
+        # (one pass over the stems, ddspp_add_chain_paired, instead of 2 P - 1 add kernels on strided views: 1.1 -> 0.25 ms
+        # at config 3)
+        subs = torch.empty((B, P, N), dtype=torch.float32, device=dev)
+        runs = torch.empty((B, P, N), dtype=torch.float32, device=dev)
+        _lib.check(_lib_().ddspp_add_chain_paired(_ptr(additive_sig), _ptr(noise_sig), _ptr(subs), _ptr(runs), B, P, N, vmi,
+                                                  _stream()))
         additive_sig = per_voice(additive_sig, (N,))
         noise_sig = per_voice(noise_sig, (N,))
-        run_sum = core.add_signals([noise_sig[:, 0], additive_sig[:, 0]])
-        outputs[plan.adds[0].name] = {'signal': run_sum,
+        outputs[plan.adds[0].name] = {'signal': runs[:, 0],
                                       'controls': {'signal_one': noise_sig[:, 0], 'signal_two': additive_sig[:, 0]}}
         for i in range(1, P):
-            sub_i = core.add_signals([noise_sig[:, i], additive_sig[:, i]])
-            outputs[plan.subs[i].name] = {'signal': sub_i,
+            outputs[plan.subs[i].name] = {'signal': subs[:, i],
                                           'controls': {'signal_one': noise_sig[:, i], 'signal_two': additive_sig[:, i]}}
-            nxt = core.add_signals([run_sum, sub_i])
-            outputs[plan.adds[i].name] = {'signal': nxt, 'controls': {'signal_one': run_sum, 'signal_two': sub_i}}
-            run_sum = nxt
-        dry = run_sum
+            outputs[plan.adds[i].name] = {'signal': runs[:, i], 'controls': {'signal_one': runs[:, i - 1], 'signal_two': subs[:, i]}}
+        dry = runs[:, P - 1].contiguous()                 # (the reverb takes rows N apart)
+        outputs[plan.adds[P - 1].name]['signal'] = dry
     else:
         prev = torch.empty((B, N), dtype=torch.float32, device=dev) if P > 1 else None
         _lib.check(_lib_().ddspp_polyphonic_mix(_ptr(additive_sig), _ptr(noise_sig), _ptr(dry), _ptr(prev), B, P, N, N,

@@ -49,7 +49,7 @@ const char* ddspp_last_error(void);
  * running sum of chunk end phases is added to a chunk wrapped, `tf.cumsum(offsets, axis=1) % (2 pi)` (the default, 0), or as it
  * is (DDSPP_ANGULAR_OFFSETS_PLAIN = 1).  Every entry point that runs the angular cumsum reads it at launch
  * (ddspp_cos_oscillator_bank, ddspp_harmonic_synthesis, ddspp_surrogate_harmonic_synthesis, ddspp_polyphonic_additive,
- * ddspp_polyphonic_surrogate_additive, ddspp_group_run); a caller that resets the options sets it again. */
+ * ddspp_polyphonic_stems, ddspp_polyphonic_surrogate_additive, ddspp_group_run); a caller that resets the options sets it again. */
 int ddspp_option(const char* name, int default_value);      /* the value in effect */
 int ddspp_set_option(const char* name, int value);
 void ddspp_reload_options(void);
@@ -259,6 +259,13 @@ int ddspp_add_signals(const float* const* srcs, int nsrc, float* out, size_t n, 
  * mix before the last voice, i.e. the first operand of the last `add` node. */
 int ddspp_polyphonic_mix(const float* additive, const float* noise, float* out, float* out_prev, int B, int P, int N,
                          int out_stride, int voice_major, hipStream_t stream);
+
+/* the whole add chain of default_model.py:56-74 with every node's signal (that node list NAMES its Add nodes, so the
+ * reference's outputs dictionary holds them all): additive / noise [B,P,N] (voice_major = 0) or [P,B,N] -> sub[B,P,N],
+ * sub[b, v] = noise[b, v] + additive[b, v] (`sub_add_v`; v = 0: `add_0`), and run[B,P,N], run[b, v] = run[b, v-1] + sub[b, v]
+ * (`add_v`), both segment major.  One pass over the stems. */
+int ddspp_add_chain_paired(const float* additive, const float* noise, float* sub, float* run, int B, int P, int N,
+                           int voice_major, hipStream_t stream);
 
 /* out[b] = sum of the PA rows a[b, :] + the PZ rows z[b, :] ([B,PA,N], [B,PZ,N], or [PA,B,N], [PZ,B,N] when
  * voice_major = 1 -> rows of out_stride floats): the add chain when the additive operand is already the
