@@ -162,7 +162,7 @@ def test_harmonic_synthesis_under_both_resize_rules(core, rule):
 @pytest.mark.parametrize('rule', ['wrapped', 'plain'])
 def test_oscillator_kernels_under_both_offset_rules(core, rule):
     """ddsp.core.angular_cumsum's offset sum, wrapped or not (round 5, the seventh switch): the materialised kernel, the
-    fused per-voice kernel, the compacted bank and a streamed render against the oracle under the same rule -- and, so that
+    fused per-voice kernel, the compacted bank (the mix and every voice's stem) and a streamed render against the oracle under the same rule -- and, so that
     the case decides something, NOT against the oracle under the other rule.  340 chunks, partials up to Nyquist."""
     import ddsp_piano_amd as dp
     other = 'plain' if rule == 'wrapped' else 'wrapped'
@@ -203,3 +203,9 @@ def test_oscillator_kernels_under_both_offset_rules(core, rule):
                                    inharm_coef=ctl['_inharm_coef'].reshape(P, T)).cpu().numpy()
     want = (refs[0] + refs[1]) + refs[2]
     assert rms_err(mix, want) < 1e-5 * max(1.0, float(np.sqrt(np.mean(want ** 2))))
+    # (4) every voice's stem from the same packing (ddspp_polyphonic_stems)
+    stems = core.polyphonic_stems(ctl['f0_hz'], ctl['amplitudes'].reshape(P, T), ctl['harmonic_distribution'], None, B, T * U, sr,
+                                  audible=ctl['_audible'], inharm_coef=ctl['_inharm_coef'].reshape(P, T)).cpu().numpy()
+    for i in range(P):
+        assert rms_err(stems[i:i + 1], refs[i]) < 1e-5 * max(1.0, float(np.sqrt(np.mean(refs[i] ** 2)))), i
+    assert rms_err(stems[0:1], ref0_other) > 10 * rms_err(stems[0:1], refs[0])
