@@ -17,13 +17,13 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
+SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'osc_stream.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
            'noise.hip', 'noise_win.hip', 'noise_bands.hip', 'reverb.hip', 'reverb_part.hip', 'fdn.hip', 'probe.hip', 'group.cpp']
 ARCH = 'gfx950'
 HEADERS = ['ddspp_common.h', 'osc_common.h', 'noise_win.h', 'reverb_part.h', os.path.join('..', '..', 'include', 'ddspp.h')]
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
-PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'noise_win.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'],
+PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'noise_win.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'], 'osc_stream.hip': ['-fno-slp-vectorize'],
                   'bank_compact.hip': ['-fno-slp-vectorize']}
 
 DDSPP_OK = 0

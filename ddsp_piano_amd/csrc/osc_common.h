@@ -164,5 +164,8 @@ void launch_bank_slot_sum(const OscParams& p, float* audio, float* audio_last, h
 void launch_bank_stems(const OscParams& p, int vpl, float* stems, hipStream_t stream);
 // compacted scan of the chunks whose frequencies move (bank_scan_kernel; p as for launch_bank_compact + the scan_* fields)
 void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream);
+// the HBM-roofline form of cos_oscillator_bank (osc_stream.hip): materialised envelopes, angular cumsum, summed, H % 64 == 0
+bool osc_stream_applies(const OscParams& p);
+void launch_osc_stream(const OscParams& p, hipStream_t stream);
 
 }  // namespace ddspp

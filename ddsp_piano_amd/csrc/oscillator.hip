@@ -1428,6 +1428,8 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
         }
         if constexpr (DECAY)               // (phases do not depend on the decay term: the pre-pass is the plain one)
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true, true>), dim3(nblk_main), blk, lds, stream, p);
+        else if (!FUSED && sum && osc_stream_applies(p) && env_int("DDSPP_OSC_STREAM", 1))
+            launch_osc_stream(p, stream);          // osc_stream.hip: the same sums, written for the HBM-bound shape
         else if (sum)
             hipLaunchKernelGGL((osc_kernel<VPL, FUSED, MODE_MAIN, true>), dim3(nblk_main), blk, lds, stream, p);
         else

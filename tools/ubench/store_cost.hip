@@ -1,0 +1,115 @@
+// Round 6 probe: what do the audio stores of the graded kernel cost the read stream?  (tools/ubench/osc_graded.hip: the
+// kernel without its global store runs 3-6 % faster, although the stores are 0.4 % of the bytes.)
+// The bare read pattern of the kernel (2 wavefronts per row, 256-byte halves of both arrays, 48 non-temporal loads in
+// flight, 1024 rows x 72000 samples x 128 floats x 2 arrays) + one 128-byte store per 32 samples and row from wavefront 0,
+// with every cache-policy combination of the gfx950 store (sc0 / sc1 / nt), twice the bytes, and the bytes kept in L2.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+template <int POL>
+__device__ __forceinline__ void store_pol(float* p, float v) {
+    if (POL == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (POL == 1) asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 2) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (POL == 3) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 5) asm volatile("global_store_dword %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 6) asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 7) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+// MODE: 0 = wavefront 0 stores 32 floats per 32 samples; 1 = the same address range again and again (4 KB per row);
+//       2 = 64 floats per 32 samples (twice the bytes, into a [R, 2N] buffer); 3 = no store; 4 = the stores of 8 tiles
+//       issued together (8 x 128 bytes every 256 samples)
+template <int POL, int MODE>
+__global__ void __launch_bounds__(128) read_store(const float* __restrict__ fe, const float* __restrict__ ae, int N, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const float* f = fe + (size_t)blockIdx.x * N * 128 + 64 * g + lane;
+    const float* a = ae + (size_t)blockIdx.x * N * 128 + 64 * g + lane;
+    float* o = out + (size_t)blockIdx.x * N * (MODE == 2 ? 2 : 1);
+    float acc = 0.f;
+    constexpr int NB = 4, B = 8;
+    float vf[NB][B], va[NB][B];
+    auto load = [&](int n0, float* bf, float* ba) {
+        const int nc = min(n0, N - B);
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            bf[u] = __builtin_nontemporal_load(f + (size_t)(nc + u) * 128);
+            ba[u] = __builtin_nontemporal_load(a + (size_t)(nc + u) * 128);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) load(b * B, vf[b], va[b]);
+    for (int n0 = 0; n0 < N; n0 += NB * B) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            load(n0 + (b + NB - 1) * B, vf[(b + NB - 1) % NB], va[(b + NB - 1) % NB]);
+#pragma unroll
+            for (int u = 0; u < B; ++u) acc += vf[b][u] + va[b][u];
+        }
+        if (MODE == 0 && g == 0 && lane < 32) store_pol<POL>(o + n0 + lane, acc);
+        if (MODE == 1 && g == 0 && lane < 32) store_pol<POL>(o + (n0 & 1023) + lane, acc);
+        if (MODE == 2 && g == 0) store_pol<POL>(o + 2 * n0 + lane, acc);
+        if (MODE == 4 && g == 0 && lane < 32 && (n0 & 255) == 224) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) store_pol<POL>(o + n0 - 224 + 32 * k + lane, acc);
+        }
+    }
+    if (acc == 1.2345e30f) out[0] = acc;
+}
+
+template <typename F>
+float timeit(F f) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    f();
+    (void)hipDeviceSynchronize();
+    float sum = 0;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        f();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        sum += ms;
+    }
+    return sum / 3;
+}
+
+int main() {
+    const size_t R = 1024, N = 72000;
+    const size_t bytes = R * N * 128 * 4;
+    float *fe, *ae, *out;
+    if (hipMalloc(&fe, bytes) != hipSuccess || hipMalloc(&ae, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMalloc(&out, R * N * 8);
+    (void)hipMemset(fe, 0x3c, bytes);
+    (void)hipMemset(ae, 0x3c, bytes);
+    const double b = 2.0 * (double)bytes;
+    float ms, base = 0;
+#define RUN(name, POL, MODE)                                                                                       \
+    ms = timeit([&] { hipLaunchKernelGGL((read_store<POL, MODE>), dim3(R), dim3(128), 0, 0, fe, ae, (int)N, out); }); \
+    if (MODE == 3) base = ms;                                                                                      \
+    printf("%-52s: %7.3f ms  %5.0f GB/s read  (+%.3f ms over no store)\n", name, ms, b / ms / 1e6, ms - base);
+    for (int rep = 0; rep < 2; ++rep) {
+        RUN("no store", 0, 3);
+        RUN("128 B / 32 samples, plain", 0, 0);
+        RUN("128 B / 32 samples, nt", 1, 0);
+        RUN("128 B / 32 samples, sc0", 2, 0);
+        RUN("128 B / 32 samples, sc1", 3, 0);
+        RUN("128 B / 32 samples, sc0 sc1", 4, 0);
+        RUN("128 B / 32 samples, sc0 nt", 5, 0);
+        RUN("128 B / 32 samples, sc1 nt", 6, 0);
+        RUN("128 B / 32 samples, sc0 sc1 nt", 7, 0);
+        RUN("same 4 KB per row again and again, plain", 0, 1);
+        RUN("same 4 KB per row again and again, nt", 1, 1);
+        RUN("same 4 KB per row again and again, sc0 sc1", 4, 1);
+        RUN("256 B / 32 samples (twice the bytes), plain", 0, 2);
+        RUN("256 B / 32 samples (twice the bytes), nt", 1, 2);
+        RUN("8 x 128 B every 256 samples, plain", 0, 4);
+        RUN("8 x 128 B every 256 samples, nt", 1, 4);
+    }
+    return 0;
+}
