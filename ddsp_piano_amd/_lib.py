@@ -113,6 +113,7 @@ SIGNATURES = {
     'ddspp_group_run': (c_int, [c_void_p] * 11 + [ctypes.c_size_t, c_void_p]),
     'ddspp_linear_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
     'ddspp_hbm_read_probe': (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    'ddspp_hbm_write_probe': (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'ddspp_fma_probe': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ddspp_walk_weights_host': (c_int, [c_int, c_int, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'ddspp_fir_tables_shape': (c_int, [c_int, c_int, c_void_p, c_void_p]),

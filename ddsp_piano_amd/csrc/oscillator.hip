@@ -525,16 +525,22 @@ __global__ void __launch_bounds__(256) osc_kernel(const OscParams p) {
     } else {
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b) load_block(n_begin + b * BLK, fbuf[b], abuf[b]);
-        for (int n0 = n_begin; n0 < n_end; n0 += NBUF * BLK) {
+        // whole turns of the ring without a branch around a load: hipcc's s_waitcnt bookkeeping joins the states of all
+        // paths into a block, and with `if (nb0 < n_end)` around every ring position (rounds 1-5) the waits assumed the
+        // skipped loads had never been issued -- vmcnt(16 .. 47) where 48 .. 62 is right, one or two blocks in flight
+        // instead of three (found in round 6, osc_stream.hip)
+        int n0 = n_begin;
+        for (; n0 + NBUF * BLK <= n_end; n0 += NBUF * BLK) {
 #pragma unroll
             for (int b = 0; b < NBUF; ++b) {
-                const int nb0 = n0 + b * BLK;
-                if (nb0 < n_end) {
-                    load_block(nb0 + (NBUF - 1) * BLK, fbuf[(b + NBUF - 1) % NBUF], abuf[(b + NBUF - 1) % NBUF]);
-                    do_block(nb0, fbuf[b], abuf[b]);
-                }
+                load_block(n0 + (b + NBUF - 1) * BLK, fbuf[(b + NBUF - 1) % NBUF], abuf[(b + NBUF - 1) % NBUF]);
+                do_block(n0 + b * BLK, fbuf[b], abuf[b]);
             }
         }
+        // the last, partial turn (at most NBUF - 1 blocks): they are in the ring already
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b)
+            if (n0 + b * BLK < n_end) do_block(n0 + b * BLK, fbuf[b], abuf[b]);
     }
 }
 

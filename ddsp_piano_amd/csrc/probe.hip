@@ -25,6 +25,24 @@ __global__ void __launch_bounds__(256) hbm_read_streams_kernel(const float* __re
     if (acc == 1.2345e30f) sink[0] = acc;        // never true for finite audio-rate data: keeps the loads alive
 }
 
+// The write ceiling (round 6; the stand-alone upsamplers are pure write streams): every wavefront fills its own contiguous
+// region with 16-byte stores, 1 KB per instruction, non-temporal or plain.
+template <bool NT>
+__global__ void __launch_bounds__(256) hbm_write_streams_kernel(float* __restrict__ x, size_t per_wave, float v) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v* p = reinterpret_cast<f4v*>(x + wave * per_wave) + lane;
+    const f4v val = {v, v + 1.0f, v + 2.0f, v + 3.0f};
+    for (size_t i = 0; i < per_wave / 4; i += 64 * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (NT) __builtin_nontemporal_store(val, p + i + u * 64);
+            else p[i + u * 64] = val;
+        }
+    }
+}
+
 // The other ceiling (round 5; bench.py's `roofline_step.measured_ceiling`): what the chip SUSTAINS in wave64 multiply-adds.
 // The step's two large kernels are bound by VALU issue, and "one instruction per 2 cycles at 2.4 GHz" is not what a SIMD
 // delivers for long: under a pure stream of independent v_fmac_f32 (three VGPR operands, twelve accumulators per lane -- the
@@ -81,6 +99,21 @@ int ddspp_hbm_read_probe(const float* x, size_t n_floats, int n_waves, float* si
     hipLaunchKernelGGL((ddspp::hbm_read_streams_kernel<16>), dim3(n_waves / 4), dim3(256), 0, stream, x, per_wave, sink);
     DDSPP_LAUNCH_CHECK();
     if (bytes_read) *bytes_read = per_wave * (size_t)n_waves * sizeof(float);
+    return DDSPP_OK;
+}
+
+// Fills the first `n_floats` (rounded down to whole 8 KB wavefront steps) of x from `n_waves` concurrent streams (a multiple of
+// 4), with non-temporal (1) or plain (0) 16-byte stores; *bytes_written: what was written.
+int ddspp_hbm_write_probe(float* x, size_t n_floats, int n_waves, int nontemporal, size_t* bytes_written, hipStream_t stream) {
+    DDSPP_REQUIRE(x && n_waves >= 4 && n_waves % 4 == 0, "hbm_write_probe: bad arguments");
+    DDSPP_REQUIRE((uintptr_t)x % 16 == 0, "hbm_write_probe: the buffer must be 16-byte aligned");
+    constexpr size_t chunk = 64 * 4 * 8;                  // floats per wavefront step
+    const size_t per_wave = (n_floats / (size_t)n_waves) / chunk * chunk;
+    DDSPP_REQUIRE(per_wave > 0, "hbm_write_probe: buffer too small for %d streams", n_waves);
+    if (nontemporal) hipLaunchKernelGGL((ddspp::hbm_write_streams_kernel<true>), dim3(n_waves / 4), dim3(256), 0, stream, x, per_wave, 1.0f);
+    else hipLaunchKernelGGL((ddspp::hbm_write_streams_kernel<false>), dim3(n_waves / 4), dim3(256), 0, stream, x, per_wave, 1.0f);
+    DDSPP_LAUNCH_CHECK();
+    if (bytes_written) *bytes_written = per_wave * (size_t)n_waves * sizeof(float);
     return DDSPP_OK;
 }
 

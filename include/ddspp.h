@@ -295,6 +295,10 @@ int ddspp_mix_last_voice_paired(const float* a, int PA, const float* z, int PZ, 
  * could reach at most on that buffer in this run (bench.py: roofline.measured_peak).  sink: one float of device memory
  * (never written for finite data); *bytes_read (host, may be NULL): the bytes the launch reads. */
 int ddspp_hbm_read_probe(const float* x, size_t n_floats, int n_waves, float* sink, size_t* bytes_read, hipStream_t stream);
+/* The write-side counterpart: x[0 .. n_floats) filled by n_waves concurrent wavefront streams with 16-byte stores (1 KB per
+ * instruction), non-temporal (1) or plain (0) -- the rate the stand-alone upsamplers (ddspp_resample_linear / _window, pure
+ * write streams) could reach at most in this run (bench.py: extras.three_operator_chain.write_ceiling). */
+int ddspp_hbm_write_probe(float* x, size_t n_floats, int n_waves, int nontemporal, size_t* bytes_written, hipStream_t stream);
 /* Measurement aid for the VALU-bound kernels of the step (bench.py: roofline_step.measured_ceiling): a pure stream of
  * independent wave64 multiply-adds, `iters` x 192 per lane, on `waves_per_simd` wavefronts per SIMD of the whole chip;
  * *wave_fmas_per_simd = instructions each SIMD executed.  Timed by the caller (HIP events, ~20 ms so that the power
