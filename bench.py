@@ -431,9 +431,9 @@ def measure_roofline(dp, base, args, T, U, device):
                              base['f0_hz'].reshape(rows_all, T, -1)[sl][..., :1].contiguous())
     hf = core.get_harmonic_frequencies(ctl['f0_hz'], H) * (1.0 + ctl['harmonic_shifts'])
     ha = ctl['amplitudes'] * ctl['harmonic_distribution']
+    hf, ha = hf.contiguous(), ha.contiguous()
     fe = core.resample(hf, N)
     ae = core.resample(ha, N, method='window')
-    del hf, ha
     out = torch.empty((rows, N), dtype=torch.float32, device=device)
     ws, nbytes = core._osc_workspace(rows, N, H, device)
     lib = core._lib_()
@@ -467,6 +467,49 @@ def measure_roofline(dp, base, args, T, U, device):
         tp = float(np.min(event_times(read_both, 4, warmup=1))) * 1e-3
         probe[waves] = nb / tp / 1e9
     read_peak = max(probe.values())
+    # the reference's literal operator chain resample -> resample -> cos_oscillator_bank (inharm_synth.py:117-127) at this size:
+    # the two stand-alone upsamplers (pure write streams) rewriting fe / ae in place, against the pure write of the same buffer
+    lo_, hi_, w_, _ = core.linear_tables(T, N, device)
+    win_ = core.hann_window(2 * U, device)
+
+    def up_linear():
+        rc = lib.ddspp_resample_linear(core._ptr(hf), core._ptr(lo_), core._ptr(hi_), core._ptr(w_), core._ptr(fe), rows, T, H, N,
+                                       core._stream())
+        assert rc == 0, core._lib.last_error()
+
+    def up_window():
+        rc = lib.ddspp_resample_window(core._ptr(ha), core._ptr(win_), core._ptr(ae), rows, T, H, U, core._stream())
+        assert rc == 0, core._lib.last_error()
+    fe_check = fe[0, :256].clone()
+    t_lin = float(np.mean(event_times(up_linear, 3, warmup=1))) * 1e-3
+    t_win = float(np.mean(event_times(up_window, 3, warmup=1))) * 1e-3
+    assert torch.equal(fe_check, fe[0, :256])
+    wprobe = {}
+    scratch = torch.empty_like(fe)
+    for nt in (1, 0):
+        for waves in (2048, 4096):
+            nwr = ctypes.c_size_t(0)
+
+            def wr():
+                rc = lib.ddspp_hbm_write_probe(core._ptr(scratch), scratch.numel(), waves, nt, ctypes.byref(nwr), core._stream())
+                assert rc == 0, core._lib.last_error()
+            wr()
+            tw = float(np.min(event_times(wr, 3, warmup=1))) * 1e-3
+            wprobe[f"{'nt' if nt else 'plain'}_{waves}"] = nwr.value / tw / 1e9
+    del scratch
+    write_peak = max(wprobe.values())
+    up_bytes = rows * N * H * 4
+    chain = {'workload': f'resample(linear) + resample(window) + cos_oscillator_bank on {rows} rows x {N} samples x {H} harmonics '
+                         '(inharm_synth.py:117-127 as three operators, envelopes materialised in HBM)',
+             'ms': {'resample_linear': t_lin * 1e3, 'resample_window': t_win * 1e3, 'cos_oscillator_bank': t * 1e3,
+                    'total': (t_lin + t_win + t) * 1e3},
+             'upsampler_bytes_written_each': up_bytes,
+             'gb_per_s_written': {'resample_linear': up_bytes / t_lin / 1e9, 'resample_window': up_bytes / t_win / 1e9},
+             'write_ceiling': {'gb_per_s_by_policy_and_streams': wprobe, 'best': write_peak,
+                               'note': 'ddspp_hbm_write_probe: 16-byte stores, a contiguous stream per wavefront, on a buffer of '
+                                       'the same size; best of 3'},
+             'frac_of_measured_write': {'resample_linear': up_bytes / t_lin / 1e9 / write_peak,
+                                        'resample_window': up_bytes / t_win / 1e9 / write_peak}}
     traffic, stale = None, None
     tf = os.path.join(ROOT, 'profiles', 'osc_traffic.json')
     if os.path.exists(tf):
@@ -478,7 +521,7 @@ def measure_roofline(dp, base, args, T, U, device):
                 traffic = prof['hbm_bytes_per_launch'] * alg_bytes / prof['algorithmic_bytes_per_launch']
         except Exception:  # noqa: BLE001
             traffic = None
-    del fe, ae, out
+    del fe, ae, out, hf, ha
     torch.cuda.empty_cache()
     peaks = measure_device_peaks(device)
     peaks['library_read_probe'] = {'gb_per_s_by_streams': {str(k): v for k, v in probe.items()},
@@ -492,8 +535,9 @@ def measure_roofline(dp, base, args, T, U, device):
             'frac': alg_bytes / t / HBM_PEAK_BYTES, 'traffic': traffic, 'counters_stale': stale,
             'measured_peak': best, 'frac_of_measured_peak': alg_bytes / t / 1e9 / best, 'measured': peaks,
             'guide_achievable': 6290.0, 'frac_of_guide_achievable': alg_bytes / t / 1e9 / 6290.0,
-            'kernel': 'ddspp::osc_kernel<VPL, materialised, MODE_MAIN, sum> (ddspp_cos_oscillator_bank, spans=1: '
-                      'every envelope byte read once)',
+            'kernel': 'ddspp::osc_stream_kernel<H / 64> (ddspp_cos_oscillator_bank on materialised envelopes, angular cumsum, '
+                      'summed, spans=1: every envelope byte read once)',
+            'three_operator_chain': chain,
             'rows': rows, 'n_samples': N, 'n_harmonics': H, 'algorithmic_bytes_per_launch': alg_bytes,
             'ms_per_launch': t * 1e3, 'ms_min': float(np.min(times)) * 1e3}
 
