@@ -62,6 +62,34 @@ def test_spans_are_bitwise_equivalent():
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize('B,N,H,sr,spans', [
+    (3, 5000, 64, 16000, 1),          # one wavefront per row, a partial last tile (5000 = 156 x 32 + 8)
+    (2, 7000, 128, 24000, 1),         # the graded shape's two wavefronts per row
+    (2, 7000, 128, 24000, 3),         # ... started from the span offsets of the pre-pass
+    (1, 3008, 192, 32000, 2),
+    (1, 2016, 256, 48000, 1),         # four wavefronts per row
+    (2, 8, 64, 16000, 1),             # a single block: nothing but the ring's tail
+    (1, 1040, 128, 24000, 1),         # one chunk boundary, then 40 samples
+])
+def test_stream_kernel_writes_what_osc_kernel_writes(monkeypatch, B, N, H, sr, spans):
+    """osc_stream.hip (round 6: the HBM-bound shape's own kernel) against oscillator.hip's osc_kernel on the same envelopes:
+    same phases, same order of the harmonic sum -> the same audio bit for bit; frequencies at 0, above Nyquist and (one
+    column) negative so that the fast and the generic block forms both run."""
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(99 + N + H)
+    fe, ae = _envelopes(rng, B, N, H, sr)
+    fe[:, N // 3:N // 2, 5] = 0.0
+    fe[0, N // 2:, 7] = -40.0
+    fe[0, : N // 4, 9] = 1e-33
+    set_option(monkeypatch, 'DDSPP_OSC_STREAM', 1)
+    new = core.cos_oscillator_bank(_dev(fe), _dev(ae), sr, use_angular_cumsum=True, spans=spans)
+    set_option(monkeypatch, 'DDSPP_OSC_STREAM', 0)
+    old = core.cos_oscillator_bank(_dev(fe), _dev(ae), sr, use_angular_cumsum=True, spans=spans)
+    assert torch.equal(new, old)
+    ref = O.cos_oscillator_bank(fe, ae, sample_rate=sr, use_angular_cumsum=True)
+    assert rms_err(new.cpu().numpy(), ref) < TOL
+
+
 def test_unsummed_sinusoids():
     from ddsp_piano_amd import core
     rng = np.random.default_rng(11)

@@ -19,6 +19,8 @@ __device__ __forceinline__ void store_pol(float* p, float v) {
     if (POL == 7) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
 }
 
+// (A path around the vector L1 does not exist: s_store_dwordx4 + s_dcache_wb assemble for gfx950 but write nothing -- a
+// one-wavefront test printed the buffer's old contents -- and inside this pattern they fault.)
 // MODE: 0 = wavefront 0 stores 32 floats per 32 samples; 1 = the same address range again and again (4 KB per row);
 //       2 = 64 floats per 32 samples (twice the bytes, into a [R, 2N] buffer); 3 = no store; 4 = the stores of 8 tiles
 //       issued together (8 x 128 bytes every 256 samples)
