@@ -943,7 +943,7 @@ void launch_bank_stems(const OscParams& p, int vpl, float* stems, hipStream_t st
 void launch_bank_scan(const OscParams& p, int vpl, hipStream_t stream) {
     // persistent grid: as many one-wavefront workgroups as the chip holds a few times over; the task count lives on the device
     const size_t lds = (size_t)(64 + 256 * SCAN_WQ + 8) * sizeof(float);
-    const unsigned grid = (unsigned)ddspp_option("DDSPP_OSC_SCAN_WAVES", 8192);
+    const unsigned grid = (unsigned)ddspp_option_literal("DDSPP_OSC_SCAN_WAVES", 8192);
     if (vpl == 1) hipLaunchKernelGGL((bank_scan_kernel<1>), dim3(grid), dim3(64), lds, stream, p);
     else hipLaunchKernelGGL((bank_scan_kernel<2>), dim3(grid), dim3(64), lds, stream, p);
 }

@@ -629,12 +629,12 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     const size_t frames = (size_t)R * T;
     const int nj = (H + 15) / 16;
     const bool two_pass = nj <= 8 || (nj == 12 && norm_after && normalize_below_nyquist && H % 16 == 0 &&
-                                      !ddspp_option("DDSPP_CONTROLS_GENERIC", 0));          // (the lean kernel: always two)
+                                      !ddspp_option_literal("DDSPP_CONTROLS_GENERIC", 0));          // (the lean kernel: always two)
     const size_t per_wg = (size_t)4 * 4 * (two_pass ? 2 : 1);           // four wavefronts of 4 * CTL_PASS frames
     const dim3 grid((unsigned)((frames + per_wg - 1) / per_wg)), block(256);
     // every shipped model: 48 / 64 / 96 / 128 / 192 harmonics (8, 16, 16 / 24, 24 / 48, 32 kHz) with the default flags
     const bool lean = norm_after && normalize_below_nyquist && H % 16 == 0 &&
-                      (nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12) && !ddspp_option("DDSPP_CONTROLS_GENERIC", 0);
+                      (nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12) && !ddspp_option_literal("DDSPP_CONTROLS_GENERIC", 0);
 #define DDSPP_LEAN(NJ)                                                                                              \
     do {                                                                                                            \
         if (scale_kind == SCALE_EXP_SIGMOID)                                                                        \

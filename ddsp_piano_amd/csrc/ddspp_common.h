@@ -35,6 +35,8 @@ static inline int ddspp_auto_delay(int delay_compensation, int ir_size) {
 extern "C" void ddspp_set_error(const char* fmt, ...);
 // tuning option `name` (a DDSPP_* environment variable, read once and cached; ddspp_set_option / ddspp_reload_options)
 extern "C" int ddspp_option(const char* name, int dflt);
+// the library's own call sites: `name` must be a string LITERAL (its address is the cache key) -- no lock, no allocation
+extern "C" __attribute__((visibility("hidden"))) int ddspp_option_literal(const char* name, int dflt);
 
 #define DDSPP_REQUIRE(cond, ...)                 \
     do {                                         \

@@ -99,7 +99,7 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
     g->vpr = 1;
     // (voices are summed in the kernel only when the rows alone give it workgroups enough -- a window is 30 frames, the chip
     // holds 768 workgroups: a single 3 s segment is 50 units of eight voices or 400 of one)
-    const int forced = ddspp_option("DDSPP_VOICE_SUMS", 0);                // (tests: voice sums at small sizes)
+    const int forced = ddspp_option_literal("DDSPP_VOICE_SUMS", 0);                // (tests: voice sums at small sizes)
     if (g->fused_noise)
         for (int v : {8, 4, 2})
             if (P % v == 0 && (forced > 0 ? v <= forced : (long long)B * (P / v) * ((T + 29) / 30) >= 768)) {
@@ -131,9 +131,9 @@ int ddspp_group_create(const ddspp_group_config* cfg, ddspp_group** out) {
     if (rc == DDSPP_OK && c.ir_length > 0)
         rc = ddspp_fftconv_plan_create(B, c.ir_batch ? c.ir_batch : B, N, c.ir_length, &g->plan);
     // a side stream for the noise branch is opt-in (DDSPP_SIDE_STREAM=1): both branches want the same VALU issue slots
-    if (rc == DDSPP_OK && ddspp_option("DDSPP_SIDE_STREAM", 0) &&
-        (long long)R * N >= (long long)ddspp_option("DDSPP_SIDE_STREAM_MIN", 1 << 24) &&
-        !ddspp_option("DDSPP_NO_SIDE_STREAM", 0)) {
+    if (rc == DDSPP_OK && ddspp_option_literal("DDSPP_SIDE_STREAM", 0) &&
+        (long long)R * N >= (long long)ddspp_option_literal("DDSPP_SIDE_STREAM_MIN", 1 << 24) &&
+        !ddspp_option_literal("DDSPP_NO_SIDE_STREAM", 0)) {
         hipError_t e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);

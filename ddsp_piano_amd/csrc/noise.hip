@@ -750,7 +750,7 @@ static unsigned stream_grid(size_t total) {
     return (unsigned)blocks;
 }
 
-static int env_int(const char* name, int dflt) { return ddspp_option(name, dflt); }
+static int env_int(const char* name, int dflt) { return ddspp_option_literal(name, dflt); }
 
 }  // namespace ddspp
 

@@ -28,6 +28,15 @@
 
 #include "noise_win.h"
 
+// DDSPP_WIN_DEBUG's timing ablations (bits 0 .. 7: no walk, no design, priorities, a shorter walk -- deliberately WRONG audio)
+// exist only in -DDDSPP_ABLATIONS builds (tools/build_variant.py); in the shipped library the kernels see a constant 0
+// there and the compiler removes the branches.  Bits 8 .. (the stride of the TRACE instrumentation) are not an ablation.
+#ifdef DDSPP_ABLATIONS
+#define DDSPP_WIN_ABLATION_BITS(d) (d)
+#else
+#define DDSPP_WIN_ABLATION_BITS(d) ((d) & ~0xff)
+#endif
+
 namespace ddspp {
 
 constexpr int WIN_D = 32;            // designed frames per window = two MFMA row tiles
@@ -341,7 +350,8 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
                        float* __restrict__ out,              // [R / vq, N]
                        float* __restrict__ out_last,         // [R / n_voices, N] or null
                        int R, int N, int T, int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices,
-                       int vmajor, int tpw, int dbg, long long* __restrict__ trace) {
+                       int vmajor, int tpw, int dbg_arg, long long* __restrict__ trace) {
+    const int dbg = DDSPP_WIN_ABLATION_BITS(dbg_arg);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int K = 2 * KH, KS = KH / 4, D = WIN_D, U = 4 * BPF, NP = U / OPL, NPASS = (NP + 7) / 8;
     constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
@@ -670,8 +680,9 @@ __device__ __forceinline__ void
 noise_win_ride_body(const float* __restrict__ x, const float* __restrict__ mags, const float* __restrict__ CE,
                     const float* __restrict__ CO, const int* __restrict__ tap_idx, const float* __restrict__ tap_we,
                     const float* __restrict__ tap_wo, float* __restrict__ out, float* __restrict__ out_last, int R, int N, int T,
-                    int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices, int vmajor, int tpw, int dbg,
+                    int NJ, WinGeom g, float bias, ScaleFn scale, int vq, int n_voices, int vmajor, int tpw, int dbg_arg,
                     long long* __restrict__ trace) {
+    const int dbg = DDSPP_WIN_ABLATION_BITS(dbg_arg);
     constexpr int K = 2 * KH, KS = KH / 4, D = WIN_D, U = 4 * BPF;
     constexpr int XQ = (BPF * D + 255) / 256, PER_ROW = K / 4, MQ = (D * PER_ROW + 255) / 256;
     static_assert(JT == 3 && D == 32, "wavefronts 0 .. 2 design both row tiles of their column block, wavefront 3 none");
@@ -1020,14 +1031,18 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
                      hipStream_t stream) {
     const long long tasks = (long long)(R / vq) * g.wpr;
     DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
-    const size_t lds = win_lds_bytes(g, K) + (size_t)ddspp_option("DDSPP_WIN_LDS_PAD", 0);     // pad: fewer workgroups per CU (A/B)
+    const size_t lds = win_lds_bytes(g, K) + (size_t)ddspp_option_literal("DDSPP_WIN_LDS_PAD", 0);     // pad: fewer workgroups per CU (A/B)
     // About eight (window, voice) units per workgroup: the set-up (zeroed images, table fragments) is paid once per
     // eight, and there are several times more workgroups than the chip holds at once, so the last round of a launch
     // is spread over all CUs by the dispatcher instead of leaving a fixed assignment's stragglers.
-    int tpw = ddspp_option("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
+    int tpw = ddspp_option_literal("DDSPP_WIN_UNITS_PER_WG", 8) / vq;
     if (tpw < 1) tpw = 1;
     while (tpw > 1 && tasks / tpw < 768) tpw >>= 1;          // few tasks (a single segment): one unit per workgroup
-    const int dbg = ddspp_option("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk, 16 = untrimmed walk
+#ifdef DDSPP_ABLATIONS
+    const int dbg = ddspp_option_literal("DDSPP_WIN_DEBUG", 0);     // timing ablations: 1 = no walk, 2 = no design, 8 = shorter walk, 16 = untrimmed walk
+#else
+    const int dbg = ddspp_option_literal("DDSPP_WIN_DEBUG", 0) & ~0xff;    // the shipped library: only the trace stride (bits 8 ..) is read
+#endif
     if (dbg & (1 | 2 | 8)) {                                // (these three leave work out: the audio is WRONG by design)
         static bool warned = false;
         if (!warned) {
@@ -1055,12 +1070,12 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     // image but the window's first, i.e. at least one frame of look-back
     // the matrix-pipe walk: its schedule is compiled for one (delay, taps, look-back, look-ahead); a misaligned delay makes
     // it read taps below index 0, which are zeros of a gap in any image but the window's first (RL >= 1)
-    const bool mw = ddspp_option("DDSPP_WIN_MFMA", 0) && g.padl >= 8;      // opt-in: same time as the vector walk
+    const bool mw = ddspp_option_literal("DDSPP_WIN_MFMA", 0) && g.padl >= 8;      // opt-in: same time as the vector walk
 #define DDSPP_WIN_LAUNCH_MW(KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH)                                                        \
     hipLaunchKernelGGL((noise_win_fused_mw_kernel<KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH>), grid, block, lds, stream, audio, \
                        magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices,   \
                        voice_major, tpw, dbg)
-    if (K == 96 && U == 96 && mw && ddspp_option("DDSPP_WIN_MFMA", 0) == 2 && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
+    if (K == 96 && U == 96 && mw && ddspp_option_literal("DDSPP_WIN_MFMA", 0) == 2 && g.delay == 93 && g.Lw == 190 && g.RL == 1 && g.RH == 1)
         hipLaunchKernelGGL((noise_win_fused_ride_kernel<48, 3, 24, 13, 93, 190, 1, 1>), grid, block, lds, stream, audio, magnitudes,
                            CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices, voice_major, tpw,
                            dbg);

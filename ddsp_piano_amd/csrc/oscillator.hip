@@ -1291,7 +1291,7 @@ static bool sample_rate_is_checked(float sr) {
     return false;
 }
 
-static int env_int(const char* name, int dflt) { return ddspp_option(name, dflt); }
+static int env_int(const char* name, int dflt) { return ddspp_option_literal(name, dflt); }
 
 static int pick_vpl(int V) {
     const int need = (V + 63) / 64;

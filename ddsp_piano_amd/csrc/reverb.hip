@@ -127,8 +127,8 @@ int ddspp_fft_size(int N, int L) {
 // DDSPP_FFT_POW2=1 keeps the reference's size, DDSPP_FFT_SIZE=n forces a length (tuning).
 static int fast_fft_size(int N, int L) {
     const long long need = (long long)N + L - 1;
-    if (ddspp_option("DDSPP_FFT_POW2", 0) == 1) return ddspp_fft_size(N, L);
-    const int forced = ddspp_option("DDSPP_FFT_SIZE", 0);
+    if (ddspp_option_literal("DDSPP_FFT_POW2", 0) == 1) return ddspp_fft_size(N, L);
+    const int forced = ddspp_option_literal("DDSPP_FFT_SIZE", 0);
     if (forced >= need && forced % 8 == 0) return forced;
     long long best = -1;
     double best_cost = 0.0;
@@ -159,7 +159,7 @@ int ddspp_fftconv_plan_create(int B, int B_ir, int N, int L, ddspp_fftconv_plan*
     pl->B = B; pl->B_ir = B_ir; pl->N = N; pl->L = L; pl->nfft = nfft;
     // Route: partitioned overlap-save with LDS-resident 8192-point transforms when the convolution spans at least a few
     // blocks (DDSPP_FFT_PARTITIONED=0: always the whole-signal rocFFT route; =2: always partitioned).
-    const int part_opt = ddspp_option("DDSPP_FFT_PARTITIONED", 1);
+    const int part_opt = ddspp_option_literal("DDSPP_FFT_PARTITIONED", 1);
     if (part_opt == 2 || (part_opt == 1 && (long long)N + L >= 6 * REVERB_PART_BLOCK)) {
         pl->part = true;
         pl->pp.Pn = (L + REVERB_PART_BLOCK - 1) / REVERB_PART_BLOCK;
