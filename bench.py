@@ -174,6 +174,94 @@ def make_features(B, P, T, H, K, S, L, device, seed, silent_frac=0.25, midi_lo=2
     return feats, base
 
 
+def synthetic_piano_roll(rng, T, frame_rate=250, notes_per_s=9.0):
+    """A piano roll [T, 88, 2] (active, onset velocity in (0, 1]) like note_seq's sequence_to_pianoroll hands
+    io_utils.load_midi_as_conditioning (io_utils.py:106-113): notes held over from before the segment, a Poisson stream of
+    onsets (single notes and chords of 2-4), durations 80 ms .. 2.5 s (sustained passages overlap: polyphony 1 .. 12),
+    pitches around the middle of the keyboard with occasional bass / treble notes."""
+    roll = np.zeros((T, 88, 2), np.float32)
+
+    def note(t0, dur, pitch, vel, onset=True):
+        t1 = min(T, t0 + max(int(dur * frame_rate), 2))
+        k = int(np.clip(pitch, 21, 108)) - 21
+        if roll[t0:t1, k, 0].any():
+            return
+        roll[t0:t1, k, 0] = 1.0
+        if onset:
+            roll[t0, k, 1] = vel
+    for _ in range(rng.poisson(2.5)):                        # already sounding at the start (their onsets lie before it)
+        note(0, rng.uniform(0.2, 1.5), rng.normal(58, 14), 0.0, onset=False)
+    t = 0.0
+    while True:
+        t += rng.exponential(1.0 / notes_per_s)
+        t0 = int(t * frame_rate)
+        if t0 >= T - 2:
+            break
+        n = 1 if rng.random() > 0.3 else int(rng.integers(2, 5))
+        root = rng.normal(60, 13) if rng.random() > 0.15 else rng.choice([rng.uniform(21, 40), rng.uniform(88, 108)])
+        for j in range(n):
+            note(t0, float(np.clip(rng.lognormal(-0.9, 0.8), 0.08, 2.5)), root + (0 if j == 0 else rng.choice([3, 4, 7, 12, -12, 16])),
+                 float(np.clip(rng.normal(0.55, 0.18), 0.08, 1.0)))
+    return roll
+
+
+def make_midi_like_features(dp, B, P, T, H, K, S, L, device, seed):
+    """Controls shaped like a performance instead of 12 held notes per segment: a synthetic piano roll per
+    segment through MIDIRoll2Conditioning (midi_encoders.py:33-104, the package's C++ allocator), then what the control
+    networks do with its two columns -- f0 = midi_to_hz(pitch) (sub_modules.py:942: pitch 0, a free voice, is 8.18 Hz and
+    gated by min_frequency), inharmonicity from the v2 tuning curve of the pitch, amplitudes re-triggered at every onset (level from
+    the velocity, the bench's exponential decay counted from the onset), the rest as make_features draws it.
+    Returns (features, base, stats)."""
+    rng = np.random.default_rng(seed)
+    pitch = np.zeros((B, P, T), np.float32)
+    since = np.zeros((B, P, T), np.float32)
+    level = np.zeros((B, P, T), np.float32)
+    poly = []
+    for b in range(B):
+        enc = dp.MIDIRoll2Conditioning(P)
+        cond, polyphony = enc(synthetic_piano_roll(rng, T))
+        poly.append(np.asarray(polyphony))
+        pit, vel = cond[:, :, 0].T, cond[:, :, 1].T                     # [P, T]
+        pitch[b] = pit
+        # frames since the voice's last onset (or since the segment started, for a note held over) and that onset's velocity
+        started = (vel > 0) | (np.diff(pit, axis=1, prepend=0.0) != 0)
+        idx = np.where(started, np.arange(T)[None, :], 0)
+        last = np.maximum.accumulate(idx, axis=1)
+        since[b] = np.arange(T)[None, :] - last
+        v_on = np.take_along_axis(np.where(vel > 0, vel, 0.5), last, axis=1)
+        level[b] = v_on
+    poly = np.stack(poly)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+    midi = torch.as_tensor(pitch, device=device).view(B, P, T, 1)
+    active = midi > 0
+    f0 = 440.0 * torch.pow(2.0, (midi - 69.0) / 12.0)                   # midi_to_hz; pitch 0 -> 8.1758 Hz
+    detune = torch.pow(2.0, 0.3 * torch.arange(S, device=device, dtype=torch.float32) / 1200.0)
+    f0 = (f0 * detune.view(1, 1, 1, S)).contiguous()
+    inharm = (torch.exp(-0.105 * midi - 6.87) + torch.exp(0.094 * midi - 13.70)).contiguous()
+    age = torch.as_tensor(since, device=device).view(B, P, T, 1)
+    lvl = torch.as_tensor(level, device=device).view(B, P, T, 1)
+    amps = (-1.0 + 3.0 * (lvl - 0.55)) + 3.0 * (torch.exp(-age / (0.4 * 750.0)) - 1.0)
+    amps = torch.where(active, amps, torch.full_like(amps, -10.0)).contiguous()
+    hd = randn(B, P, T, H) - 0.05 * torch.arange(1, H + 1, device=device, dtype=torch.float32).view(1, 1, 1, H)
+    hd = torch.nn.functional.avg_pool2d(hd.view(B * P, 1, T, H), (5, 1), stride=1, padding=(2, 0),
+                                        count_include_pad=False).view(B, P, T, H).contiguous()
+    mags = randn(B, P, T, K)
+    n = torch.arange(L, device=device, dtype=torch.float32)
+    ir = randn(B, L) * torch.exp(-6.9 * n / L).view(1, L) * 0.02
+    ir[:, 1] = 3.0
+    base = dict(amplitudes=amps, harmonic_distribution=hd, inharm_coef=inharm, f0_hz=f0, magnitudes=mags)
+    feats = {f'{k}_{i}': v[:, i] for k, v in base.items() for i in range(P)}
+    feats['reverb_ir'] = ir.contiguous()
+    onsets = int((np.diff((pitch > 0).astype(np.int8), axis=2, prepend=0) > 0).sum())
+    stats = {'audible_voice_frames': float((pitch > 0).mean()), 'polyphony_mean': float(poly.mean()), 'polyphony_max': float(poly.max()),
+             'voice_onsets_per_segment': onsets / B, 'voices_used_per_segment': float(((pitch > 0).any(axis=2)).sum(axis=1).mean())}
+    return feats, base, stats
+
+
 def build_group(dp, P, sr, frame_rate=250):
     additive = dp.MultiInharmonic(name='additive', frame_rate=frame_rate, sample_rate=sr, inference=True)
     noise = dp.DynamicSizeFilteredNoise(name='noise', frame_rate=frame_rate, sample_rate=sr)
@@ -1023,6 +1111,15 @@ def main():
                                           'every frame (0.2 % vibrato + glide)',
                               'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
         del fm, pgm
+        # note-shaped controls: a synthetic performance through MIDIRoll2Conditioning (onsets and releases inside the
+        # segment, free voices at pitch 0 = 8.18 Hz gated by min_frequency, polyphony as it comes)
+        fn_, _, st_ = make_midi_like_features(dp, B, P, T, H, K, S, L, device, seed=33)
+        pgn = build_group(dp, P, sr)
+        ts = event_times(lambda: call(pgn, fn_), 10, warmup=3)
+        extra['midi_like'] = {'workload': f'batch={B} x {args.seconds:g} s, controls from a synthetic piano roll per segment through '
+                                          'MIDIRoll2Conditioning (f0 = midi_to_hz(pitch), amplitudes re-triggered at onsets)',
+                              'inputs': st_, 'ms_per_step': ms_summary(ts), 'rtf': B * N / (float(np.median(ts)) * 1e-3) / sr}
+        del fn_, pgn
         f1, _ = make_features(1, P, T, H, K, S, L, device, seed=7)
         pg1 = build_group(dp, P, sr)
         d1 = min(time_steps(lambda: call(pg1, f1), 20, 3) for _ in range(3))          # best of three runs of 20

@@ -37,7 +37,7 @@ F32 = np.float32
 TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2.0 * pi`
 
 # ----------------------------------------------------------------------------------------------
-# The seven details of ddsp 3.7.0 that are RECALLED, not read (SURVEY.md 8(c) "VERIFY" list).  Each is ONE
+# The eight details of ddsp 3.7.0 that are RECALLED, not read (SURVEY.md 8(c) "VERIFY" list).  Each is ONE
 # switchable entry here; every function below reads it at call time.  The defaults are the builder's
 # recollection of ddsp 3.7.0; the alternatives are what a different recollection would give.  A host with
 # TensorFlow + ddsp settles them: tests/golden/make_golden.py (DDSP_GOLDEN_BACKEND=tf) regenerates the
@@ -57,6 +57,11 @@ TWO_PI_F32 = F32(2.0 * np.pi)          # float32(6.2831855), what TF makes of `2
 #                     'wrapped'  offsets = tf.cumsum(offsets, axis=1) % (2 pi)   
 #                     'plain'    offsets = tf.cumsum(offsets, axis=1)            (the sum grows by up to 2 pi per chunk;
 #                                `phase + offsets` is then rounded at the magnitude of the sum: ulp(2 pi n_chunks))
+#   angular_wrap    core.angular_cumsum's LAST step (round 6):
+#                     'final'  phase = (phase + offsets) % (2 pi): the function returns phases in [0, 2 pi)
+#                     'none'   phase + offsets is returned as it is (up to ~2 pi x 500 inside a chunk for a partial near
+#                              Nyquist) and tf.cos reduces it by the TRUE 2 pi: float32(2 pi) - 2 pi = 1.75e-7 per turn,
+#                              <= 9e-5 rad on the argument of the highest partials' cosine, nothing on the phase state
 #   exp_sigmoid     defaults (exponent, max_value, threshold) of core.exp_sigmoid
 #   initial_bias    default of synths.FilteredNoise(initial_bias=)
 # ----------------------------------------------------------------------------------------------
@@ -66,6 +71,7 @@ RECALLED_DEFAULTS = {
     'resize': 'legacy',
     'angular_cumsum': 'ddsp370',
     'angular_offsets': 'wrapped',
+    'angular_wrap': 'final',
     'exp_sigmoid': (10.0, 2.0, 1e-7),
     'initial_bias': -5.0,
 }
@@ -75,6 +81,7 @@ RECALLED_CHOICES = {
     'resize': ('legacy', 'half_pixel'),
     'angular_cumsum': ('ddsp370', 'exclusive'),
     'angular_offsets': ('wrapped', 'plain'),
+    'angular_wrap': ('final', 'none'),
 }
 RECALLED = dict(RECALLED_DEFAULTS)
 
@@ -314,7 +321,8 @@ def angular_cumsum(angular_frequency, chunk_size=1000):
     if RECALLED['angular_offsets'] == 'wrapped':
         offsets = np.mod(offsets, TWO_PI_F32).astype(F32)
     phase = (phase + offsets).astype(F32)
-    phase = np.mod(phase, TWO_PI_F32).astype(F32)
+    if RECALLED['angular_wrap'] == 'final':
+        phase = np.mod(phase, TWO_PI_F32).astype(F32)
     phase = phase.reshape((n_batch, length_p) + rest)
     return phase[:, :length]
 

@@ -152,6 +152,14 @@ def report_recalled(cases):
             d = np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - want.astype(np.float64)))))
             rows.append((f'angular_offsets (scan={scan})', offs, float(np.sqrt(np.mean(d ** 2))),
                          f'{int((got != want).sum())} of {got.size} phases differ bitwise, max {d.max():.2e} rad'))
+    # ... and whether angular_cumsum wraps what it returns (round 6): the stored phases ARE the function's output, so a TF
+    # golden in [0, 2 pi) settles 'final', one that grows to thousands of radians settles 'none' -- no tolerance involved
+    for wrap in O.RECALLED_CHOICES['angular_wrap']:
+        with O.recalled(angular_wrap=wrap):
+            ph = O.angular_cumsum(cases['omega_long'])
+        got = np.concatenate([ph[:, ::41].ravel(), ph[:, -1000:].ravel()])
+        want = np.concatenate([cases['phase_long_strided'].ravel(), cases['phase_long_tail'].ravel()])
+        rows.append(('angular_wrap', wrap, err(got, want), f'golden phases span [{want.min():.3g}, {want.max():.6g}] rad'))
     for key, fn in (('rs_linear_96', lambda: O.resample(cases['rs_in'], 37 * 96)),
                     ('rs_linear_nonint', lambda: O.resample(cases['rs_in'], 1000)),
                     ('rs_window_96', lambda: O.resample(cases['rs_in'], 37 * 96, method='window'))):

@@ -93,7 +93,7 @@ def test_oracle_reproduces_small_config2():
     assert rms_err(out['signal'], g['audio']) < _tol() * max(1.0, rms(g['audio']))
 
 
-@pytest.mark.parametrize('detail', ['auto_delay', 'window_crop', 'resize', 'angular_cumsum', 'angular_offsets',
+@pytest.mark.parametrize('detail', ['auto_delay', 'window_crop', 'resize', 'angular_cumsum', 'angular_offsets', 'angular_wrap',
                                     'upsamplers_bitwise', 'exp_sigmoid',
                                     'initial_bias', 'framed_fft_convolve', 'reverb_dry_mask', 'window_end_points',
                                     'exp_tanh', 'multi_add_order'])
@@ -131,6 +131,23 @@ def test_recalled_details_match(detail):
         assert np.sqrt(np.mean(d ** 2)) < 0.2 * np.sqrt(np.mean(d_other ** 2)), \
             "the golden phases are closer to angular_offsets='plain' than to the default 'wrapped'"
         assert np.sqrt(np.mean(d ** 2)) < 1e-5
+        return
+    elif detail == 'angular_wrap':
+        # the eighth switch (round 6): does angular_cumsum wrap what it returns?  The golden holds the function's OUTPUT for 301
+        # chunks of a partial near Nyquist: wrapped it lies in [0, 2 pi), unwrapped it reaches ~3000 rad -- the two settings are
+        # 1e3 rad apart, whatever the backend's rounding
+        want = np.concatenate([g['phase_long_strided'].ravel(), g['phase_long_tail'].ravel()])
+        wrapped = bool(want.max() < 6.2831855)
+        with O.recalled(angular_wrap='final' if wrapped else 'none'):
+            ph = O.angular_cumsum(g['omega_long'])
+        got = np.concatenate([ph[:, ::41].ravel(), ph[:, -1000:].ravel()])
+        assert rms_err(got, want) < 1e-3
+        assert wrapped == (O.RECALLED_DEFAULTS['angular_wrap'] == 'final'), \
+            "the golden phases say angular_cumsum's final `% 2 pi` is " + ('present' if wrapped else 'absent') + \
+            ": oracle.RECALLED_DEFAULTS['angular_wrap'] is the wrong recollection"
+        with O.recalled(angular_wrap='none'):
+            unwrapped = O.angular_cumsum(g['omega_long'])
+        assert unwrapped.max() > 1000.0 and np.abs(np.mod(unwrapped[:, :1000], O.TWO_PI_F32) - ph[:, :1000]).max() < 1e-3 or not wrapped
         return
     elif detail == 'upsamplers_bitwise':
         for key, val in (('rs_linear_96', O.resample(g['rs_in'], 37 * 96)), ('rs_linear_nonint', O.resample(g['rs_in'], 1000)),

@@ -103,6 +103,41 @@ def test_config3_batch64_headline_routes():
     _check_against_oracle({'signal': audio}, feats, noise, segments[:2], P, sr, 'C3 audio only')
 
 
+def test_config3_note_shaped_controls():
+    """bench.py's `midi_like` inputs (round 6): a synthetic performance per segment through MIDIRoll2Conditioning -- onsets and
+    releases inside the segment, free voices at pitch 0 (8.18 Hz: gated by min_frequency), amplitudes re-triggered at onsets --
+    at config 3's size: every row against the every-stem route, FOUR segments against the oracle (the busiest, the
+    emptiest, two at random)."""
+    bench = _bench()
+    import ddsp_piano_amd as dp
+    B, P, T, H, K, S, sr, L = 64, 16, 750, 128, 96, 1, 24000, 72000
+    N = T * 96
+    dev = torch.device('cuda', 0)
+    feats, base, stats = bench.make_midi_like_features(dp, B, P, T, H, K, S, L, dev, seed=33)
+    assert 0.1 < stats['audible_voice_frames'] < 0.6 and stats['polyphony_max'] >= 8 and stats['voice_onsets_per_segment'] > 10, stats
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    noise = torch.rand(B, P, N, generator=g, device=dev) * 2.0 - 1.0
+    pg = bench.build_group(dp, P, sr)
+    audio = pg(feats, noise=noise)
+    full = pg(feats, return_outputs_dict=True, noise=noise)
+    stems = pg(feats, return_outputs_dict=True, need_stems=True, noise=noise)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(stems['signal'].abs().max()))
+    assert torch.isfinite(audio).all()
+    assert (audio - stems['signal']).abs().max().item() < 2e-5 * scale
+    assert (full['signal'] - stems['signal']).abs().max().item() < 2e-5 * scale
+    busy = (base['f0_hz'][..., 0] > 20.0).float().mean(dim=(1, 2)).cpu().numpy()          # audible voice-frames per segment
+    picks = {int(np.argmax(busy)), int(np.argmin(busy))}
+    for b in np.random.default_rng(5).permutation(B):
+        if len(picks) >= 4:
+            break
+        picks.add(int(b))
+    segments = sorted(picks)
+    _check_against_oracle(full, feats, noise, segments, P, sr, 'C3 note-shaped controls, outputs dict')
+    _check_against_oracle({'signal': audio}, feats, noise, segments[:1], P, sr, 'C3 note-shaped controls, audio only')
+
+
 @pytest.mark.parametrize('H,K', [(96, 64), (128, 96)])
 def test_config2_one_3s_poly16_segment(H, K):
     bench = _bench()

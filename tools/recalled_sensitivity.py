@@ -43,6 +43,7 @@ SWITCHES = [
     ('resize', 'half_pixel', ('additive',), "recalled_details.npz: ramp_linear, rs_linear_96, rs_linear_nonint (bitwise)"),
     ('angular_cumsum', 'exclusive', ('additive',), "recalled_details.npz: phase, phase_long_* (bitwise)"),
     ('angular_offsets', 'plain', ('additive',), "recalled_details.npz: phase_long_strided / phase_long_tail (bitwise, 301 chunks)"),
+    ('angular_wrap', 'none', ('additive',), "recalled_details.npz: phase, phase_long_* (the function's output lies in [0, 2 pi) or grows to ~3000 rad: no tolerance needed)"),
     ('exp_sigmoid', (10.0, 2.0, 0.0), ('additive', 'noise'), "recalled_details.npz: exp_sigmoid (threshold 1e-7 -> 0 shown here)"),
     ('initial_bias', -4.0, ('noise',), "recalled_details.npz: noise_controls (-5 -> -4 shown here)"),
 ]
