@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(256) bank_stems_sum_kernel(const float* __rest
 // a wavefront -- instead of one wavefront per (row, 64 harmonics), which at a piano's note mix has 1.7 lanes per audible
 // partial.  A persistent grid walks (slot, segment, chunk); which chunks are flagged is only known on the device: none --
 // held notes -- and the wavefronts leave at once.  Same arithmetic, same order, same bits as the pre-pass's own moving branch
-// (scan_block_staged); rows that are constant in a listed chunk are written by both kernels with the same values.
+// (scan_block_staged); a (row, chunk) that is constant is the pre-pass's and left out of the packed list here.
 #ifndef SCAN_WPE
 #define SCAN_WPE 4      // wavefronts per SIMD of bank_scan_kernel (an even count: a SIMD issues for two wavefronts at a time)
 #endif
@@ -772,8 +772,12 @@ bank_scan_kernel(const OscParams p) {
         if (lane < Q) {
             const int v = lane / S;
             const int vrow = p.vmajor ? v * p.R + seg : seg * p.P + v;
-            len = p.rowmax[vrow];
             mv = p.scan_tasks[(size_t)vrow * p.npre + c];
+            // only the voices that MOVE in this chunk are packed (round 6): the pre-pass memoises every (row, chunk) that is
+            // constant, whatever the segment's other voices do.  Before, one moving voice had the whole segment's audible
+            // oscillators scanned: with note onsets and releases in every chunk of a performance (bench.py midi_like: 80 changes
+            // per 3 s segment over 72 chunks) that was every chunk of every voice -- 0.71 ms, more than the bank itself.
+            len = mv ? p.rowmax[vrow] : 0;
         }
         if (!__any(mv != 0)) continue;                       // no frequency of this segment moves in this chunk: the pre-pass has it
         int incl = len;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one bench input case a few times (for rocprofv3 --kernel-trace --stats).
-usage: python tools/trace_case.py [headline|moving|dense|c5|dafx22|dafx24|multi|surrogate|enst8k|enst32k|file|one] [audio|dict|stems] [reps]"""
+usage: python tools/trace_case.py [headline|midi|moving|dense|c5|dafx22|dafx24|multi|surrogate|enst8k|enst32k|file|one] [audio|dict|stems] [reps]"""
 import os
 import sys
 
@@ -34,9 +34,13 @@ elif case == 'enst8k':      # configs/ENSTDkCl-8kHz.gin dims (here with ddsp.eff
     B, P, H, K, S, sr, L = 64, 16, 48, 32, 1, 8000, 16000
 elif case in ('enst32k', 'enst32kmoving'):     # configs/ENSTDkCl-32kHz.gin dims
     B, P, H, K, S, sr, L = 64, 16, 192, 128, 1, 32000, 64000
-kw = {'headline': {}, 'moving': dict(vibrato=0.002), 'dafx24moving': dict(vibrato=0.002), 'multimoving': dict(vibrato=0.002), 'enst32kmoving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'surrogate': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
+kw = {'headline': {}, 'midi': {}, 'moving': dict(vibrato=0.002), 'dafx24moving': dict(vibrato=0.002), 'multimoving': dict(vibrato=0.002), 'enst32kmoving': dict(vibrato=0.002), 'c5': {}, 'dafx22': {}, 'dafx24': {}, 'multi': {}, 'surrogate': {}, 'enst8k': {}, 'enst32k': {}, 'file': {}, 'one': {},
       'dense': dict(silent_frac=0.0, midi_lo=21, midi_hi=33, vibrato=0.004)}[case]
-feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
+if case == 'midi':          # bench.py midi_like: note-shaped controls from a synthetic piano roll
+    feats, _, _st = bench.make_midi_like_features(dp, B, P, T, H, K, S, L, dev, seed=33)
+    print('midi_like inputs:', _st)
+else:
+    feats, _ = bench.make_features(B, P, T, H, K, S, L, dev, seed=31, **kw)
 pg = bench.build_group(dp, P, sr)
 if case == 'surrogate':
     g = torch.Generator(device=dev)
