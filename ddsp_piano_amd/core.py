@@ -62,9 +62,11 @@ def set_recalled(**rules):
         if v not in _RECALLED_CHOICES[k]:
             raise ValueError(f'{k} must be one of {_RECALLED_CHOICES[k]}, got {v!r}')
     previous = dict(RECALLED)
-    RECALLED.update(rules)
-    if 'angular_offsets' in rules:
+    # the library's switch first, and only when it changes (a restore of `previous` on a host-only path must not load
+    # libddspp): RECALLED says 'plain' only once the kernels do
+    if 'angular_offsets' in rules and rules['angular_offsets'] != RECALLED['angular_offsets']:
         _lib.set_option('DDSPP_ANGULAR_OFFSETS_PLAIN', 1 if rules['angular_offsets'] == 'plain' else 0, persistent=True)
+    RECALLED.update(rules)
     return previous
 
 
@@ -285,7 +287,7 @@ def _walk_weights_np(n_frames, n_timesteps, rule='legacy', first_sample=0, n=Non
     return w, True
 
 
-@functools.lru_cache(maxsize=8)
+@functools.lru_cache(maxsize=2)        # (whole-signal float32 arrays: 115 MB for a 20-minute file; the device copy lives in _table_cache)
 def _walk_full_np(n_frames, n_timesteps, rule):
     """(w, walkable) of a whole signal, computed ONCE per shape: fused_synthesis_supported() and walk_weights() both ask
     (a 20-minute file is 28.8 M samples -- seconds of host work and ~1 GB of temporaries per evaluation)."""
@@ -300,6 +302,15 @@ def _walkable_np(n_frames, n_timesteps, rule):
         if n_frames < linear_exact_frames(n_timesteps // n_frames):
             return True
     return _walk_full_np(n_frames, n_timesteps, rule)[1]
+
+
+@functools.lru_cache(maxsize=8)
+def _walkable_piece_np(n_frames, n_timesteps, rule, first_sample, n):
+    """walkable flag of samples first_sample .. + n (host arithmetic, a few thousand samples for a streamed piece).  Cached:
+    StreamingSynthesizer.push asks core.walkable() and the kernels' wrappers ask again through walk_weights() with the same
+    arguments -- the second question costs nothing, and neither touches the device (a device-side check needed a
+    synchronising .item() per piece, which is also illegal inside a stream capture: ADVICE r05)."""
+    return bool(_walk_weights_np(n_frames, n_timesteps, rule, first_sample, n)[1])
 
 
 _table_cache = {}
@@ -349,7 +360,8 @@ def walkable(n_frames, n_timesteps, sample_offset=0, n=None):
     """Can the frame-walking kernels render samples sample_offset .. + n of a signal with n_frames per n_timesteps?"""
     if not sample_offset and n is None:
         return _walkable_np(int(n_frames), int(n_timesteps), RECALLED['resize'])
-    return _walk_weights_np(n_frames, n_timesteps, RECALLED['resize'], sample_offset, n)[1]
+    return _walkable_piece_np(int(n_frames), int(n_timesteps), RECALLED['resize'], int(sample_offset),
+                              int(n_timesteps if n is None else n))
 
 
 def linear_weights(n_frames, n_timesteps, device, sample_offset=0):
@@ -395,15 +407,14 @@ def _linear_weights_at(n_frames, n_timesteps, device, sample_offset, walk=False)
         if int(n_timesteps) % int(n_frames) != 0:
             raise ValueError(f'walk_weights: {n_timesteps} samples are not a whole number of hops of {n_frames} frames')
         u = int(n_timesteps) // int(n_frames)
-        t = idx // u
-        lo = fl.to(torch.int64).clamp_(min=0)
-        off = lo != t
-        nxt = off & (lo == t + 1) & (w == 0) & (idx % u >= u - WALK_BLOCK)
-        if bool((off & ~nxt).any().item()):
+        if not _walkable_piece_np(int(n_frames), int(n_timesteps), RECALLED['resize'], int(sample_offset), int(n_timesteps)):
             raise ValueError(f'walk_weights: samples {int(sample_offset)} .. {int(sample_offset) + int(n_timesteps)} of a signal '
                              f'with {u} samples per frame are not walkable under resize={RECALLED["resize"]!r} (the bilinear '
                              'resize leaves frames n // U and n // U + 1 there); render the piece through resample + '
                              'cos_oscillator_bank, or ask core.walkable() first')
+        t = idx // u
+        lo = fl.to(torch.int64).clamp_(min=0)
+        nxt = (lo == t + 1) & (w == 0) & (idx % u >= u - WALK_BLOCK)
         w = torch.where(nxt, torch.ones_like(w), w)
     return w.contiguous()
 

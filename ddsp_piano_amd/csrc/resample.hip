@@ -14,9 +14,16 @@ namespace ddspp {
 // (round 5's flat grid-stride loop spent two 64-bit divisions and two 64-bit remainders per element and ran at 0.41-0.44 of
 // the HBM peak: VALU bound), four outputs in flight per thread, non-temporal 16-byte stores (the envelopes are consumed by
 // another kernel much later or never from cache: nothing of 2.4 GB per voice should displace x in L2).
+constexpr int RS_NT_DEFAULT = 1;  // non-temporal stores unless DDSPP_RESAMPLE_NT=0 (A/B: profiles/r06_ubench.txt)
 constexpr int RS_TILE = 768;      // samples per workgroup: a multiple of 256 / gcd(256, C / VEC) for every C / VEC <= 256 that matters
 
 typedef float rs_f4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, class V>
+__device__ __forceinline__ void rs_store(V v, V* p) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // thread -> (column piece c, first sample nl of the tile), and its step: 256 consecutive pieces later
 struct RsWalk {
@@ -38,7 +45,7 @@ struct RsWalk {
 };
 
 // y[r, n, c] = x[r, lo[n], c] + (x[r, hi[n], c] - x[r, lo[n], c]) * w[n]
-template <int VEC>
+template <int VEC, bool NT>
 __global__ void __launch_bounds__(256) resample_linear_kernel(const float* __restrict__ x,
                                                             const int* __restrict__ lo,
                                                             const int* __restrict__ hi,
@@ -89,9 +96,9 @@ __global__ void __launch_bounds__(256) resample_linear_kernel(const float* __res
                 o.y = a[u].y + (b[u].y - a[u].y) * wn[u];
                 o.z = a[u].z + (b[u].z - a[u].z) * wn[u];
                 o.w = a[u].w + (b[u].w - a[u].w) * wn[u];
-                __builtin_nontemporal_store(o, reinterpret_cast<rs_f4*>(yo));
+                rs_store<NT>(o, reinterpret_cast<rs_f4*>(yo));
             } else {
-                __builtin_nontemporal_store(a[u].x + (b[u].x - a[u].x) * wn[u], yo);
+                rs_store<NT>(a[u].x + (b[u].x - a[u].x) * wn[u], yo);
             }
         }
     }
@@ -99,7 +106,7 @@ __global__ void __launch_bounds__(256) resample_linear_kernel(const float* __res
 
 // y[r, t*U + j, c] = x[r, t, c] * win[U + j] + x[r, min(t + 1, T - 1), c] * win[j]
 // (= overlap_and_add of Hann-windowed frames with the appended end point, trimmed by one hop)
-template <int VEC>
+template <int VEC, bool NT>
 __global__ void __launch_bounds__(256) resample_window_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ win,
                                                             float* __restrict__ y, int T, int C, int U, int tiles) {
@@ -156,9 +163,9 @@ __global__ void __launch_bounds__(256) resample_window_kernel(const float* __res
                 o.y = a[u].y * w0[u] + b[u].y * w1[u];
                 o.z = a[u].z * w0[u] + b[u].z * w1[u];
                 o.w = a[u].w * w0[u] + b[u].w * w1[u];
-                __builtin_nontemporal_store(o, reinterpret_cast<rs_f4*>(yo));
+                rs_store<NT>(o, reinterpret_cast<rs_f4*>(yo));
             } else {
-                __builtin_nontemporal_store(a[u].x * w0[u] + b[u].x * w1[u], yo);
+                rs_store<NT>(a[u].x * w0[u] + b[u].x * w1[u], yo);
             }
         }
     }
@@ -205,10 +212,11 @@ int ddspp_resample_linear(const float* x, const int* lo, const int* hi, const fl
     const int tiles = (N + RS_TILE - 1) / RS_TILE;
     DDSPP_REQUIRE((long long)R * tiles < (1ll << 31), "resample_linear: R x N too large for one launch");
     const dim3 grid((unsigned)(R * tiles));
-    if (vec)
-        hipLaunchKernelGGL(resample_linear_kernel<4>, grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
-    else
-        hipLaunchKernelGGL(resample_linear_kernel<1>, grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
+    const bool nt = ddspp_option_literal("DDSPP_RESAMPLE_NT", RS_NT_DEFAULT) != 0;
+    if (vec && nt) hipLaunchKernelGGL((resample_linear_kernel<4, true>), grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
+    else if (vec) hipLaunchKernelGGL((resample_linear_kernel<4, false>), grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
+    else if (nt) hipLaunchKernelGGL((resample_linear_kernel<1, true>), grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
+    else hipLaunchKernelGGL((resample_linear_kernel<1, false>), grid, dim3(256), 0, stream, x, lo, hi, w, y, T, C, N, tiles);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }
@@ -224,10 +232,11 @@ int ddspp_resample_window(const float* x, const float* window, float* y, int R, 
     const int tiles = (T * U + RS_TILE - 1) / RS_TILE;
     DDSPP_REQUIRE((long long)R * tiles < (1ll << 31), "resample_window: R x N too large for one launch");
     const dim3 grid((unsigned)(R * tiles));
-    if (vec)
-        hipLaunchKernelGGL(resample_window_kernel<4>, grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
-    else
-        hipLaunchKernelGGL(resample_window_kernel<1>, grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
+    const bool nt = ddspp_option_literal("DDSPP_RESAMPLE_NT", RS_NT_DEFAULT) != 0;
+    if (vec && nt) hipLaunchKernelGGL((resample_window_kernel<4, true>), grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
+    else if (vec) hipLaunchKernelGGL((resample_window_kernel<4, false>), grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
+    else if (nt) hipLaunchKernelGGL((resample_window_kernel<1, true>), grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
+    else hipLaunchKernelGGL((resample_window_kernel<1, false>), grid, dim3(256), 0, stream, x, window, y, T, C, U, tiles);
     DDSPP_LAUNCH_CHECK();
     return DDSPP_OK;
 }

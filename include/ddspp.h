@@ -175,7 +175,12 @@ int ddspp_polyphonic_additive(const float* f0_hz, const float* amplitudes, const
  * (--decompose), and what the outputs dictionary of default_model.py:56-74's node list holds (every `sub_add_i` names a
  * voice's signal).  The same compacted bank with the harmonic sum stopped at voice boundaries: lanes only for audible
  * oscillators, the voices of a segment packed back to back in whole blocks of 32.  Arguments as
- * ddspp_polyphonic_additive (no streaming state); workspace: ddspp_polyphonic_stems_workspace_bytes. */
+ * ddspp_polyphonic_additive (no streaming state); workspace: ddspp_polyphonic_stems_workspace_bytes.
+ * Memory: the workspace holds one partial row of T*U floats per 32-entry block of the packed list, sized for the worst
+ * case (every harmonic of every voice audible): B * P * S * ceil(H / 32) rows = ceil(H / 32) times the stems themselves
+ * (H = 128: four times; config 3: 1.2 GB beside 0.3 GB of stems; config 5 at batch 256: 18.9 GB beside 4.7 GB) -- the caller
+ * owns it and may release it after the call; ask ddspp_polyphonic_stems_workspace_bytes before choosing this entry point
+ * for hours-long single segments. */
 size_t ddspp_polyphonic_stems_workspace_bytes(int B, int P, int T, int S, int H, int U);
 int ddspp_polyphonic_stems(const float* f0_hz, const float* amplitudes, const float* harmonic_distribution,
                            const float* harmonic_shifts, const float* inharm_coef, const int* audible, const float* wlin,

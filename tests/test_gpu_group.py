@@ -516,11 +516,22 @@ def test_paired_substrings_in_the_compacted_bank(monkeypatch):
     for b in range(B):
         ref = osyn(*[raw[k][b * P:(b + 1) * P] for k in keys]).sum(0)
         assert rms_err(mix[b].cpu().numpy(), ref) < TOL * max(1.0, rms(ref)), b
-    # ... and it matters: with sub-string 1's harmonic 12 left in, the audio is another one
+    # the unpaired kernel (one oscillator per lane, each masked by its own frequency) agrees ...
     set_option(monkeypatch, 'DDSPP_OSC_PAIR', '0')
     plain = core.polyphonic_additive(ctl['f0_hz'], amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr,
                                      audible=ctl['_audible'])
     assert (mix - plain).abs().max().item() < 2e-6 * max(1.0, float(plain.abs().max()))
+    set_option(monkeypatch, 'DDSPP_OSC_PAIR')
+    # ... and the gap is really there: with sub-string 1 moved to sub-string 0's frequency its harmonic 12 is below
+    # Nyquist and sounds, so the paired kernel must have silenced exactly that partial above -- the two renders differ by about
+    # its amplitude, amp * hd[11] / 2, in the voices at 1 kHz (and not at all in the voices an octave lower)
+    f0_same = ctl['f0_hz'].clone()
+    f0_same[..., 1] = f0_same[..., 0]
+    unmasked = core.polyphonic_additive(f0_same, amp, ctl['harmonic_distribution'], ctl['harmonic_shifts'], B, N, sr,
+                                        audible=ctl['_audible'])
+    partial = float((amp[0::2, :, None] * ctl['harmonic_distribution'][0::2, :, 11:12]).abs().max()) / 2
+    assert partial > 1e-5
+    assert (unmasked - mix).abs().max().item() > 0.5 * partial
 
 
 def test_moving_frequencies_prepass_parts_and_nyquist_crossings(monkeypatch):

@@ -36,9 +36,14 @@ def main():
             t = float(np.min(bench.event_times(wr, 4, warmup=1))) * 1e-3
             print(f'write probe nt={nt} streams={waves:6d}: {t * 1e3:7.3f} ms  {nw.value / t / 1e9:7.1f} GB/s')
     del y
-    for name, fn in (('resample linear', lambda: core.resample(hf, N)), ('resample window', lambda: core.resample(ha, N, method='window'))):
-        ts = np.array(bench.event_times(fn, 5, warmup=1))
-        print(f'{name}: min {ts.min():7.3f} ms  mean {ts.mean():7.3f} ms  {nbytes / ts.mean() / 1e6:7.1f} GB/s written')
+    from ddsp_piano_amd import _lib
+    for rep in range(2):
+        for nt in (1, 0):
+            _lib.set_option('DDSPP_RESAMPLE_NT', nt)
+            for name, fn in (('resample linear', lambda: core.resample(hf, N)), ('resample window', lambda: core.resample(ha, N, method='window'))):
+                ts = np.array(bench.event_times(fn, 5, warmup=1))
+                print(f'{name} ({"non-temporal" if nt else "plain"} stores): min {ts.min():7.3f} ms  mean {ts.mean():7.3f} ms  '
+                      f'{nbytes / ts.mean() / 1e6:7.1f} GB/s written')
 
 
 if __name__ == '__main__':
