@@ -17,14 +17,18 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libddspp.so')
-SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'osc_stream.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
+SOURCES = ['error.cpp', 'midi_conditioning.cpp', 'tables.cpp', 'oscillator.hip', 'oscillator_p1.hip', 'oscillator_p2.hip', 'oscillator_p3.hip', 'osc_stream.hip', 'bank_compact.hip', 'resample.hip', 'controls.hip',
            'noise.hip', 'noise_win.hip', 'noise_bands.hip', 'reverb.hip', 'reverb_part.hip', 'fdn.hip', 'probe.hip', 'group.cpp']
 ARCH = 'gfx950'
 HEADERS = ['ddspp_common.h', 'osc_common.h', 'noise_win.h', 'reverb_part.h', os.path.join('..', '..', 'include', 'ddspp.h')]
 # packed f32 math has the per-element rate of plain VALU ops on gfx950 (profiles/r01_ubench.txt); in the
 # time-varying FIR the SLP vectoriser's v_pk_fma_f32 operand pairs cost a dozen extra LDS reads / moves per step
-PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'noise_win.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'], 'osc_stream.hip': ['-fno-slp-vectorize'],
+PER_FILE_FLAGS = {'noise.hip': ['-fno-slp-vectorize'], 'noise_win.hip': ['-fno-slp-vectorize'], 'oscillator.hip': ['-fno-slp-vectorize'], 'oscillator_p1.hip': ['-fno-slp-vectorize'], 'oscillator_p2.hip': ['-fno-slp-vectorize'],
+                  'oscillator_p3.hip': ['-fno-slp-vectorize'], 'osc_stream.hip': ['-fno-slp-vectorize'],
                   'bank_compact.hip': ['-fno-slp-vectorize']}
+
+# sources a translation unit includes beside the HEADERS (oscillator_p*.hip are oscillator.hip again, with DDSPP_OSC_PART set)
+EXTRA_DEPS = {f'oscillator_p{k}.hip': ['oscillator.hip'] for k in (1, 2, 3)}
 
 DDSPP_OK = 0
 DDSPP_EINVAL = -22
@@ -72,7 +76,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
         srcp = os.path.join(_CSRC, src)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
-                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, h)) for h in HEADERS)):
+                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(_CSRC, h)) for h in HEADERS + EXTRA_DEPS.get(src, []))):
             return obj
         extra = PER_FILE_FLAGS.get(src, [])
         cmd = [hipcc] + flags + extra + ['-x', 'hip', '-c', srcp, '-o', obj]

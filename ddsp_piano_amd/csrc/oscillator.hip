@@ -28,7 +28,26 @@
 
 #include "osc_common.h"
 
+// One source, four translation units (round 6: the template instances of osc_kernel / osc_prepass_fused_kernel were 1 min 55 s
+// of a 2-minute cold build in ONE compiler process): this file compiled as it is (part 0) holds every non-template kernel,
+// the host side, the C-ABI and the instances for 1 and 2 oscillators per lane; oscillator_p1/2/3.hip define DDSPP_OSC_PART
+// and include it again for the instances with 3-4, 6 and 8 oscillators per lane (rows of 129 .. 512 oscillators: S x H of the
+// fused entry points, H of cos_oscillator_bank -- every shipped configuration except ENSTDkCl-32kHz (192) and the two-string
+// 24 kHz one (256) stays within part 0).  The parts build in parallel (ddsp_piano_amd/_lib.py).
+#ifndef DDSPP_OSC_PART
+#define DDSPP_OSC_PART 0
+#endif
+#define DDSPP_OSC_OWNS(vpl)                                                                                     \
+    ((DDSPP_OSC_PART == 0 && (vpl) <= 2) || (DDSPP_OSC_PART == 1 && ((vpl) == 3 || (vpl) == 4)) ||              \
+     (DDSPP_OSC_PART == 2 && (vpl) == 6) || (DDSPP_OSC_PART == 3 && (vpl) == 8))
+
 namespace ddspp {
+
+// helpers of the launchers below, defined in part 0
+int env_int(const char* name, int dflt);
+void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps, hipStream_t stream,
+                        const float* state_in = nullptr, int V = 0);
+void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* echunk, hipStream_t stream);
 
 // DECAY (fused source, SurrogateAdditive): the amplitude of oscillator k in frame t is multiplied by
 // |decays[t, k]| ** (decay_time[t] U + r), r = sample in the frame (surrogate_synth.py:76-95: tf.repeat of the frame's
@@ -872,6 +891,18 @@ __global__ void __launch_bounds__(256) osc_prepass_fused_kernel(const OscParams 
     }
 }
 
+// launchers of the per-VPL instances: defined here, instantiated by the part that owns the VPL (the others see `extern template`)
+template <int VPL>
+void launch_prepass_one_wave(const OscParams& q, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((osc_prepass_fused_kernel<VPL, 1>), grid, blk, lds, stream, q);
+}
+// osc_kernel<VPL, fused, MODE_PREPASS>: the block machinery as a chunk pre-pass (span_starts, whole-file mode with > 128 oscillators per row)
+template <int VPL>
+void launch_block_prepass(const OscParams& q, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((osc_kernel<VPL, true, MODE_PREPASS, true>), grid, blk, lds, stream, q);
+}
+
+#if DDSPP_OSC_PART == 0
 // Chunk-parallel pre-pass for a few long rows (a whole file as one segment): one wavefront per (row, chunk) writes
 // the chunk's end phase e = (sum of the chunk's 1000 omegas, sequentially in float32) % 2 pi.  All frames the chunk
 // touches are fetched in one batch; a chunk whose oscillators keep their frequency (a held note -- nearly all of
@@ -1172,10 +1203,8 @@ __global__ void __launch_bounds__(256) osc_offset_scan_groups_kernel(const float
     }
 }
 
-static int env_int(const char* name, int dflt);
-
-static void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
-                               hipStream_t stream, const float* state_in = nullptr, int V = 0) {
+void launch_offset_scan(const float* ework, float* astart, int R, int npre, int VP, int spans, int cps,
+                        hipStream_t stream, const float* state_in, int V) {
     const size_t nthr = (size_t)R * VP;
     if (npre > SCAN_CT && !env_int("DDSPP_OSC_SHORT_SCAN", 0)) {
         OscParams q{};                     // (no audible counts on this path: every group is scanned)
@@ -1291,7 +1320,7 @@ static bool sample_rate_is_checked(float sr) {
     return false;
 }
 
-static int env_int(const char* name, int dflt) { return ddspp_option_literal(name, dflt); }
+int env_int(const char* name, int dflt) { return ddspp_option_literal(name, dflt); }
 
 static int pick_vpl(int V) {
     const int need = (V + 63) / 64;
@@ -1373,7 +1402,7 @@ static Plan make_plan(int R, int N, int V, bool angular, bool fused, int spans_r
 // Launch of the memoised pre-pass: `tasks` (row, group) pairs, start offsets into q.ework (= astart).  In sections
 // (workgroups of four wavefronts, PARTS = 4, chunk end phases through `echunk` [R, npre, VP] and the group scan) when the
 // task is at most 128 oscillators wide and there are chunks enough to share out; one wavefront per pair otherwise.
-static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* echunk, hipStream_t stream) {
+void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* echunk, hipStream_t stream) {
     const size_t ldsw = (size_t)4 * PRE_W * sizeof(float);              // weight buffers of the four wavefronts
     const bool parts4 = vpl <= 2 && echunk && q0.npre >= 8 && !env_int("DDSPP_OSC_PREPASS_ONE_WAVE", 0);
     // (skip_moving is only set where this holds: polyphonic_additive_impl tests the same conditions)
@@ -1402,17 +1431,18 @@ static void launch_memo_prepass(int vpl, const OscParams& q0, int tasks, float* 
     const OscParams& q = q0;
     const dim3 grid((tasks + 3) / 4), blk(256);
     switch (vpl) {
-        case 1: hipLaunchKernelGGL((osc_prepass_fused_kernel<1, 1>), grid, blk, ldsw, stream, q); break;
-        case 2: hipLaunchKernelGGL((osc_prepass_fused_kernel<2, 1>), grid, blk, ldsw, stream, q); break;
-        case 3: hipLaunchKernelGGL((osc_prepass_fused_kernel<3, 1>), grid, blk, ldsw, stream, q); break;
-        case 4: hipLaunchKernelGGL((osc_prepass_fused_kernel<4, 1>), grid, blk, ldsw, stream, q); break;
-        case 6: hipLaunchKernelGGL((osc_prepass_fused_kernel<6, 1>), grid, blk, ldsw, stream, q); break;
-        default: hipLaunchKernelGGL((osc_prepass_fused_kernel<8, 1>), grid, blk, ldsw, stream, q); break;
+        case 1: launch_prepass_one_wave<1>(q, grid, blk, ldsw, stream); break;
+        case 2: launch_prepass_one_wave<2>(q, grid, blk, ldsw, stream); break;
+        case 3: launch_prepass_one_wave<3>(q, grid, blk, ldsw, stream); break;
+        case 4: launch_prepass_one_wave<4>(q, grid, blk, ldsw, stream); break;
+        case 6: launch_prepass_one_wave<6>(q, grid, blk, ldsw, stream); break;
+        default: launch_prepass_one_wave<8>(q, grid, blk, ldsw, stream); break;
     }
 }
+#endif  // DDSPP_OSC_PART == 0
 
 template <int VPL, bool FUSED, bool DECAY = false>
-static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t stream) {
+void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t stream) {
     const int nblk_main = p.R * p.spans;
     const dim3 blk(64 * p.groups);
     const size_t lds = ((size_t)p.groups * (TILE * TSTRIDE) + 2 * p.groups * 32) * sizeof(float);
@@ -1453,6 +1483,35 @@ static void launch_all(const OscParams& p, bool angular, bool sum, hipStream_t s
     }
 }
 
+#define DDSPP_OSC_INSTANCES(vpl, linkage)                                                                          \
+    linkage template void launch_all<vpl, false, false>(const OscParams&, bool, bool, hipStream_t);                    \
+    linkage template void launch_all<vpl, true, false>(const OscParams&, bool, bool, hipStream_t);                     \
+    linkage template void launch_all<vpl, true, true>(const OscParams&, bool, bool, hipStream_t);                      \
+    linkage template void launch_prepass_one_wave<vpl>(const OscParams&, dim3, dim3, size_t, hipStream_t);             \
+    linkage template void launch_block_prepass<vpl>(const OscParams&, dim3, dim3, size_t, hipStream_t);
+#if DDSPP_OSC_OWNS(1)
+DDSPP_OSC_INSTANCES(1, )
+DDSPP_OSC_INSTANCES(2, )
+#endif
+#if DDSPP_OSC_OWNS(3)
+DDSPP_OSC_INSTANCES(3, )
+DDSPP_OSC_INSTANCES(4, )
+#else
+DDSPP_OSC_INSTANCES(3, extern)
+DDSPP_OSC_INSTANCES(4, extern)
+#endif
+#if DDSPP_OSC_OWNS(6)
+DDSPP_OSC_INSTANCES(6, )
+#else
+DDSPP_OSC_INSTANCES(6, extern)
+#endif
+#if DDSPP_OSC_OWNS(8)
+DDSPP_OSC_INSTANCES(8, )
+#else
+DDSPP_OSC_INSTANCES(8, extern)
+#endif
+
+#if DDSPP_OSC_PART == 0
 template <bool FUSED, bool DECAY = false>
 static int dispatch_vpl(int vpl, const OscParams& p, bool angular, bool sum, hipStream_t stream) {
     switch (vpl) {
@@ -1506,20 +1565,23 @@ static void span_starts(const OscParams& p, int R, int V, int vpl_pre, float* as
             const dim3 grid((unsigned)(R * q.npre)), blk(64);
             const size_t plds = ((size_t)(TILE * TSTRIDE) + 2 * 32) * sizeof(float);
             switch (vpl_pre) {
-                case 1: hipLaunchKernelGGL((osc_kernel<1, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 2: hipLaunchKernelGGL((osc_kernel<2, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 3: hipLaunchKernelGGL((osc_kernel<3, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 4: hipLaunchKernelGGL((osc_kernel<4, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                case 6: hipLaunchKernelGGL((osc_kernel<6, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
-                default: hipLaunchKernelGGL((osc_kernel<8, true, MODE_PREPASS, true>), grid, blk, plds, stream, q); break;
+                case 1: launch_block_prepass<1>(q, grid, blk, plds, stream); break;
+                case 2: launch_block_prepass<2>(q, grid, blk, plds, stream); break;
+                case 3: launch_block_prepass<3>(q, grid, blk, plds, stream); break;
+                case 4: launch_block_prepass<4>(q, grid, blk, plds, stream); break;
+                case 6: launch_block_prepass<6>(q, grid, blk, plds, stream); break;
+                default: launch_block_prepass<8>(q, grid, blk, plds, stream); break;
             }
         }
     }
     launch_offset_scan(ework, astart, R, q.npre, VP, p.spans, p.cps, stream, p.state_in, V);
 }
 
+#endif  // DDSPP_OSC_PART == 0 (dispatch, span starts)
+
 }  // namespace ddspp
 
+#if DDSPP_OSC_PART == 0
 using namespace ddspp;
 
 extern "C" {
@@ -1901,3 +1963,4 @@ int ddspp_oscillator_phase_state(const float* f0_hz, const float* harmonic_shift
 }
 
 }  // extern "C"
+#endif  // DDSPP_OSC_PART == 0 (the C-ABI)

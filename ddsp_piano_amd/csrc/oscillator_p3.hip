@@ -1,0 +1,4 @@
+// oscillator.hip, part 3: the template instances of osc_kernel / osc_prepass_fused_kernel with 8 oscillators per
+// lane (see the head of oscillator.hip: one source, four translation units that build in parallel).
+#define DDSPP_OSC_PART 3
+#include "oscillator.hip"

@@ -13,5 +13,7 @@ for k in ('value','ms_per_step','rtf','step_ms'): print(k, d.get(k))
 for k in ("audio_only_call","dense_worst_case","moving_f0","single_stream","single_stream_graph","single_stream_native","native_group_call","whole_file"): print(k, {kk:vv for kk,vv in d.get(k,{}).items() if kk!='workload'})
 print('roofline', {k:d['roofline'][k] for k in ('frac','ms_per_launch')})
 print('roofline_step', d['roofline_step'])
-c=d['cpu_baseline']; print('cpu', c['value'], c['cores'], c['numpy_oracle']['value'], c['torch_cpu_all_cores']['value'], c['torch_cpu_all_cores']['sample'][:200])
+c=d['cpu_baseline']; print('cpu', c['value'], c['cores'], c['kind'], c['sample'][:160])
+print('midi_like', {kk:vv for kk,vv in d.get('midi_like',{}).items() if kk!='workload'})
+ch=d['roofline'].get('three_operator_chain'); print('chain', ch and ch['ms'], ch and ch['frac_of_measured_write'])
 PY
