@@ -149,6 +149,8 @@ SIGNATURES = {
                                           c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     'ddspp_inharmonic_controls_group': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_float, c_int, c_float, c_float, c_float,
                                                 c_float, c_int, c_int, c_void_p]),
+    'ddspp_inharmonic_controls_sparse': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_float, c_int, c_float, c_float, c_float,
+                                                 c_float, c_int, c_int, c_void_p]),
     'ddspp_scale_bias': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_float, c_float, c_float,
                                  c_float, c_void_p]),
     'ddspp_add_signals': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -167,6 +169,9 @@ SIGNATURES = {
     'ddspp_frequency_filter_eo_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'ddspp_frequency_filter_eo': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 + [c_void_p]),
     'ddspp_frequency_filter_eo_voices': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float] * 5 + [c_int] * 3 + [c_void_p]),
+    'ddspp_frequency_filter_eo_drawn_supported': (c_int, [c_int] * 5),
+    'ddspp_frequency_filter_eo_voices_drawn': (c_int, [c_uint64, c_uint64] + [c_void_p] * 8 + [c_int] * 8 + [c_float] * 5 +
+                                               [c_int] * 3 + [c_void_p]),
     'ddspp_time_varying_fir': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     'ddspp_noise_bands': (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),

@@ -1187,16 +1187,62 @@ def frequency_filter(audio, magnitudes, window_size=0, padding='same', raw_scale
     fused = _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale)
     if fused is not None:
         return fused
+    if isinstance(audio, DrawnNoise):
+        audio = audio.materialise()
     impulse_response = frequency_impulse_response(magnitudes, window_size=window_size, raw_scale=raw_scale)
     return fft_convolve(audio, impulse_response, padding=padding)
+
+
+class DrawnNoise:
+    """U(-1, 1) noise [rows, n] that has NOT been drawn yet: the (seed, offset) of the library's Philox4x32-10 stream that
+    uniform_noise((rows, n), seed, offset) would draw it from.  frequency_filter / frequency_filter_voice_sums hand it to the
+    windowed kernel, which draws the numbers while staging them (ddspp_frequency_filter_eo_voices_drawn, round 6: the
+    [rows, n] tensor is never written or read back); any other route calls materialise() -- the same numbers, bit for bit."""
+
+    def __init__(self, rows, n, seed, offset, device):
+        self.shape = (int(rows), int(n))
+        self.seed, self.offset, self.device = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), device
+
+    def materialise(self):
+        return uniform_noise(self.shape, seed=self.seed, offset=self.offset, device=self.device)
 
 
 def _frequency_filter_fused(audio, magnitudes, window_size, padding, raw_scale, voices=None):
     """FIR design + time-varying FIR in one kernel (ddspp_frequency_filter_eo) when the shape fits, else None.
     Bit-identical to the two-kernel form; the [B, T, Lw] impulse responses are never materialised."""
-    if padding != 'same' or not (torch.is_tensor(audio) and torch.is_tensor(magnitudes)):
+    drawn = audio if isinstance(audio, DrawnNoise) else None
+    if padding != 'same' or not ((drawn is not None or torch.is_tensor(audio)) and torch.is_tensor(magnitudes)):
         return None
-    x, mags = tf_float32(audio), tf_float32(magnitudes)
+    mags = tf_float32(magnitudes)
+    if drawn is not None:
+        # the shape decides first: only the windowed kernel draws its own noise
+        if (mags.dim() != 3 or drawn.shape[0] != mags.shape[0] or drawn.shape[1] % 4 or mags.shape[1] < 2 or
+                drawn.shape[1] % mags.shape[1]):
+            audio, drawn = drawn.materialise(), None
+        else:
+            eo = fir_eo_tables(int(mags.shape[2]), int(window_size), mags.device)
+            if eo is None or not _lib_().ddspp_frequency_filter_eo_drawn_supported(
+                    drawn.shape[1], int(mags.shape[1]), int(mags.shape[2]), eo[6], _auto_delay(-1)):
+                audio, drawn = drawn.materialise(), None
+    if drawn is not None:
+        mags = mags.contiguous()
+        if mags.data_ptr() % 16:
+            return None
+        b, n = drawn.shape
+        t, k = int(mags.shape[1]), int(mags.shape[2])
+        ce, co, idx, we, wo, nj, lw = fir_eo_tables(k, int(window_size), mags.device)
+        code, bias, prm = (-1, 0.0, dict(exponent=10.0, max_value=2.0, threshold=1e-7, gain=1.0)) if raw_scale is None else raw_scale
+        n_voices, vq, vmajor, split_last = voices if voices is not None else (1, 1, False, False)
+        if n_voices % vq or b % n_voices or (split_last and vq < 2):
+            return None
+        out = torch.empty((b // vq, n), dtype=torch.float32, device=mags.device)
+        last = torch.empty((b // n_voices, n), dtype=torch.float32, device=mags.device) if split_last else None
+        _lib.check(_lib_().ddspp_frequency_filter_eo_voices_drawn(
+            drawn.seed, drawn.offset, _ptr(mags), _ptr(ce), _ptr(co), _ptr(idx), _ptr(we), _ptr(wo), _ptr(out), _ptr(last), b, n,
+            t, k, lw, nj, _auto_delay(-1), int(code), float(bias), prm['exponent'], prm['max_value'], prm['threshold'],
+            prm['gain'], n_voices, vq, int(vmajor), _stream()))
+        return (out, last) if split_last else out
+    x = tf_float32(audio)
     if x.dim() != 2 or mags.dim() != 3 or x.shape[0] != mags.shape[0]:
         return None
     b, n = x.shape

@@ -129,6 +129,18 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
     //   ha(t, v) = amp[t] * hd[t, k]                      inharm_synth.py:112
     float x0[VPL], x1[VPL], a0[VPL], a1[VPL];
     float q_f0[VPL], q_sh[VPL], q_hd[VPL], q_amp[VPL];
+    // Round 6: with get_controls' per-frame counts at hand (p.audible: 1 + the last harmonic whose amp * hd is not zero) a
+    // harmonic at or above its frame's count is taken as silent FROM THE COUNT -- the product it replaces is exactly zero --
+    // so get_controls need not write that part of harmonic_distribution at all (InharmParams::hd_sparse: two thirds of the
+    // [R, T, H] tensor at a piano's note mix; what the load returns there is never used).  One more 4-byte load per lane and
+    // frame; the compare takes the place of the `valid` select.
+    const bool by_count = p.audible != nullptr;
+    int q_cnt[VPL], vkv[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        vkv[j] = valid[j] ? vk[j] : 0x7fffffff;
+        q_cnt[j] = 0x10000;
+    }
     // DECAY: d0 = |decays| of the current frame, e_blk = d0 ** (decay_time U + r) at the start of the current block,
     // d0_8 = d0 ** 8; nd / ndt = the next frame's raw factor and time (requested when the current frame starts)
     float d0[DECAY ? VPL : 1], e_blk[DECAY ? VPL : 1], d0_8[DECAY ? VPL : 1], nd[DECAY ? VPL : 1], ndt[DECAY ? VPL : 1];
@@ -163,9 +175,11 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
                 q_amp[j] = q_amp[0];
                 q_sh[j] = q_sh[0];
                 q_hd[j] = q_hd[0];
+                q_cnt[j] = q_cnt[0];
                 continue;
             }
             q_amp[j] = p.amp[fr];
+            if (by_count) q_cnt[j] = p.audible[fr] & 0xffff;
             q_sh[j] = has_shifts ? p.shifts[fr * H + vk[j]] : (from_inh ? p.inh[fr] : 0.0f);
             q_hd[j] = p.hd[fr * H + vk[j]];
         }
@@ -185,7 +199,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
             }
             const float a = q_amp[j] * q_hd[j];
             xf[j] = valid[j] ? f : 0.0f;
-            xa[j] = valid[j] ? a : 0.0f;
+            xa[j] = vkv[j] < q_cnt[j] ? a : 0.0f;
         }
     };
     // per-frame classification (wave-uniform):
@@ -548,7 +562,7 @@ __device__ __forceinline__ void bank_slot(const OscParams& p, float* tile, const
             for (int j = 0; j < VPL; ++j) {
                 a0[j] = a1[j];
                 const float a = q_amp[j] * q_hd[j];
-                a1[j] = valid[j] ? a : 0.0f;
+                a1[j] = vkv[j] < q_cnt[j] ? a : 0.0f;
                 const bool gone = x0[j] >= nyq;
                 am0[j] = gone ? 0.0f : a0[j];
                 da[j] = gone ? 0.0f : a1[j] - a0[j];

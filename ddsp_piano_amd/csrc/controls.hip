@@ -33,6 +33,13 @@ struct InharmParams {
     float nyquist, min_frequency, n_substrings;
     int normalize_after_nyquist_cut, normalize_below_nyquist;
     ScaleFn scale;
+    // Round 6 (lean kernel only): hd_out of a frame is written only below the frame's audible count, in whole groups of 16
+    // (k < 16 ceil(count / 16)); the rest of the row keeps whatever the buffer held.  Every harmonic at or above the count has
+    // amp_out * hd_out == 0 by the count's definition, and the compacted bank -- the only reader on that route -- takes them as 0
+    // from the count itself (bank_compact.hip, frame_request).  Rows of a segment's last voice (shifts_last given) are
+    // written whole: the outputs dictionary keeps that voice's controls.  At a piano's note mix two thirds of the [R, T, H]
+    // tensor are never written.
+    int hd_sparse;
 };
 
 // A frame is conditioned by ONE DPP ROW (16 lanes), lane i of the row taking harmonics i, i + 16, i + 32, ...; a
@@ -411,16 +418,6 @@ __global__ void __launch_bounds__(256) inharmonic_controls_lean_kernel(const Inh
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             if (amp * *hd[j] != 0.0f) last = sub + 16 * j + 1;
-        if (live) {
-            float* dst = p.hd_out + frame * H + sub;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) dst[16 * j] = *hd[j];
-            if (sub == 0) p.amp_out[frame] = amp;
-        }
-        if (p.count_out) {
-            last = row_max(last);
-            if (live && sub == 0) p.count_out[frame] = last;            // bit 16 is added by frames_moved_kernel
-        }
         // harmonic_shifts: every frame's when the caller keeps them all, else those of the segments' last voices
         bool is_last = false;
         unsigned row = row0, tt = tt0 + 4 * (unsigned)u + (unsigned)rowi;
@@ -431,6 +428,21 @@ __global__ void __launch_bounds__(256) inharmonic_controls_lean_kernel(const Inh
             }
             is_last = live && (p.vmajor ? row >= last_lo : (row % (unsigned)p.P) == (unsigned)p.P - 1);
         }
+        if (p.count_out) last = row_max(last);
+        if (live) {
+            float* dst = p.hd_out + frame * H + sub;
+            if (p.hd_sparse) {                                          // (InharmParams::hd_sparse; wave-uniform)
+                const int keep = is_last ? H : last;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (16 * j < keep) dst[16 * j] = *hd[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dst[16 * j] = *hd[j];
+            }
+            if (sub == 0) p.amp_out[frame] = amp;
+        }
+        if (p.count_out && live && sub == 0) p.count_out[frame] = last;  // bit 16 is added by frames_moved_kernel
         if (__any(live && (p.shifts_out != nullptr || is_last))) {
             const unsigned b = p.vmajor ? row - last_lo : row / (unsigned)p.P;
 #pragma unroll
@@ -603,7 +615,7 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
                               float exponent, float max_value, float threshold, float gain,
                               int normalize_after_nyquist_cut, int normalize_below_nyquist,
                               float* shifts_last_out, int n_voices, int voice_major,
-                              hipStream_t stream) {
+                              hipStream_t stream, int hd_sparse = 0) {
     DDSPP_REQUIRE(amplitudes && harmonic_distribution && inharm_coef && f0_hz && amplitudes_out &&
                       harmonic_distribution_out,
                   "inharmonic_controls: null buffer");
@@ -635,6 +647,8 @@ static int inharmonic_controls_impl(const float* amplitudes, const float* harmon
     // every shipped model: 48 / 64 / 96 / 128 / 192 harmonics (8, 16, 16 / 24, 24 / 48, 32 kHz) with the default flags
     const bool lean = norm_after && normalize_below_nyquist && H % 16 == 0 &&
                       (nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12) && !ddspp_option_literal("DDSPP_CONTROLS_GENERIC", 0);
+    // (the sparse store is the lean kernel's; any other shape or flag set writes the whole tensor, which is always valid)
+    p.hd_sparse = (hd_sparse && lean && audible_out && !ddspp_option_literal("DDSPP_CONTROLS_DENSE_HD", 0)) ? 1 : 0;
 #define DDSPP_LEAN(NJ)                                                                                              \
     do {                                                                                                            \
         if (scale_kind == SCALE_EXP_SIGMOID)                                                                        \
@@ -690,6 +704,28 @@ int ddspp_inharmonic_controls_group(const float* amplitudes, const float* harmon
                                     min_frequency, scale_kind, exponent, max_value, threshold, gain,
                                     normalize_after_nyquist_cut, normalize_below_nyquist, shifts_last_out, n_voices,
                                     voice_major, stream);
+}
+
+// ddspp_inharmonic_controls_group for a caller whose only reader of harmonic_distribution_out is the compacted oscillator
+// bank (ddspp_polyphonic_additive / ddspp_polyphonic_stems with `audible` = audible_out, required here): a frame's row is
+// written only below its audible count, rounded up to whole groups of 16 harmonics -- every value left out would have been
+// multiplied by an amplitude to exactly zero, and the bank takes it as zero from the count -- except for the rows of every
+// segment's last voice (when shifts_last_out is given), which are written whole for the outputs dictionary.  The rest of
+// the buffer keeps what it held: it is NOT a valid harmonic_distribution for any other reader.  Saves two thirds of the
+// tensor's write at a piano's note mix (config 3: 0.42 -> 0.15 GB).  DDSPP_CONTROLS_DENSE_HD=1: write everything (A/B).
+int ddspp_inharmonic_controls_sparse(const float* amplitudes, const float* harmonic_distribution,
+                                     const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                                     float* harmonic_distribution_out, float* shifts_last_out, int* audible_out,
+                                     int R, int T, int H, int S, int n_voices, int voice_major, float sample_rate,
+                                     float min_frequency, int scale_kind, float exponent, float max_value,
+                                     float threshold, float gain, int normalize_after_nyquist_cut,
+                                     int normalize_below_nyquist, hipStream_t stream) {
+    DDSPP_REQUIRE(audible_out, "inharmonic_controls_sparse: audible_out is what tells the reader where a row ends");
+    return inharmonic_controls_impl(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amplitudes_out,
+                                    harmonic_distribution_out, nullptr, audible_out, R, T, H, S, sample_rate,
+                                    min_frequency, scale_kind, exponent, max_value, threshold, gain,
+                                    normalize_after_nyquist_cut, normalize_below_nyquist, shifts_last_out, n_voices,
+                                    voice_major, stream, 1);
 }
 
 // SurrogateAdditive.get_controls' decay factors -- ddsp_piano/modules/surrogate_synth.py:163-171:

@@ -241,7 +241,12 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
         if (rc != DDSPP_OK) return leave(rc);
     }
     const float* z = noise;
-    if (!z) {
+    // (round 6) no noise given and the windowed kernel takes the shape: it draws the numbers itself while staging them
+    const bool draw = !z && g->fused_noise &&
+                      ddspp_frequency_filter_eo_drawn_supported(N, T, K, g->Lw, c.delay_compensation);
+    const unsigned long long draw_off = (unsigned long long)g->calls << 40;
+    if (draw) ++g->calls;
+    if (!z && !draw) {
         float* zbuf = (float*)(ws + g->o_noise);
         rc = ddspp_uniform_noise(zbuf, ((size_t)R * N + 3) / 4 * 4, c.noise_seed, g->calls << 40, zs);
         if (rc != DDSPP_OK) return leave(rc);
@@ -251,7 +256,13 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
     float* zrows = (float*)(ws + g->o_zrows);
     float* zlast = want ? (outputs->noise_last ? outputs->noise_last : (float*)(ws + g->o_zlast)) : nullptr;
     const bool split_in_kernel = want && vpr > 1;
-    if (g->fused_noise) {
+    if (draw) {
+        rc = ddspp_frequency_filter_eo_voices_drawn(c.noise_seed, draw_off, magnitudes, g->CE, g->CO, g->tap_idx, g->tap_we,
+                                                    g->tap_wo, zrows, split_in_kernel ? zlast : nullptr, R, N, T, K, g->Lw,
+                                                    g->NJ, c.delay_compensation, c.noise_scale_kind, c.noise_bias,
+                                                    c.noise_exponent, c.noise_max_value, c.noise_threshold, c.noise_gain, P,
+                                                    vpr, vm, zs);
+    } else if (g->fused_noise) {
         rc = ddspp_frequency_filter_eo_voices(z, magnitudes, g->CE, g->CO, g->tap_idx, g->tap_we, g->tap_wo, zrows,
                                               split_in_kernel ? zlast : nullptr, R, N, T, K, g->Lw, g->NJ, c.delay_compensation,
                                               c.noise_scale_kind, c.noise_bias, c.noise_exponent, c.noise_max_value,
@@ -268,7 +279,8 @@ int ddspp_group_run(ddspp_group* g, const float* amplitudes, const float* harmon
 
     // ---- get_controls of the additive processor over all rows (inharm_synth.py:167-219, :254-270) -------------------
     float* shifts_last = want ? (outputs->harmonic_shifts_last ? outputs->harmonic_shifts_last : (float*)(ws + g->o_shl)) : nullptr;
-    rc = ddspp_inharmonic_controls_group(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amp_c, hd_c,
+    // (the only reader of hd_c is the compacted bank below, and the copy of the last voice's rows: the sparse form, round 6)
+    rc = ddspp_inharmonic_controls_sparse(amplitudes, harmonic_distribution, inharm_coef, f0_hz, amp_c, hd_c,
                                          want ? shifts_last : nullptr, aud, R, T, H, S, P, vm, c.sample_rate,
                                          c.min_frequency, c.scale_kind, c.exponent, c.max_value, c.threshold, c.gain,
                                          c.normalize_after_nyquist_cut, c.normalize_below_nyquist, stream);

@@ -695,30 +695,11 @@ __global__ void __launch_bounds__(256) tv_fir_generic_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 uniform noise in [-1, 1)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k[0] += 0x9E3779B9u;
-    k[1] += 0xBB67AE85u;
-}
-
+// (philox_round / philox_uniform4: noise_win.h)
 __global__ void __launch_bounds__(256) uniform_noise_kernel(float* __restrict__ out, size_t n4,
                                                           uint64_t seed, uint64_t offset) {
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n4; g += (size_t)gridDim.x * 256) {
-        const uint64_t ctr = offset + g;
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-        for (int r = 0; r < 10; ++r) philox_round(c, k);
-        float4 v;
-        v.x = (float)(c[0] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.y = (float)(c[1] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.z = (float)(c[2] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.w = (float)(c[3] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        reinterpret_cast<float4*>(out)[g] = v;
+        reinterpret_cast<float4*>(out)[g] = philox_uniform4(seed, offset + g);
     }
 }
 
@@ -728,17 +709,7 @@ __global__ void __launch_bounds__(256) uniform_noise_rows_kernel(float* __restri
     const size_t total = (size_t)R * n4;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const size_t r = g / n4, i = g - r * n4;
-        const uint64_t ctr = offset + r * row_stride + i;
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-        for (int rr = 0; rr < 10; ++rr) philox_round(c, k);
-        float4 v;
-        v.x = (float)(c[0] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.y = (float)(c[1] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.z = (float)(c[2] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        v.w = (float)(c[3] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        reinterpret_cast<float4*>(out)[g] = v;
+        reinterpret_cast<float4*>(out)[g] = philox_uniform4(seed, offset + r * row_stride + i);
     }
 }
 
@@ -954,8 +925,9 @@ static int launch_fused_noise(const float* audio, const float* magnitudes, const
                               int R, int N,
                               int T, int K, int Lw, int NJ, int delay_compensation, int scale_kind, float bias,
                               float exponent, float max_value, float threshold, float gain, int vq, int n_voices,
-                              int voice_major, hipStream_t stream) {
-    DDSPP_REQUIRE(audio && magnitudes && CE && CO && tap_idx && tap_we && tap_wo && out,
+                              int voice_major, hipStream_t stream, bool draw = false, uint64_t draw_seed = 0,
+                              uint64_t draw_offset = 0) {
+    DDSPP_REQUIRE((audio || draw) && magnitudes && CE && CO && tap_idx && tap_we && tap_wo && out,
                   "frequency_filter_eo: null buffer");
     DDSPP_REQUIRE(R > 0, "frequency_filter_eo: bad dims");
     DDSPP_REQUIRE(scale_kind >= -1 && scale_kind <= 2, "frequency_filter_eo: unknown scale_fn %d", scale_kind);
@@ -969,8 +941,10 @@ static int launch_fused_noise(const float* audio, const float* magnitudes, const
     if (NJ == K / 2 && !env_int("DDSPP_FIR_NO_FUSED", 0) && win_fused_shape(N, T, K, Lw, delay_compensation, &wg)) {
         const ScaleFn wsf{scale_kind, scale_kind > 0 ? logf(exponent) : 0.0f, max_value, threshold, gain};
         return launch_win_fused(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, K, NJ, wg, bias,
-                                wsf, vq, n_voices, voice_major, stream);
+                                wsf, vq, n_voices, voice_major, stream, draw, draw_seed, draw_offset);
     }
+    DDSPP_REQUIRE(!draw, "frequency_filter_eo_voices_drawn: only the windowed kernel draws its own noise "
+                  "(ddspp_frequency_filter_eo_drawn_supported says for which shapes): N=%d T=%d K=%d Lw=%d", N, T, K, Lw);
     FusedGeom g;
     DDSPP_REQUIRE(fused_geometry(N, T, K, Lw, delay_compensation, &g) && NJ == K / 2,
                   "frequency_filter_eo: shape not supported (N=%d T=%d K=%d Lw=%d)", N, T, K, Lw);
@@ -1020,6 +994,26 @@ int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes
     return launch_fused_noise(audio, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, K, Lw, NJ,
                               delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain,
                               voices_per_row, n_voices, voice_major, stream);
+}
+
+// ddspp_frequency_filter_eo_voices on noise that is DRAWN INSIDE THE KERNEL: exactly the U(-1, 1) numbers
+// ddspp_uniform_noise(buf, R * N, seed, offset) would have written into a [R, N] tensor, which then never exists (config 3:
+// 0.29 GB written and read back per step) -- DynamicSizeFilteredNoise.get_signal's tf.random.uniform feeding its
+// frequency_filter (filtered_noise_synth.py:39-42) in one kernel.  Shapes: ddspp_frequency_filter_eo_drawn_supported.
+int ddspp_frequency_filter_eo_drawn_supported(int N, int T, int K, int Lw, int delay_compensation) {
+    WinGeom wg;
+    return (!env_int("DDSPP_FIR_NO_FUSED", 0) && !env_int("DDSPP_NOISE_NO_DRAW", 0) &&
+            win_fused_shape(N, T, K, Lw, delay_compensation, &wg)) ? 1 : 0;
+}
+int ddspp_frequency_filter_eo_voices_drawn(uint64_t seed, uint64_t offset, const float* magnitudes, const float* CE,
+                                           const float* CO, const int* tap_idx, const float* tap_we, const float* tap_wo,
+                                           float* out, float* out_last, int R, int N, int T, int K, int Lw, int NJ,
+                                           int delay_compensation, int scale_kind, float bias, float exponent,
+                                           float max_value, float threshold, float gain, int n_voices, int voices_per_row,
+                                           int voice_major, hipStream_t stream) {
+    return launch_fused_noise(nullptr, magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, K, Lw, NJ,
+                              delay_compensation, scale_kind, bias, exponent, max_value, threshold, gain,
+                              voices_per_row, n_voices, voice_major, stream, true, seed, offset);
 }
 
 // U(-1, 1) noise, Philox4x32-10(counter = offset + i / 4, key = seed); n % 4 == 0.

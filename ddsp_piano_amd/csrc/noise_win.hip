@@ -321,6 +321,17 @@ __device__ __forceinline__ void win_fetch_x(const float* __restrict__ xrow, int 
 #pragma unroll
     for (int u = 0; u < XQ; ++u) xv[u] = xg[min(max(jb0 + (int)threadIdx.x + 256 * u, 0), nblk - 1)];
 }
+// ... or drawn in place (WinGeom::draw_on): the same clamped blocks, from the counters of their place in a [R, N] tensor
+template <int BPF, int XQ>
+__device__ __forceinline__ void win_draw_x(unsigned long long seed, unsigned long long row_base, int nblk, int jb0,
+                                           float4 (&xv)[XQ]) {
+#pragma unroll
+    for (int u = 0; u < XQ; ++u) {
+        const int b = threadIdx.x + 256 * u;
+        if (XQ * 256 == BPF * WIN_D || b < BPF * WIN_D)
+            xv[u] = philox_uniform4(seed, row_base + (unsigned long long)min(max(jb0 + b, 0), nblk - 1));
+    }
+}
 template <int BPF, int XQ>
 __device__ __forceinline__ void win_store_x(float* __restrict__ Xs, int nblk, int jb0, const float4 (&xv)[XQ]) {
 #pragma unroll
@@ -408,6 +419,8 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
         F0 = (task - orow * g.wpr) * g.W;
     };
     float4 xv[XQ], mv[MQ];
+    const int upw = tpw * vq;
+    const int u_begin = min((int)blockIdx.x * upw, nunits), u_end = min(u_begin + upw, nunits);
     // The tap weights of a column are 12 values (4 indices, 4 even and 4 odd weights) and the four lanes (col, kq = 0..3)
     // of a column need the same twelve: each keeps three of them for the life of the workgroup and the design fetches
     // the other nine with ds_bpermute -- 3 registers instead of 12, and no loads in the loop (columns past NJ repeat
@@ -433,7 +446,12 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     auto fetch_x = [&](int unit) {
         int row, F0;
         unit_geometry(min(unit, nunits - 1), row, F0);
-        win_fetch_x<BPF, XQ>(x + (size_t)row * N, nblk, BPF * (F0 - g.RL), xv);
+        if (g.draw_on) {                 // (wave-uniform)
+            if (unit < u_end)            // nothing is drawn for a unit no walk will read
+                win_draw_x<BPF, XQ>(g.draw_seed, g.draw_offset + (unsigned long long)row * nblk, nblk, BPF * (F0 - g.RL), xv);
+        } else {
+            win_fetch_x<BPF, XQ>(x + (size_t)row * N, nblk, BPF * (F0 - g.RL), xv);
+        }
     };
     auto store_x = [&](int unit) {
         int row, F0;
@@ -469,8 +487,6 @@ noise_win_fused_body(const float* __restrict__ x,          // [R, N] noise
     //   noise(u+1) registers -> LDS, fetch noise(u+2)
     // Both prefetches have a whole walk to land (measured: with the magnitudes fetched behind the design only, the
     // kernel waited ~2 us per unit for them).
-    const int upw = tpw * vq;
-    const int u_begin = min((int)blockIdx.x * upw, nunits), u_end = min(u_begin + upw, nunits);
     if (u_begin < u_end) {
         fetch_x(u_begin);
         fetch_m(u_begin);
@@ -1001,6 +1017,7 @@ bool win_geometry(int N, int T, int Lw, int delay, WinGeom* g) {
     // are the two triangles fir_win_step's HEAD / TAIL leave out
     g->trim = (delay + OPL - 1) % 4 == 0 && Lw + 2 + OPL == 4 * g->nsteps;
     g->Lw = Lw;
+    g->draw_on = 0; g->draw_seed = 0; g->draw_offset = 0;        // (launch_win_fused sets them)
     return true;
 }
 
@@ -1027,8 +1044,12 @@ bool win_tvfir_supported(int N, int T, int Lw, int delay, WinGeom* g) {
 
 int launch_win_fused(const float* audio, const float* magnitudes, const float* CE, const float* CO, const int* tap_idx,
                      const float* tap_we, const float* tap_wo, float* out, float* out_last, int R, int N, int T, int K,
-                     int NJ, const WinGeom& g, float bias, const ScaleFn& sf, int vq, int n_voices, int voice_major,
-                     hipStream_t stream) {
+                     int NJ, const WinGeom& g_in, float bias, const ScaleFn& sf, int vq, int n_voices, int voice_major,
+                     hipStream_t stream, bool draw, unsigned long long draw_seed, unsigned long long draw_offset) {
+    WinGeom g = g_in;
+    g.draw_on = draw ? 1 : 0;
+    g.draw_seed = draw_seed;
+    g.draw_offset = draw_offset;
     const long long tasks = (long long)(R / vq) * g.wpr;
     DDSPP_REQUIRE((long long)R * g.wpr < (1ll << 31), "frequency_filter_eo: too many tasks");
     const size_t lds = win_lds_bytes(g, K) + (size_t)ddspp_option_literal("DDSPP_WIN_LDS_PAD", 0);     // pad: fewer workgroups per CU (A/B)
@@ -1070,7 +1091,7 @@ int launch_win_fused(const float* audio, const float* magnitudes, const float* C
     // image but the window's first, i.e. at least one frame of look-back
     // the matrix-pipe walk: its schedule is compiled for one (delay, taps, look-back, look-ahead); a misaligned delay makes
     // it read taps below index 0, which are zeros of a gap in any image but the window's first (RL >= 1)
-    const bool mw = ddspp_option_literal("DDSPP_WIN_MFMA", 0) && g.padl >= 8;      // opt-in: same time as the vector walk
+    const bool mw = ddspp_option_literal("DDSPP_WIN_MFMA", 0) && g.padl >= 8 && !draw;      // opt-in: same time as the vector walk
 #define DDSPP_WIN_LAUNCH_MW(KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH)                                                        \
     hipLaunchKernelGGL((noise_win_fused_mw_kernel<KH, JT, OPL, BPF, QB, DELAY, LW, RL, RH>), grid, block, lds, stream, audio, \
                        magnitudes, CE, CO, tap_idx, tap_we, tap_wo, out, out_last, R, N, T, NJ, g, bias, sf, vq, n_voices,   \

@@ -319,7 +319,7 @@ def run(plan, inputs, noise=None, need_stems=True):
     def noise_branch(noise):
         nctl = None if fuse_scale else noise_p.get_controls(mags)    # audio only: scale_fn runs inside the FIR design
         if noise is None:
-            noise = noise_p.draw_noise(R, N, dev)
+            noise = noise_p.draw_noise_lazy(R, N, dev)    # (round 6) drawn inside the filter kernel when its shape allows
         else:
             noise = noise_rows(noise, B, P, N, vm)
         m_src = mags if fuse_scale else nctl['magnitudes']
@@ -362,8 +362,12 @@ def run(plan, inputs, noise=None, need_stems=True):
             return None
     else:
         lean = compact or stems_compact
+        # (round 6) on both compacted routes the bank is the only reader of the normalised distribution: the rows are
+        # written only below each frame's audible count (the last voice's whole, for the outputs dictionary)
+        to_bank = compact or (stems_compact and P * S <= 64 and not _lib.options.stems_single)
         ctl = additive._controls(amp, hd, inh, f0, want_counts=lean, want_shifts=not lean,
-                                 last_voice_of=(P, vm) if (want_last or stems_compact) else None)
+                                 last_voice_of=(P, vm) if (want_last or stems_compact) else None,
+                                 sparse_for_bank=(P, vm) if to_bank else None)
     additive_last = None
     if surrogate and compact:
         additive_mix = core.polyphonic_additive(ctl['f0_hz'], ctl['amplitudes'].reshape(R, T),

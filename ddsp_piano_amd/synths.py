@@ -35,12 +35,16 @@ class InHarmonic(Processor):
         return int(self.sample_rate / self.frame_rate)               # :163-165
 
     def _controls(self, amplitudes, harmonic_distribution, inharm_coef, f0_hz, want_counts=False, want_shifts=True,
-                  last_voice_of=None):
+                  last_voice_of=None, sparse_for_bank=None):
         """One fused kernel for :183-214 (+ :269); f0_hz may carry several sub-strings.
         want_shifts=False: 'harmonic_shifts' is left out (the compacted oscillator bank forms it from inharm_coef per
         lane and frame, a [R, T, H] tensor less to write and read back); '_inharm_coef' carries the raw coefficients.
         last_voice_of=(n_voices, voice_major) with want_shifts=False: '_shifts_last' [rows / n_voices, T, H] holds the
-        harmonic_shifts of every segment's last voice (what the reference's outputs dictionary keeps)."""
+        harmonic_shifts of every segment's last voice (what the reference's outputs dictionary keeps).
+        sparse_for_bank=(n_voices, voice_major) (round 6; with want_counts and want_shifts=False): the caller's only reader
+        of 'harmonic_distribution' is the compacted oscillator bank, which takes harmonics at or above a frame's audible
+        count as silent from the count: those values are not written (ddspp_inharmonic_controls_sparse) -- except for
+        every segment's last voice when last_voice_of is given.  The tensor is then NOT valid for any other reader."""
         amplitudes = core.tf_float32(amplitudes)
         harmonic_distribution = core.tf_float32(harmonic_distribution)
         inharm_coef = core.tf_float32(inharm_coef)
@@ -65,12 +69,16 @@ class InHarmonic(Processor):
         shifts_out = torch.empty_like(harmonic_distribution) if want_shifts else None
         counts = torch.empty((b, t), dtype=torch.int32, device=amplitudes.device) if want_counts else None
         shifts_last = None
-        if last_voice_of is not None and not want_shifts:
-            n_voices, voice_major = last_voice_of
-            shifts_last = torch.empty((b // n_voices, t, h), dtype=torch.float32, device=amplitudes.device)
-            _lib.check(_lib_().ddspp_inharmonic_controls_group(
+        if (last_voice_of is not None or sparse_for_bank is not None) and not want_shifts:
+            n_voices, voice_major = last_voice_of if last_voice_of is not None else sparse_for_bank
+            if last_voice_of is not None:
+                shifts_last = torch.empty((b // n_voices, t, h), dtype=torch.float32, device=amplitudes.device)
+            entry = _lib_().ddspp_inharmonic_controls_sparse if (sparse_for_bank is not None and counts is not None) \
+                else _lib_().ddspp_inharmonic_controls_group
+            _lib.check(entry(
                 _ptr(amplitudes), _ptr(harmonic_distribution), _ptr(inharm_coef), _ptr(f0_hz), _ptr(amp_out),
-                _ptr(hd_out), _ptr(shifts_last), counts.data_ptr() if counts is not None else None, b, t, h, s,
+                _ptr(hd_out), _ptr(shifts_last) if shifts_last is not None else None,
+                counts.data_ptr() if counts is not None else None, b, t, h, s,
                 int(n_voices), int(bool(voice_major)), float(self.sample_rate), float(self.min_frequency),
                 code, prm['exponent'], prm['max_value'], prm['threshold'], prm['gain'],
                 int(bool(self.normalize_after_nyquist_cut)), int(bool(self.normalize_below_nyquist)), _stream()))
@@ -271,12 +279,17 @@ class FilteredNoise(Processor):
         call = next(self._calls)
         return core.uniform_noise((batch_size, n_samples), seed=self.seed, offset=call << 40, device=device, out=out)
 
+    def draw_noise_lazy(self, batch_size, n_samples, device):
+        """The same draw as draw_noise (same call counter, same numbers), left to the filter kernel (core.DrawnNoise)."""
+        call = next(self._calls)
+        return core.DrawnNoise(batch_size, n_samples, self.seed, call << 40, device)
+
     def get_signal(self, magnitudes, noise=None):
         magnitudes = core.tf_float32(magnitudes)
         batch_size = int(magnitudes.shape[0])
         n_samples = self._n_samples(magnitudes)
         if noise is None:
-            noise = self.draw_noise(batch_size, n_samples, magnitudes.device)
+            noise = self.draw_noise_lazy(batch_size, n_samples, magnitudes.device)
         else:
             noise = core.tf_float32(noise)
             if tuple(noise.shape) != (batch_size, n_samples):

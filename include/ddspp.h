@@ -155,7 +155,9 @@ int ddspp_surrogate_harmonic_synthesis(const float* f0_hz, const float* amplitud
  * harmonic_shifts NULL and inharm_coef[R,T] given (the raw get_controls input): the kernels form
  * harmonic_shifts = sqrt(k^2 max(inharm_coef, 0) + 1) - 1 (get_inharmonic_freq, inharm_synth.py:37-44) per lane and
  * frame -- bit for bit what ddspp_inharmonic_controls writes -- and the [R,T,H] tensor need not exist.
- * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.
+ * audible[R,T] (may be NULL): ddspp_inharmonic_controls' per-frame count of leading non-silent harmonics.  When given, a
+ * harmonic at or above its frame's count is taken as silent from the count (its amplitude product is zero by definition)
+ * and harmonic_distribution is not trusted there (ddspp_inharmonic_controls_sparse leaves it unwritten).
  * phase_state_in[R, S*H] (may be NULL): streaming -- these controls continue a signal; every oscillator starts from the
  * float32 running sum of chunk end phases the previous call left (ddspp_oscillator_phase_state).  The call must start
  * on a 1000-sample chunk boundary of the whole signal (a multiple of lcm(U, 1000) / U frames), and wlin then holds the
@@ -248,6 +250,23 @@ int ddspp_inharmonic_controls_group(const float* amplitudes, const float* harmon
                                     float min_frequency, int scale_kind, float exponent, float max_value,
                                     float threshold, float gain, int normalize_after_nyquist_cut,
                                     int normalize_below_nyquist, hipStream_t stream);
+
+/* ddspp_inharmonic_controls_group for a caller whose ONLY reader of harmonic_distribution_out is the compacted oscillator
+ * bank (ddspp_polyphonic_additive / ddspp_polyphonic_stems / ddspp_polyphonic_surrogate_additive called with `audible` =
+ * audible_out, which is required here).  A frame's row is written only below its audible count, in whole groups of 16
+ * harmonics: every value left out is one whose product with amplitudes_out is exactly zero (that is what the count
+ * means), and the bank takes those harmonics as silent from the count itself.  Rows of every segment's last voice are
+ * written whole when shifts_last_out is given (the outputs dictionary keeps that voice's controls).  What is not written
+ * keeps whatever the buffer held: harmonic_distribution_out is then NOT a valid tensor for any other reader.  At a
+ * piano's note mix two thirds of the [R,T,H] write disappear (InHarmonic.get_controls, inharm_synth.py:200-214, zeroes
+ * them).  Shapes or flags the lean kernel does not take are written whole, which is always valid. */
+int ddspp_inharmonic_controls_sparse(const float* amplitudes, const float* harmonic_distribution,
+                                     const float* inharm_coef, const float* f0_hz, float* amplitudes_out,
+                                     float* harmonic_distribution_out, float* shifts_last_out, int* audible_out,
+                                     int R, int T, int H, int S, int n_voices, int voice_major, float sample_rate,
+                                     float min_frequency, int scale_kind, float exponent, float max_value,
+                                     float threshold, float gain, int normalize_after_nyquist_cut,
+                                     int normalize_below_nyquist, hipStream_t stream);
 
 /* ddsp.synths.FilteredNoise.get_controls: y = scale_fn(x + initial_bias), elementwise. */
 int ddspp_scale_bias(const float* x, float* y, size_t n, float bias, int scale_kind, float exponent,
@@ -364,6 +383,19 @@ int ddspp_frequency_filter_eo_voices(const float* audio, const float* magnitudes
                                      int scale_kind, float bias, float exponent, float max_value, float threshold,
                                      float gain, int n_voices, int voices_per_row, int voice_major,
                                      hipStream_t stream);
+/* DynamicSizeFilteredNoise.get_signal with its own draw (filtered_noise_synth.py:39-42: tf.random.uniform, then
+ * frequency_filter) in ONE kernel: the windowed kernel draws the U(-1, 1) numbers it filters while staging them --
+ * exactly the ones ddspp_uniform_noise(buf, R * N, seed, offset) would have written into a [R, N] tensor (same
+ * Philox4x32-10 counters, same bits), which then never exists (config 3: 0.29 GB written and read back per step).
+ * Everything else as ddspp_frequency_filter_eo_voices (voices_per_row = 1, n_voices = 1: plain rows).
+ * ddspp_frequency_filter_eo_drawn_supported: the shapes of the windowed kernel (every shipped hop / band count). */
+int ddspp_frequency_filter_eo_drawn_supported(int N, int T, int K, int Lw, int delay_compensation);
+int ddspp_frequency_filter_eo_voices_drawn(uint64_t seed, uint64_t offset, const float* magnitudes, const float* CE,
+                                           const float* CO, const int* tap_idx, const float* tap_we, const float* tap_wo,
+                                           float* out, float* out_last, int R, int N, int T, int K, int Lw, int NJ,
+                                           int delay_compensation, int scale_kind, float bias, float exponent,
+                                           float max_value, float threshold, float gain, int n_voices, int voices_per_row,
+                                           int voice_major, hipStream_t stream);
 
 /* NoiseBandNetSynth.get_signal -- filtered_noise_synth.py:213-262: audio[r, n] = sum_k noise_bands[(n mod noise_len
  * - shift) mod noise_len, k] * amplitude_k(n), amplitude_k(n) = the chunk-wise ddsp.core.resample(method='linear') of

@@ -874,3 +874,87 @@ def test_noise_voice_sums_equal_the_per_voice_rows(monkeypatch):
         gnoise.seed = 9
         outs.append(dp.ProcessorGroup(dag)(feats))
     assert (outs[0] - outs[1]).abs().max().item() < 5e-6
+
+
+def test_sparse_get_controls_feeds_the_bank_the_same_bits(monkeypatch):
+    """Round 6: on the compacted routes get_controls writes a frame's normalised harmonic_distribution only below the
+    frame's audible count, in whole groups of 16 (ddspp_inharmonic_controls_sparse); the bank takes everything at or above
+    the count as silent from the count.  Here the output buffer is POISONED with NaN first: what the kernel leaves out stays
+    NaN, what it writes equals the dense kernel's, the last voice's rows are whole, and the bank (mix, split mix, every
+    voice's stems; one and two sub-strings, both row orders) gives the dense route's audio bit for bit -- a NaN that reached
+    a lane would show.  Then the whole group with the switch DDSPP_CONTROLS_DENSE_HD=1 against the default."""
+    import ctypes
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import _lib, core
+    lib = _lib.load()
+    rng = np.random.default_rng(606)
+    for (B, P, T, H, S, sr, vm) in [(3, 16, 60, 128, 1, 24000, False), (2, 5, 40, 96, 2, 16000, True),
+                                    (4, 3, 50, 192, 1, 32000, False), (2, 6, 30, 48, 1, 8000, True)]:
+        U = sr // 250
+        N = T * U
+        R = B * P
+        raw = synth_controls(rng, R, T, H, S=S, silent_frac=0.3)
+        raw_t = [torch.as_tensor(raw[k], device='cuda').contiguous()       # (raw pointers below: numpy leaves the smoothed hd strided)
+                 for k in ('amplitudes', 'harmonic_distribution', 'inharm_coef', 'f0_hz')]
+        syn = dp.MultiInharmonic(sample_rate=sr, inference=True)
+        dense = syn._controls(*raw_t, want_counts=True, want_shifts=False, last_voice_of=(P, vm))
+        prm = core.scale_kind(syn.scale_fn)[1]
+        amp_s = torch.empty_like(dense['amplitudes'])
+        hd_s = torch.full_like(dense['harmonic_distribution'], float('nan'))
+        shl = torch.empty_like(dense['_shifts_last'])
+        cnt_s = torch.empty_like(dense['_audible'])
+        _lib.check(lib.ddspp_inharmonic_controls_sparse(
+            *[ctypes.c_void_p(x.data_ptr()) for x in raw_t], ctypes.c_void_p(amp_s.data_ptr()), ctypes.c_void_p(hd_s.data_ptr()),
+            ctypes.c_void_p(shl.data_ptr()), ctypes.c_void_p(cnt_s.data_ptr()), R, T, H, S, P, int(vm), float(sr),
+            float(syn.min_frequency), core.scale_kind(syn.scale_fn)[0], prm['exponent'], prm['max_value'], prm['threshold'],
+            prm['gain'], 1, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert torch.equal(cnt_s, dense['_audible']) and torch.equal(amp_s, dense['amplitudes'])
+        assert torch.equal(shl, dense['_shifts_last'])
+        cnt = (cnt_s & 0xffff).long()
+        keep = ((cnt + 15) // 16 * 16)[..., None]                          # a row is written in whole groups of 16
+        k = torch.arange(H, device='cuda')[None, None, :]
+        rows = torch.arange(R, device='cuda')
+        is_last = (rows >= (P - 1) * B) if vm else (rows % P == P - 1)
+        written = (k < keep) | is_last[:, None, None]
+        assert torch.equal(torch.isnan(hd_s), ~written)                     # nothing else was touched, nothing kept was left out
+        assert torch.equal(hd_s[written], dense['harmonic_distribution'][written])
+        assert float((~written).float().mean()) > 0.3                      # (the point: a good part of the tensor is never written)
+        amp = amp_s.reshape(R, T)
+        inh = raw_t[2].reshape(R, T).contiguous()
+        for spans in (0, 1, 5):
+            for split in (False, True):
+                a = core.polyphonic_additive(dense['f0_hz'], amp, dense['harmonic_distribution'], None, B, N, sr, spans=spans,
+                                             voice_major=vm, audible=cnt_s, split_last=split, inharm_coef=inh)
+                b = core.polyphonic_additive(dense['f0_hz'], amp, hd_s, None, B, N, sr, spans=spans, voice_major=vm,
+                                             audible=cnt_s, split_last=split, inharm_coef=inh)
+                for x, y in zip(a if split else (a,), b if split else (b,)):
+                    assert torch.equal(x, y) and bool(torch.isfinite(y).all()), (B, P, H, S, spans, split)
+                # ... and the counts change nothing when the tensor is whole (they only replace exact zeros)
+                c = core.polyphonic_additive(dense['f0_hz'], amp, dense['harmonic_distribution'], None, B, N, sr, spans=spans,
+                                             voice_major=vm, split_last=split, inharm_coef=inh)
+                for x, y in zip(a if split else (a,), c if split else (c,)):
+                    assert torch.equal(x, y), (B, P, H, S, spans, split)
+            a = core.polyphonic_stems(dense['f0_hz'], amp, dense['harmonic_distribution'], None, B, N, sr, spans=spans,
+                                      voice_major=vm, audible=cnt_s, inharm_coef=inh)
+            b = core.polyphonic_stems(dense['f0_hz'], amp, hd_s, None, B, N, sr, spans=spans, voice_major=vm, audible=cnt_s,
+                                      inharm_coef=inh)
+            assert torch.equal(a, b) and bool(torch.isfinite(b).all()), (B, P, H, S, spans)
+    # the whole group, every dictionary form, sparse (default) against dense
+    B, P, T, H, K, S, sr, L = 3, 6, 50, 128, 96, 1, 24000, 3000
+    N = T * (sr // 250)
+    feats = {k: torch.as_tensor(v, device='cuda') for k, v in _features(rng, B, P, T, H, K, S, L).items()}
+    nz = [torch.as_tensor(rng.uniform(-1, 1, [B, N]).astype(np.float32), device='cuda') for _ in range(P)]
+    gdag, _ = _build(dp, P, sr)
+    pg = dp.ProcessorGroup(gdag)
+    for stems in (False, 'last', True):
+        set_option(monkeypatch, 'DDSPP_CONTROLS_DENSE_HD', 1)
+        want = pg(feats, return_outputs_dict=True, need_stems=stems, noise=nz)
+        set_option(monkeypatch, 'DDSPP_CONTROLS_DENSE_HD', None)
+        got = pg(feats, return_outputs_dict=True, need_stems=stems, noise=nz)
+        assert torch.equal(got['signal'], want['signal']) and bool(torch.isfinite(got['signal']).all()), stems
+        if stems:
+            for kk, v in want['controls']['additive']['controls'].items():
+                assert torch.equal(got['controls']['additive']['controls'][kk], v), (stems, kk)
+            assert torch.equal(got['controls']['additive']['signal'], want['controls']['additive']['signal'])
+        if stems is True:
+            assert torch.equal(got['controls']['voices']['additive'], want['controls']['voices']['additive'])

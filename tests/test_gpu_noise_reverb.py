@@ -232,3 +232,67 @@ def test_fused_frequency_filter_equals_the_two_kernel_form(B, T, U, K, monkeypat
         set_option(monkeypatch, 'DDSPP_FIR_NO_FUSED')
         assert fused.shape == split.shape == (B, N)
         assert torch.equal(fused, split), (B, T, U, K, rs is not None)
+
+
+@pytest.mark.parametrize('R,T,U,K,P,vq,split,vm', [(3, 40, 96, 96, 1, 1, False, False), (16, 61, 96, 96, 8, 8, False, False),
+                                                   (16, 61, 96, 96, 8, 4, True, True), (32, 30, 96, 96, 16, 8, True, False),
+                                                   (4, 750, 96, 96, 2, 2, False, False), (6, 33, 64, 64, 3, 1, False, False),
+                                                   (8, 20, 128, 32, 4, 2, True, True), (4, 25, 192, 96, 2, 2, False, False),
+                                                   (4, 31, 128, 128, 4, 4, False, False), (5, 50, 32, 32, 1, 1, False, False)])
+def test_noise_drawn_inside_the_filter_kernel(R, T, U, K, P, vq, split, vm, monkeypatch):
+    """Round 6: without a `noise=` argument the windowed FilteredNoise kernel draws its U(-1, 1) numbers while staging them
+    (ddspp_frequency_filter_eo_voices_drawn) -- the Philox counters of their place in a [R, N] tensor, so the result is the
+    filter of ddspp_uniform_noise's tensor bit for bit, which never has to exist.  Every hop / band count the kernel has an
+    instance for, plain rows and voice sums, the last voice apart, both row orders, ragged windows (T no multiple of 30)."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core, _lib
+    rng = np.random.default_rng(R * 31 + T)
+    N = T * U
+    raw = torch.as_tensor(rng.normal(0, 2, [R, T, K]).astype(np.float32), device='cuda')
+    synth = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=250 * U, initial_bias=-3.0)
+    rs = synth.raw_scale()
+    assert _lib.load().ddspp_frequency_filter_eo_drawn_supported(N, T, K, 2 * (K - 1), -1) == 1
+    seed, off = 0x1234567, (5 << 40) + 12
+    lazy = core.DrawnNoise(R, N, seed, off, raw.device)
+    tensor = core.uniform_noise((R, N), seed=seed, offset=off, device=raw.device)
+    assert torch.equal(lazy.materialise(), tensor)
+    if P == 1:
+        a = (core.frequency_filter(lazy, raw, window_size=synth.window_size, raw_scale=rs),)
+        b = (core.frequency_filter(tensor, raw, window_size=synth.window_size, raw_scale=rs),)
+    else:
+        a = core.frequency_filter_voice_sums(lazy, raw, synth.window_size, rs, P, vq, vm, split_last=split)
+        b = core.frequency_filter_voice_sums(tensor, raw, synth.window_size, rs, P, vq, vm, split_last=split)
+        a, b = (a if split else (a,)), (b if split else (b,))
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y) and float(y.abs().max()) > 0
+    # the switch back (A/B): the tensor is drawn and read
+    set_option(monkeypatch, 'DDSPP_NOISE_NO_DRAW', 1)
+    assert _lib.load().ddspp_frequency_filter_eo_drawn_supported(N, T, K, 2 * (K - 1), -1) == 0
+    c = core.frequency_filter(lazy, raw, window_size=synth.window_size, raw_scale=rs)
+    set_option(monkeypatch, 'DDSPP_NOISE_NO_DRAW')
+    assert torch.equal(c, core.frequency_filter(tensor, raw, window_size=synth.window_size, raw_scale=rs))
+
+
+def test_processor_draws_the_same_numbers_either_way(monkeypatch):
+    """DynamicSizeFilteredNoise()(magnitudes) and the batched group without `noise=`: the call counter advances as before and the
+    audio equals the one made from the tensor the same (seed, call) would have drawn."""
+    import ddsp_piano_amd as dp
+    from ddsp_piano_amd import core
+    rng = np.random.default_rng(77)
+    B, T, K, sr = 3, 45, 96, 24000
+    raw = torch.as_tensor(rng.normal(0, 1, [B, T, K]).astype(np.float32), device='cuda')
+    g1 = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=sr)
+    g2 = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=sr)
+    g2.seed = g1.seed
+    for _ in range(2):
+        got = g1(raw)
+        noise = g2.draw_noise(B, T * 96, raw.device)
+        want = g2.get_signal(g2.get_controls(raw)['magnitudes'], noise=noise)
+        assert torch.equal(got, want)
+    # a shape the windowed kernel has no instance for (hop 80): the tensor is drawn, same numbers
+    g3 = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=20000)
+    g4 = dp.DynamicSizeFilteredNoise(frame_rate=250, sample_rate=20000)
+    g4.seed = g3.seed
+    got = g3(raw)
+    want = g4.get_signal(g4.get_controls(raw)['magnitudes'], noise=g4.draw_noise(B, T * 80, raw.device))
+    assert torch.equal(got, want)
