@@ -237,3 +237,22 @@ def test_group_driver_argument_errors(lib):
     assert _Config.reverb_keep_dry_tap.offset == 128
     assert ctypes.sizeof(_Config) == lib.ddspp_group_config_bytes()
     assert ctypes.sizeof(_Outputs) == lib.ddspp_group_outputs_bytes() == 8 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_round6_entry_points_refuse_what_they_cannot_do(lib):
+    """ddspp_inharmonic_controls_sparse needs the counts it tells its reader about; the drawn-noise filter exists only for the
+    shapes of the windowed kernel (host-side checks, no launch)."""
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(256)
+    rc = lib.ddspp_inharmonic_controls_sparse(one, one, one, one, one, one, null, null, 32, 750, 128, 1, 16, 0, 24000.0, 20.0, 1,
+                                              10.0, 2.0, 1e-7, 1.0, 1, 1, null)
+    assert rc == _lib.DDSPP_EINVAL and b'audible_out' in lib.ddspp_last_error()
+    assert lib.ddspp_frequency_filter_eo_drawn_supported(72000, 750, 96, 190, -1) == 1       # 24 kHz
+    assert lib.ddspp_frequency_filter_eo_drawn_supported(144000, 750, 96, 190, -1) == 1      # 48 kHz, hop 192
+    assert lib.ddspp_frequency_filter_eo_drawn_supported(30000, 750, 32, 62, -1) == 0        # hop 40: no windowed instance
+    rc = lib.ddspp_frequency_filter_eo_voices_drawn(1, 0, one, one, one, one, one, one, one, null, 4, 30000, 750, 32, 62, 16, -1, 1,
+                                                    -5.0, 10.0, 2.0, 1e-7, 1.0, 1, 1, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'windowed kernel' in lib.ddspp_last_error()
+    rc = lib.ddspp_frequency_filter_eo_voices_drawn(1, 0, null, one, one, one, one, one, one, null, 4, 72000, 750, 96, 190, 48, -1, 1,
+                                                    -5.0, 10.0, 2.0, 1e-7, 1.0, 1, 1, 0, null)
+    assert rc == _lib.DDSPP_EINVAL and b'null' in lib.ddspp_last_error()
