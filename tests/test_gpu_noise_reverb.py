@@ -296,3 +296,31 @@ def test_processor_draws_the_same_numbers_either_way(monkeypatch):
     got = g3(raw)
     want = g4.get_signal(g4.get_controls(raw)['magnitudes'], noise=g4.draw_noise(B, T * 80, raw.device))
     assert torch.equal(got, want)
+
+
+def test_philox_known_answers():
+    """The library's generator IS Philox4x32-10 (Salmon et al., SC'11): counter (0, 0, 0, 0) under key (0, 0) gives
+    6627e8d5 e169c58d bc57ac4c 9b00dbd8 (Random123's known-answer vector), reachable through ddspp_uniform_noise's
+    (offset, seed) = (counter words 0-1, key); a number is (word >> 8) 2^-23 - 1.  A plain-integer restatement of the ten
+    rounds, checked against that vector, then gives the expected words for a second (offset, seed).  Holds whichever
+    instruction sequence forms the 64-bit products (round 6: v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32)."""
+    from ddsp_piano_amd import core
+
+    def want(words):
+        return np.array([(w >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0) for w in words], dtype=np.float32)
+
+    got = core.uniform_noise((4,), seed=0, offset=0).cpu().numpy()
+    assert np.array_equal(got, want([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]))
+    # (counter words 2, 3 are always zero here, so Random123's other vectors are out of reach)
+    def philox(ctr, key):
+        c = [ctr & 0xffffffff, ctr >> 32, 0, 0]
+        k = [key & 0xffffffff, key >> 32]
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return c
+    assert philox(0, 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    seed, off = 0xa4093822299f31d0, 0x85a308d3243f6a88
+    got = core.uniform_noise((8,), seed=seed, offset=off).cpu().numpy()
+    assert np.array_equal(got, want(philox(off, seed) + philox(off + 1, seed)))
