@@ -12,9 +12,12 @@ cp $S/step_pmc_summary.txt profiles/r06_step_pmc.txt
 cp $S/step_valu.json $S/osc_traffic.json profiles/
 {
   echo "# tools/ubench probes of round 6 (tools/profile_r06.sh), one MI355X"
-  for f in osc_graded_spread osc_graded lds_stream store_cost resample_time; do
+  for f in osc_graded_spread osc_graded lds_stream store_cost resample_time philox_rates; do
     [ -f $S/$f.txt ] && { echo; echo "## $f"; cat $S/$f.txt; }
   done
+  echo; echo "## side stream A/B (DDSPP_SIDE_STREAM=1; bench.py --steps 40 --sustain-seconds 3: synchronised median, min, sustained, pipelined ms per step)"
+  [ -f gpurun_out/side_ab.log ] && grep "^\[" gpurun_out/side_ab.log | grep -v gpurun
+  echo; echo "## dense worst case without spans: profiles/r06_dense_ab.txt"
 } > profiles/r06_ubench.txt
 python - <<'PY'
 import json

@@ -34,5 +34,6 @@ done > $OUT/osc_graded_spread.txt
 ./tools/ubench/osc_graded 1024 5 > $OUT/osc_graded.txt 2>&1
 ./tools/ubench/lds_stream > $OUT/lds_stream.txt 2>&1
 ./tools/ubench/store_cost > $OUT/store_cost.txt 2>&1
+./tools/ubench/philox_rates > $OUT/philox_rates.txt 2>&1
 python tools/resample_time.py > $OUT/resample_time.txt 2>&1
 ls $OUT
